@@ -1,0 +1,226 @@
+/* pvtrace_hip.h — C ABI of the MI355X photon-tracing engine (libpvtrace_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of pvtrace: the native call
+ *     _kernel.trace_bundle(compiled, positions, directions, wavelengths, seed,
+ *                          maxsteps, max_events, emit_method, num_threads,
+ *                          record_every) -> dict
+ * (reference pvtrace/engine/_kernel.pyx:903-1115), which engine.simulate()
+ * (pvtrace/engine/api.py:197-246) wraps.  Plain pointers and sizes only; no
+ * torch / numpy / HIP types appear in any signature.  INTEGRATION.md shows the
+ * ctypes stub a pvtrace maintainer would add.
+ *
+ * Table layouts, dtypes and tag values are exactly the reference's
+ * CompiledScene (pvtrace/engine/compiler.py:25-50, :75-204) so the same arrays
+ * can be handed to either engine.  All matrices are row-major 4x4 doubles.
+ */
+#ifndef PVTRACE_HIP_H
+#define PVTRACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVT_ABI_VERSION 1
+
+/* limits (reference _kernel.pyx:65-68) */
+#define PVT_MAX_NODES 128
+#define PVT_MAX_RECORDERS 256
+#define PVT_MAX_HITS 512
+
+/* event codes == pvtrace.light.event.Event (reference light/event.py:7-16) */
+enum {
+    PVT_EV_GENERATE = 0, PVT_EV_REFLECT = 1, PVT_EV_TRANSMIT = 2, PVT_EV_ABSORB = 3,
+    PVT_EV_NONRADIATIVE = 4, PVT_EV_SCATTER = 5, PVT_EV_EMIT = 6, PVT_EV_EXIT = 7,
+    PVT_EV_REACT = 8, PVT_EV_KILL = 9
+};
+/* geometry / surface / component / phase / emit-method tags (compiler.py:25-48) */
+enum { PVT_GEOM_BOX = 0, PVT_GEOM_SPHERE = 1, PVT_GEOM_CYLINDER = 2 };
+enum { PVT_SURF_FRESNEL = 0, PVT_SURF_NULL = 1 };
+enum { PVT_COMP_ABSORBER = 0, PVT_COMP_SCATTERER = 1, PVT_COMP_LUMINOPHORE = 2, PVT_COMP_REACTOR = 3 };
+enum { PVT_PHASE_ISOTROPIC = 0, PVT_PHASE_HG = 1, PVT_PHASE_CONE = 2 };
+enum { PVT_EMIT_KT = 0, PVT_EMIT_REDSHIFT = 1, PVT_EMIT_FULL = 2 };
+/* recorder selectors (engine/recorder.py:45-53) */
+enum {
+    PVT_REC_ENTERING = 0, PVT_REC_ESCAPING = 1, PVT_REC_REFLECTED = 2, PVT_REC_LOST = 3,
+    PVT_REC_REACTED = 4, PVT_REC_KILLED = 5, PVT_REC_EXIT = 6
+};
+/* error codes (negative returns) */
+enum {
+    PVT_OK = 0,
+    PVT_ERR_INVALID = -1,     /* bad argument; maps to ValueError            */
+    PVT_ERR_TOO_MANY_NODES = -2, /* > PVT_MAX_NODES; reference raises ValueError (_kernel.pyx:929-930) */
+    PVT_ERR_HIP = -3,         /* HIP runtime failure; see pvt_last_error()   */
+    PVT_ERR_NO_DEVICE = -4
+};
+
+/* ---- scene tables: HOST pointers, read once by pvt_scene_create ---------
+ * Field-for-field the attributes _kernel.trace_bundle reads off `compiled`
+ * (_kernel.pyx:933-1017), plus the coating extension (coat_*), which the
+ * reference engine has no counterpart for (its compiler rejects non-Fresnel
+ * delegates, compiler.py:237-247).  n_coatings may be 0 with NULL coat_* rows. */
+typedef struct PvtSceneTables {
+    int32_t n_nodes, root_id, n_components, n_abs, n_ems;
+    int32_t n_recorders, n_hists, total_bins, n_coatings, reserved0;
+    /* per node */
+    const int32_t* geom_type;
+    const double* geom_params;      /* (n_nodes,4) box: sx,sy,sz  sphere: r  cyl: length, radius */
+    const double* local_to_world;   /* (n_nodes,4,4) */
+    const double* world_to_local;   /* (n_nodes,4,4) */
+    const double* refractive_index;
+    const int32_t* surface_type;
+    const int32_t* comp_start;
+    const int32_t* comp_count;
+    const int32_t* coat_start;
+    const int32_t* coat_count;
+    /* per component */
+    const int32_t* comp_type;
+    const double* comp_qy;
+    const double* comp_tau_rad;
+    const double* comp_tau_nr;
+    const int32_t* comp_phase_type;
+    const double* comp_phase_param;
+    const int32_t* comp_abs_start;
+    const int32_t* comp_abs_n;
+    const int32_t* comp_ems_start;
+    const int32_t* comp_ems_n;
+    /* pooled spectra */
+    const double* abs_x;            /* (n_abs) */
+    const double* abs_y;
+    const double* ems_x;            /* (n_ems) */
+    const double* ems_cdf;
+    /* recorders */
+    const int32_t* rec_node;
+    const int32_t* rec_event;
+    const int32_t* rec_has_facet;
+    const double* rec_facet;        /* (max(n_recorders,1),3) */
+    const double* rec_atol;
+    const int32_t* rec_hist_start;
+    const int32_t* rec_hist_n;
+    /* histograms */
+    const int32_t* hist_prop_a;
+    const int32_t* hist_prop_b;     /* -1: 1-D */
+    const int32_t* hist_na;
+    const int32_t* hist_nb;
+    const double* hist_lo_a;
+    const double* hist_hi_a;
+    const double* hist_lo_b;
+    const double* hist_hi_b;
+    const int32_t* hist_offset;
+    /* coatings (extension) */
+    const double* coat_facet;       /* (n_coatings,3) local-frame outward normal */
+    const double* coat_lo;          /* (n_coatings,3) open local AABB, -inf/inf = unbounded */
+    const double* coat_hi;
+    const double* coat_reflectivity;/* <0: keep Fresnel */
+    const int32_t* coat_reflect_mode;   /* 0 specular, 1 lambertian */
+    const int32_t* coat_transmit_mode;  /* 0 Fresnel refraction, 1 index matched */
+} PvtSceneTables;
+
+/* ---- optional device-side emission (replaces the Python/numpy emitter,
+ * reference pvtrace/engine/emit.py:22-134).  Ray i is emitted by light
+ * i % n_lights (scene.emit round-robin, scene/scene.py:141-151) from its own
+ * RNG stream keyed by (emit_seed, global ray index).                        */
+enum { PVT_WL_CONSTANT = 0, PVT_WL_SPECTRUM = 1 };
+enum { PVT_POS_POINT = 0, PVT_POS_RECT = 1, PVT_POS_CIRCLE = 2, PVT_POS_CUBE = 3 };
+enum { PVT_DIR_Z = 0, PVT_DIR_CONE = 1, PVT_DIR_ISOTROPIC = 2, PVT_DIR_LAMBERTIAN = 3, PVT_DIR_HG = 4 };
+typedef struct PvtEmitterTables {
+    int32_t n_lights, n_spec;
+    const int32_t* wl_type;
+    const double* wl_value;         /* constant wavelength (nm) */
+    const int32_t* wl_spec_start;   /* into spec_x / spec_cdf */
+    const int32_t* wl_spec_n;
+    const int32_t* pos_type;
+    const double* pos_param;        /* (n_lights,3) half-extents / radius */
+    const int32_t* dir_type;
+    const double* dir_param;        /* theta_max or g */
+    const double* light_to_world;   /* (n_lights,4,4) */
+    const double* spec_x;           /* pooled inverse-CDF tables */
+    const double* spec_cdf;
+} PvtEmitterTables;
+
+typedef struct PvtTraceParams {
+    int64_t n_rays;         /* rays in this bundle                                   */
+    uint64_t seed;          /* ray i traces with RNG stream seed + ray_offset + i    */
+    uint64_t ray_offset;    /* global index of ray 0 (bundle streaming / GPU shard)  */
+    uint64_t emit_seed;     /* device emission only                                  */
+    int64_t record_every;   /* every k-th ray keeps a full history; 0 = none         */
+    int32_t maxsteps;
+    int32_t max_events;
+    int32_t emit_method;    /* PVT_EMIT_*                                            */
+    int32_t reserved;
+} PvtTraceParams;
+
+/* initial rays, world frame (exactly trace_bundle's three array arguments) */
+typedef struct PvtRays {
+    const double* position;   /* (n,3) */
+    const double* direction;  /* (n,3) */
+    const double* wavelength; /* (n)   */
+} PvtRays;
+
+/* recorder accumulators; the trace ADDS into them (caller zeroes) */
+typedef struct PvtTallies {
+    int64_t* rec_distinct;   /* (n_recorders)       */
+    int64_t* rec_crossings;  /* (n_recorders)       */
+    double* rec_sums;        /* (n_recorders,4,2)   */
+    int64_t* rec_bins;       /* (total_bins)        */
+} PvtTallies;
+
+/* event log: rows = ceil(n/record_every)*max_events; row of event k of
+ * recorded ray j is j*max_events+k (same packing as _kernel.pyx:1035-1047).
+ * pvt_trace_* pre-fills kind/position/... with 0 and the id columns with -1. */
+typedef struct PvtEventLog {
+    int32_t* counts;         /* (n_recorded) */
+    uint8_t* kind;
+    int32_t* hit;
+    int32_t* container;
+    int32_t* adjacent;
+    int32_t* component;
+    int32_t* source;
+    double* position;        /* (rows,3) */
+    double* direction;       /* (rows,3) */
+    double* normal;          /* (rows,3) */
+    double* wavelength;
+    double* travelled;
+    double* duration;
+} PvtEventLog;
+
+typedef struct PvtScene PvtScene;   /* opaque: tables resident in HBM on one GPU */
+
+int pvt_abi_version(void);
+const char* pvt_last_error(void);
+int pvt_device_count(void);
+
+/* Pack the tables and upload them once to `device`. */
+int pvt_scene_create(const PvtSceneTables* tables, int device, PvtScene** out);
+/* Attach / replace the device-side emitter of a scene (optional). */
+int pvt_scene_set_emitter(PvtScene* scene, const PvtEmitterTables* emitter);
+void pvt_scene_destroy(PvtScene* scene);
+
+/* Device-resident entry: every pointer in rays / tallies / log is a DEVICE
+ * pointer owned by the caller (e.g. torch tensors) on the scene's GPU;
+ * `stream` is a hipStream_t (NULL = default stream).  rays == NULL selects
+ * device-side emission.  log may be NULL when record_every == 0.
+ * Asynchronous: returns after enqueueing. */
+int pvt_trace_device(PvtScene* scene, const PvtRays* rays, const PvtTraceParams* params,
+                     const PvtTallies* tallies, const PvtEventLog* log, void* stream);
+
+/* Host-buffer entry — the literal replacement for _kernel.trace_bundle: all
+ * pointers are HOST memory; uploads, traces, downloads, synchronises.
+ * `kernel_ms` (nullable) receives the HIP-event time of the trace kernel. */
+int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitter,
+                     const PvtRays* rays, const PvtTraceParams* params,
+                     const PvtTallies* tallies, const PvtEventLog* log, int device,
+                     double* kernel_ms);
+
+/* Device emission only (fills caller-owned DEVICE arrays); used by tests. */
+int pvt_emit_device(PvtScene* scene, const PvtTraceParams* params, double* position,
+                    double* direction, double* wavelength, void* stream);
+
+/* Launch geometry actually used by the last trace on this scene (diagnostics). */
+int pvt_scene_launch_info(PvtScene* scene, int32_t* grid, int32_t* block, int32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVTRACE_HIP_H */

@@ -1,0 +1,788 @@
+/* pvt_oracle.c — CPU restatement of the reference photon tracer.
+ *
+ * TEST INFRASTRUCTURE.  Nothing under pvtrace_amd/ (the product) imports,
+ * links or executes this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg do, and only as the checker / CPU baseline.
+ *
+ * It restates, function by function, the reference's native kernel
+ * /root/reference/pvtrace/engine/_kernel.pyx (each function cites the lines it
+ * follows).  Parity status: PINNED — tests/test_oracle_vs_reference.py and the
+ * fixtures under tests/golden/ (made by tests/golden/make_golden.py from the
+ * reference kernel itself, driven with the same tables/rays/seed) require
+ * bit-identical event logs and tallies in math_mode 0.
+ *
+ * Two math modes:
+ *   0  libm      sin/cos/log/asin/acos from the host libm, as the reference
+ *                kernel uses (_kernel.pyx:16-26) -> bit-identical to it here.
+ *   1  portable  the same code path with pvtrace_amd/csrc/pvt_math.h, the
+ *                bit-reproducible functions the HIP kernel uses -> bit-identical
+ *                to the GPU.  The two modes differ by <= 1 ulp per call.
+ *
+ * Two things go beyond the reference kernel and are marked EXTENSION:
+ * declarative surface coatings (coat_* tables; semantics restated from the
+ * Python delegates in pvtrace/device/lsc.py:22-86 and examples/006
+ * Coatings.ipynb cell 3 — parity for these is UNPINNED against the reference
+ * engine, which cannot express them) and device-style emission
+ * (pvt_oracle_emit; distributions from pvtrace/engine/emit.py:22-89).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fopenmp -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/pvtrace_hip.h"
+#include "../pvtrace_amd/csrc/pvt_math.h"
+
+/* _kernel.pyx:28-34 */
+#define EPS 2.220446049250313e-13
+#define ALPHA_ZERO 1e-8
+#define C_CM_PER_S 2.99792458e10
+static const double KB_EV = 1.380649e-23 / 1.60217662e-19;
+
+typedef struct { int mode; } MathSel;
+static inline double m_log(const MathSel* m, double x) { return m->mode ? pvt_log(x) : log(x); }
+static inline double m_sin(const MathSel* m, double x) { return m->mode ? pvt_sin(x) : sin(x); }
+static inline double m_cos(const MathSel* m, double x) { return m->mode ? pvt_cos(x) : cos(x); }
+static inline double m_asin(const MathSel* m, double x) { return m->mode ? pvt_asin(x) : asin(x); }
+static inline double m_acos(const MathSel* m, double x) { return m->mode ? pvt_acos(x) : acos(x); }
+
+/* ---- RNG: splitmix64-seeded xoshiro256+ (_kernel.pyx:75-113) ------------ */
+typedef struct { uint64_t s0, s1, s2, s3; } Rng;
+
+static inline uint64_t splitmix64(uint64_t* state) {
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline void rng_seed(Rng* r, uint64_t seed) {
+    uint64_t st = seed;
+    r->s0 = splitmix64(&st); r->s1 = splitmix64(&st);
+    r->s2 = splitmix64(&st); r->s3 = splitmix64(&st);
+}
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline double rng_uniform(Rng* r) {
+    uint64_t result = r->s0 + r->s3;
+    uint64_t t = r->s1 << 17;
+    r->s2 ^= r->s0; r->s3 ^= r->s1; r->s1 ^= r->s2; r->s0 ^= r->s3;
+    r->s2 ^= t; r->s3 = rotl64(r->s3, 45);
+    return (double)(result >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* ---- small helpers (_kernel.pyx:203-238) -------------------------------- */
+static inline double dot3(const double* a, const double* b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+static inline void xform_point(const double* m, const double* p, double* out) {
+    for (int i = 0; i < 3; i++)
+        out[i] = m[i * 4] * p[0] + m[i * 4 + 1] * p[1] + m[i * 4 + 2] * p[2] + m[i * 4 + 3];
+}
+static inline void xform_vector(const double* m, const double* v, double* out) {
+    for (int i = 0; i < 3; i++)
+        out[i] = m[i * 4] * v[0] + m[i * 4 + 1] * v[1] + m[i * 4 + 2] * v[2];
+}
+/* np.interp-like clamped linear interpolation (_kernel.pyx:219-238) */
+static double interp_clamped(double x, const double* xs, const double* ys, int n) {
+    if (n == 1) return ys[0];
+    if (x <= xs[0]) return ys[0];
+    if (x >= xs[n - 1]) return ys[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xs[mid] <= x) lo = mid; else hi = mid;
+    }
+    if (xs[hi] == xs[lo]) return ys[lo];
+    return ys[lo] + (ys[hi] - ys[lo]) * (x - xs[lo]) / (xs[hi] - xs[lo]);
+}
+
+/* ---- intersections in the local frame (_kernel.pyx:245-356) ------------- */
+static int hit_box(const double* size, const double* o, const double* d, double* ts) {
+    double tmin = -INFINITY, tmax = INFINITY;
+    for (int a = 0; a < 3; a++) {
+        double lo = -0.5 * size[a], hi = 0.5 * size[a];
+        if (fabs(d[a]) < 1e-300) {
+            if (o[a] < lo || o[a] > hi) return 0;
+        } else {
+            double inv = 1.0 / d[a];
+            double t1 = (lo - o[a]) * inv, t2 = (hi - o[a]) * inv;
+            if (t1 > t2) { double tmp = t1; t1 = t2; t2 = tmp; }
+            if (t1 > tmin) tmin = t1;
+            if (t2 < tmax) tmax = t2;
+        }
+    }
+    if (tmax < tmin) return 0;
+    int n = 0;
+    if (tmin > EPS) ts[n++] = tmin;
+    if (tmax > EPS) ts[n++] = tmax;
+    return n;
+}
+static int hit_sphere(const double* prm, const double* o, const double* d, double* ts) {
+    double radius = prm[0];
+    double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return 0;
+    double sq = sqrt(disc);
+    int n = 0;
+    double t = (-b - sq) / (2.0 * a);
+    if (t > EPS) ts[n++] = t;
+    t = (-b + sq) / (2.0 * a);
+    if (t > EPS) ts[n++] = t;
+    return n;
+}
+static int hit_cylinder(const double* prm, const double* o, const double* d, double* ts) {
+    double half = 0.5 * prm[0], radius = prm[1];
+    double a = d[0] * d[0] + d[1] * d[1];
+    double cand[4];
+    int nc = 0;
+    if (a > 1e-300) {
+        double b = 2.0 * (o[0] * d[0] + o[1] * d[1]);
+        double c = o[0] * o[0] + o[1] * o[1] - radius * radius;
+        double disc = b * b - 4.0 * a * c;
+        if (disc >= 0.0) {
+            double sq = sqrt(disc);
+            double t = (-b - sq) / (2.0 * a);
+            double z = o[2] + t * d[2];
+            if (z > -half && z < half) cand[nc++] = t;
+            t = (-b + sq) / (2.0 * a);
+            z = o[2] + t * d[2];
+            if (z > -half && z < half) cand[nc++] = t;
+        }
+    }
+    if (fabs(d[2]) > 1e-300) {
+        double t = (-half - o[2]) / d[2];
+        double x = o[0] + t * d[0], y = o[1] + t * d[1];
+        if (x * x + y * y <= radius * radius) cand[nc++] = t;
+        t = (half - o[2]) / d[2];
+        x = o[0] + t * d[0]; y = o[1] + t * d[1];
+        if (x * x + y * y <= radius * radius) cand[nc++] = t;
+    }
+    int n = 0;
+    for (int i = 0; i < nc; i++)
+        if (cand[i] > EPS) ts[n++] = cand[i];
+    return n;
+}
+static int hit_node(const PvtSceneTables* S, int node, const double* o, const double* d, double* ts) {
+    const double* prm = S->geom_params + node * 4;
+    switch (S->geom_type[node]) {
+        case PVT_GEOM_BOX: return hit_box(prm, o, d, ts);
+        case PVT_GEOM_SPHERE: return hit_sphere(prm, o, d, ts);
+        default: return hit_cylinder(prm, o, d, ts);
+    }
+}
+
+/* outward normal at local point p (_kernel.pyx:359-400) */
+static void local_normal(const PvtSceneTables* S, int node, const double* p, double* out) {
+    const double* prm = S->geom_params + node * 4;
+    int g = S->geom_type[node];
+    if (g == PVT_GEOM_BOX) {
+        double best = INFINITY;
+        int best_axis = 0, best_sign = 1;
+        for (int a = 0; a < 3; a++)
+            for (int sign = -1; sign < 2; sign += 2) {
+                double dist = fabs(p[a] - sign * 0.5 * prm[a]);
+                if (dist < best) { best = dist; best_axis = a; best_sign = sign; }
+            }
+        out[0] = out[1] = out[2] = 0.0;
+        out[best_axis] = (double)best_sign;
+    } else if (g == PVT_GEOM_SPHERE) {
+        double mag = sqrt(dot3(p, p));
+        out[0] = p[0] / mag; out[1] = p[1] / mag; out[2] = p[2] / mag;
+    } else {
+        double half = 0.5 * prm[0];
+        if (fabs(p[2] + half) <= 1e-8 + 1e-5 * fabs(half)) {
+            out[0] = 0.0; out[1] = 0.0; out[2] = -1.0;
+        } else if (fabs(p[2] - half) <= 1e-8 + 1e-5 * fabs(half)) {
+            out[0] = 0.0; out[1] = 0.0; out[2] = 1.0;
+        } else {
+            double r = sqrt(p[0] * p[0] + p[1] * p[1]);
+            out[0] = p[0] / r; out[1] = p[1] / r; out[2] = 0.0;
+        }
+    }
+}
+
+/* ---- optics (_kernel.pyx:406-476) --------------------------------------- */
+static double fresnel_reflectivity(const MathSel* M, double angle, double n1, double n2) {
+    if (n2 < n1 && angle > m_asin(M, n2 / n1)) return 1.0;
+    double c = m_cos(M, angle), s = m_sin(M, angle);
+    double q = n1 / n2 * s;
+    double k = sqrt(1.0 - q * q);
+    double rs1 = n1 * c - n2 * k, rs2 = n1 * c + n2 * k;
+    double rs = (rs1 / rs2) * (rs1 / rs2);
+    double rp1 = n1 * k - n2 * c, rp2 = n1 * k + n2 * c;
+    double rp = (rp1 / rp2) * (rp1 / rp2);
+    return 0.5 * (rs + rp);
+}
+static void specular_reflect(const double* d, const double* normal, double* out) {
+    double n[3] = {normal[0], normal[1], normal[2]};
+    if (dot3(n, d) < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    double dd = dot3(n, d);
+    for (int i = 0; i < 3; i++) out[i] = d[i] - 2.0 * dd * n[i];
+}
+/* `normal` already flipped to point along d */
+static void fresnel_refract(const double* d, const double* normal, double n1, double n2, double* out) {
+    double n = n1 / n2;
+    double dd = dot3(d, normal);
+    double c = sqrt(1.0 - n * n * (1.0 - dd * dd));
+    double sign = dd < 0.0 ? -1.0 : 1.0;
+    for (int i = 0; i < 3; i++) out[i] = n * d[i] + sign * (c - sign * n * dd) * normal[i];
+}
+static void sphere_direction(const MathSel* M, double theta, double phi, double* out) {
+    out[0] = m_sin(M, theta) * m_cos(M, phi);
+    out[1] = m_sin(M, theta) * m_sin(M, phi);
+    out[2] = m_cos(M, theta);
+}
+static void sample_phase(const MathSel* M, int type, double param, Rng* rng, double* out) {
+    double theta, phi;
+    if (type == PVT_PHASE_HG && fabs(param) >= EPS) {
+        double g = param;
+        double g1 = rng_uniform(rng);
+        double s = 2.0 * g1 - 1.0;
+        double q = (1.0 - g * g) / (1.0 + g * s);
+        double mu = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
+        phi = 2.0 * M_PI * rng_uniform(rng);
+        theta = m_acos(M, mu);
+    } else if (type == PVT_PHASE_CONE) {
+        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+        theta = m_asin(M, sqrt(g1) * m_sin(M, param));
+        phi = 2.0 * M_PI * g2;
+    } else {
+        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+        phi = 2.0 * M_PI * g1;
+        theta = m_acos(M, 2.0 * g2 - 1.0);
+    }
+    sphere_direction(M, theta, phi, out);
+}
+
+/* ---- recorders (_kernel.pyx:482-556) ------------------------------------ */
+typedef struct { int64_t* distinct; int64_t* cross; double* sums; int64_t* bins; } Acc;
+
+static inline double prop_value(int prop, double wl, double angle, double duration,
+                                double travelled, const double* lpos) {
+    switch (prop) {
+        case 0: return wl;
+        case 1: return angle;
+        case 2: return duration;
+        case 3: return travelled;
+        case 4: return lpos[0];
+        case 5: return lpos[1];
+        default: return lpos[2];
+    }
+}
+static void tally(const PvtSceneTables* S, Acc* A, int sel, int node, unsigned char* seen,
+                  const double* wnormal, const double* lpos, double angle, double wl,
+                  double travelled, double duration) {
+    for (int r = 0; r < S->n_recorders; r++) {
+        if (S->rec_node[r] != node || S->rec_event[r] != sel) continue;
+        if (S->rec_has_facet[r] != 0) {
+            if (wnormal == NULL) continue;
+            if (fabs(S->rec_facet[r * 3] - wnormal[0]) > S->rec_atol[r]) continue;
+            if (fabs(S->rec_facet[r * 3 + 1] - wnormal[1]) > S->rec_atol[r]) continue;
+            if (fabs(S->rec_facet[r * 3 + 2] - wnormal[2]) > S->rec_atol[r]) continue;
+        }
+        A->cross[r] += 1;
+        if (seen[r]) continue;
+        seen[r] = 1;
+        A->distinct[r] += 1;
+        double* s = A->sums + r * 8;
+        s[0] += wl; s[1] += wl * wl;
+        s[2] += angle; s[3] += angle * angle;
+        s[4] += duration; s[5] += duration * duration;
+        s[6] += travelled; s[7] += travelled * travelled;
+        for (int h = S->rec_hist_start[r]; h < S->rec_hist_start[r] + S->rec_hist_n[r]; h++) {
+            double va = prop_value(S->hist_prop_a[h], wl, angle, duration, travelled, lpos);
+            int ia = (int)((va - S->hist_lo_a[h]) / (S->hist_hi_a[h] - S->hist_lo_a[h]) * S->hist_na[h]);
+            if (ia < 0 || ia >= S->hist_na[h]) continue;
+            if (S->hist_prop_b[h] < 0) {
+                A->bins[S->hist_offset[h] + ia] += 1;
+            } else {
+                double vb = prop_value(S->hist_prop_b[h], wl, angle, duration, travelled, lpos);
+                int ib = (int)((vb - S->hist_lo_b[h]) / (S->hist_hi_b[h] - S->hist_lo_b[h]) * S->hist_nb[h]);
+                if (ib < 0 || ib >= S->hist_nb[h]) continue;
+                A->bins[S->hist_offset[h] + ia * S->hist_nb[h] + ib] += 1;
+            }
+        }
+    }
+}
+
+/* ---- event log (_kernel.pyx:562-597) ------------------------------------ */
+static void record(const PvtEventLog* L, int max_events, long base, int* count, int kind, int hit,
+                   int container, int adjacent, int component, int source, const double* pos,
+                   const double* dir, const double* normal, double wl, double travelled,
+                   double duration) {
+    if (base < 0 || *count >= max_events) return;
+    long row = base + *count;
+    L->kind[row] = (uint8_t)kind;
+    L->hit[row] = hit; L->container[row] = container; L->adjacent[row] = adjacent;
+    L->component[row] = component; L->source[row] = source;
+    for (int i = 0; i < 3; i++) {
+        L->position[row * 3 + i] = pos[i];
+        L->direction[row * 3 + i] = dir[i];
+        L->normal[row * 3 + i] = normal ? normal[i] : 0.0;
+    }
+    L->wavelength[row] = wl; L->travelled[row] = travelled; L->duration[row] = duration;
+    *count += 1;
+}
+
+/* EXTENSION: first coating of node `hit` covering (local normal, local point), or -1 */
+static int find_coating(const PvtSceneTables* S, int hit, const double* nl, const double* pl) {
+    if (S->n_coatings <= 0) return -1;
+    int start = S->coat_start[hit], end = start + S->coat_count[hit];
+    for (int c = start; c < end; c++) {
+        int ok = 1;
+        for (int a = 0; a < 3 && ok; a++) {
+            double f = S->coat_facet[c * 3 + a];
+            if (fabs(nl[a] - f) > 1e-8 + 1e-5 * fabs(f)) ok = 0;
+            else if (!(pl[a] > S->coat_lo[c * 3 + a] && pl[a] < S->coat_hi[c * 3 + a])) ok = 0;
+        }
+        if (ok) return c;
+    }
+    return -1;
+}
+/* EXTENSION: cosine-weighted direction about unit vector m (local frame),
+ * Duff et al. orthonormal basis; for m = +z returns (sx, sy, sz) unchanged,
+ * which is what the reference's lambertian() delegate yields (material/utils.py:176-186). */
+static void lambertian_about(const MathSel* M, const double* m, Rng* rng, double* out) {
+    double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
+    double theta = m_asin(M, sqrt(p1));
+    double phi = 2.0 * M_PI * p2;
+    double s[3];
+    sphere_direction(M, theta, phi, s);
+    double sign = m[2] < 0.0 ? -1.0 : 1.0;
+    double a = -1.0 / (sign + m[2]);
+    double b = m[0] * m[1] * a;
+    double t1[3] = {1.0 + sign * m[0] * m[0] * a, sign * b, -sign * m[0]};
+    double t2[3] = {b, sign + m[1] * m[1] * a, -m[1]};
+    for (int i = 0; i < 3; i++) out[i] = s[0] * t1[i] + s[1] * t2[i] + s[2] * m[i];
+}
+
+/* ---- one photon (_kernel.pyx:603-897) ----------------------------------- */
+static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLog* L, int max_events,
+                     long base, Acc* A, double* pos, double* dir, double wl, uint64_t seed,
+                     int maxsteps, int emit_method) {
+    Rng rng;
+    int count = 0, nevents = 0, source = -1;
+    double travelled = 0.0, duration = 0.0;
+    unsigned char seen[PVT_MAX_RECORDERS];
+    double hit_t[PVT_MAX_HITS];
+    int hit_node_id[PVT_MAX_HITS];
+    int node_hits[PVT_MAX_NODES];
+    double node_min_t[PVT_MAX_NODES];
+    double lo[3], ld[3], lp[3], ts[8], nl[3], nrm[3], nf[3], nd[3];
+
+    memset(seen, 0, (size_t)(S->n_recorders > 0 ? S->n_recorders : 0));
+    rng_seed(&rng, seed);
+    record(L, max_events, base, &nevents, PVT_EV_GENERATE, -1, -1, -1, -1, source, pos, dir, NULL,
+           wl, travelled, duration);
+
+    for (;;) {
+        count += 1;
+        /* event budget for recorded rays only; no tally (:658-663) */
+        if (base >= 0 && nevents >= max_events - 1) {
+            record(L, max_events, base, &nevents, PVT_EV_KILL, -1, -1, -1, -1, source, pos, dir,
+                   NULL, wl, travelled, duration);
+            break;
+        }
+        /* intersect every node (:665-682) */
+        int nhits = 0;
+        for (int node = 0; node < S->n_nodes; node++) {
+            node_hits[node] = 0;
+            node_min_t[node] = INFINITY;
+            xform_point(S->world_to_local + node * 16, pos, lo);
+            xform_vector(S->world_to_local + node * 16, dir, ld);
+            int nl_ = hit_node(S, node, lo, ld, ts);
+            for (int k = 0; k < nl_; k++) {
+                if (nhits < PVT_MAX_HITS) { hit_t[nhits] = ts[k]; hit_node_id[nhits] = node; nhits++; }
+                node_hits[node] += 1;
+                if (ts[k] < node_min_t[node]) node_min_t[node] = ts[k];
+            }
+        }
+        if (nhits == 0) break;
+
+        /* nearest / second nearest, container, adjacent (:684-714) */
+        int first = 0;
+        for (int i = 1; i < nhits; i++) if (hit_t[i] < hit_t[first]) first = i;
+        int second = -1;
+        for (int i = 0; i < nhits; i++)
+            if (i != first && (second < 0 || hit_t[i] < hit_t[second])) second = i;
+        int hit = hit_node_id[first];
+        double t0 = hit_t[first];
+        int container, adjacent;
+        if (nhits == 1) {
+            container = hit; adjacent = -1;
+        } else {
+            container = -1;
+            double best = INFINITY;
+            for (int node = 0; node < S->n_nodes; node++)
+                if (node_hits[node] == 1 && node_min_t[node] < best) { best = node_min_t[node]; container = node; }
+            if (container < 0) container = hit;
+            adjacent = (container == hit) ? hit_node_id[second] : hit;
+        }
+
+        if (count > maxsteps) { /* :716-723 */
+            record(L, max_events, base, &nevents, PVT_EV_KILL, -1, container, -1, -1, source, pos,
+                   dir, NULL, wl, travelled, duration);
+            if (S->n_recorders > 0) {
+                xform_point(S->world_to_local + container * 16, pos, lp);
+                tally(S, A, PVT_REC_KILLED, container, seen, NULL, lp, 0.0, wl, travelled, duration);
+            }
+            break;
+        }
+        double n_container = S->refractive_index[container];
+
+        if (hit == S->root_id) { /* exit through the root boundary (:728-744) */
+            for (int i = 0; i < 3; i++) pos[i] = pos[i] + dir[i] * t0;
+            travelled += t0;
+            duration += t0 * n_container / C_CM_PER_S;
+            record(L, max_events, base, &nevents, PVT_EV_EXIT, hit, container, adjacent, -1, source,
+                   pos, dir, NULL, wl, travelled, duration);
+            if (S->n_recorders > 0) {
+                xform_point(S->world_to_local + hit * 16, pos, lp);
+                local_normal(S, hit, lp, nl);
+                xform_vector(S->local_to_world + hit * 16, nl, nrm);
+                double dd = fabs(dot3(nrm, dir));
+                if (dd > 1.0) dd = 1.0;
+                tally(S, A, PVT_REC_EXIT, hit, seen, nrm, lp, m_acos(M, dd), wl, travelled, duration);
+            }
+            break;
+        }
+
+        /* volume absorption (:746-760) */
+        int cbase = S->comp_start[container], ccount = S->comp_count[container];
+        double alpha = 0.0;
+        for (int k = 0; k < ccount; k++) {
+            int c = cbase + k;
+            alpha += interp_clamped(wl, S->abs_x + S->comp_abs_start[c], S->abs_y + S->comp_abs_start[c],
+                                    S->comp_abs_n[c]);
+        }
+        double depth = INFINITY;
+        if (alpha > ALPHA_ZERO) depth = -m_log(M, 1.0 - rng_uniform(&rng)) / alpha;
+
+        if (depth < t0) { /* absorbed (:762-832) */
+            for (int i = 0; i < 3; i++) pos[i] = pos[i] + dir[i] * depth;
+            travelled += depth;
+            duration += depth * n_container / C_CM_PER_S;
+            double target = rng_uniform(&rng) * alpha, running = 0.0;
+            int comp = cbase;
+            for (int k = 0; k < ccount; k++) {
+                running += interp_clamped(wl, S->abs_x + S->comp_abs_start[cbase + k],
+                                          S->abs_y + S->comp_abs_start[cbase + k], S->comp_abs_n[cbase + k]);
+                if (target <= running) { comp = cbase + k; break; }
+            }
+            record(L, max_events, base, &nevents, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
+                   dir, NULL, wl, travelled, duration);
+            int ctype = S->comp_type[comp];
+            if ((ctype == PVT_COMP_SCATTERER || ctype == PVT_COMP_LUMINOPHORE) &&
+                rng_uniform(&rng) < S->comp_qy[comp]) {
+                sample_phase(M, S->comp_phase_type[comp], S->comp_phase_param[comp], &rng, nd);
+                dir[0] = nd[0]; dir[1] = nd[1]; dir[2] = nd[2];
+                source = comp;
+                if (ctype == PVT_COMP_LUMINOPHORE) {
+                    const double* ax = S->ems_x + S->comp_ems_start[comp];
+                    const double* ay = S->ems_cdf + S->comp_ems_start[comp];
+                    int an = S->comp_ems_n[comp];
+                    double p1;
+                    if (emit_method == PVT_EMIT_FULL) {
+                        p1 = 0.0;
+                    } else {
+                        double e_nm = wl;
+                        if (emit_method == PVT_EMIT_KT) {
+                            double e_ev = 1240.0 / e_nm + 1.5 * KB_EV * 300.0;
+                            e_nm = 1240.0 / e_ev;
+                        }
+                        p1 = interp_clamped(e_nm, ax, ay, an);
+                    }
+                    double gamma = p1 + (1.0 - p1) * rng_uniform(&rng);
+                    wl = interp_clamped(gamma, ay, ax, an);
+                    if (S->comp_tau_rad[comp] > 0.0)
+                        duration += -m_log(M, 1.0 - rng_uniform(&rng)) * S->comp_tau_rad[comp];
+                    record(L, max_events, base, &nevents, PVT_EV_EMIT, -1, container, -1, comp, source,
+                           pos, dir, NULL, wl, travelled, duration);
+                } else {
+                    record(L, max_events, base, &nevents, PVT_EV_SCATTER, -1, container, -1, comp,
+                           source, pos, dir, NULL, wl, travelled, duration);
+                }
+                continue;
+            } else {
+                int sel;
+                if (S->comp_tau_nr[comp] > 0.0)
+                    duration += -m_log(M, 1.0 - rng_uniform(&rng)) * S->comp_tau_nr[comp];
+                if (ctype == PVT_COMP_REACTOR) {
+                    record(L, max_events, base, &nevents, PVT_EV_REACT, -1, container, -1, comp, source,
+                           pos, dir, NULL, wl, travelled, duration);
+                    sel = PVT_REC_REACTED;
+                } else {
+                    record(L, max_events, base, &nevents, PVT_EV_NONRADIATIVE, -1, container, -1, comp,
+                           source, pos, dir, NULL, wl, travelled, duration);
+                    sel = PVT_REC_LOST;
+                }
+                if (S->n_recorders > 0) {
+                    xform_point(S->world_to_local + container * 16, pos, lp);
+                    tally(S, A, sel, container, seen, NULL, lp, 0.0, wl, travelled, duration);
+                }
+                break;
+            }
+        }
+
+        /* surface interaction (:834-895) */
+        for (int i = 0; i < 3; i++) pos[i] = pos[i] + dir[i] * t0;
+        travelled += t0;
+        duration += t0 * n_container / C_CM_PER_S;
+        if (adjacent < 0) {
+            record(L, max_events, base, &nevents, PVT_EV_KILL, hit, container, -1, -1, source, pos, dir,
+                   NULL, wl, travelled, duration);
+            break;
+        }
+        xform_point(S->world_to_local + hit * 16, pos, lp);
+        local_normal(S, hit, lp, nl);
+        xform_vector(S->local_to_world + hit * 16, nl, nrm);
+        nf[0] = nrm[0]; nf[1] = nrm[1]; nf[2] = nrm[2];
+        if (dot3(nf, dir) < 0.0) { nf[0] = -nf[0]; nf[1] = -nf[1]; nf[2] = -nf[2]; }
+        double ddot = dot3(nf, dir);
+        if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
+        double angle = m_acos(M, ddot);
+
+        double r = 0.0, n1 = 0.0, n2 = 0.0;
+        int fres = S->surface_type[hit] == PVT_SURF_FRESNEL;
+        if (fres) {
+            n1 = S->refractive_index[container];
+            n2 = S->refractive_index[adjacent];
+            r = fresnel_reflectivity(M, angle, n1, n2);
+        }
+        int coat = fres ? find_coating(S, hit, nl, lp) : -1;          /* EXTENSION */
+        if (coat >= 0 && S->coat_reflectivity[coat] >= 0.0) r = S->coat_reflectivity[coat];
+
+        double u = 1.0;
+        if (r > 0.0) u = rng_uniform(&rng);
+        if (u < r) {
+            if (coat >= 0 && S->coat_reflect_mode[coat] == 1) {        /* EXTENSION */
+                /* hemisphere on the side the ray came from, in the hit node's frame */
+                double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
+                double ml[3] = {side * nl[0], side * nl[1], side * nl[2]}, dl[3];
+                lambertian_about(M, ml, &rng, dl);
+                xform_vector(S->local_to_world + hit * 16, dl, nd);
+            } else {
+                specular_reflect(dir, nrm, nd);
+            }
+            dir[0] = nd[0]; dir[1] = nd[1]; dir[2] = nd[2];
+            record(L, max_events, base, &nevents, PVT_EV_REFLECT, hit, container, adjacent, -1, source,
+                   pos, dir, nrm, wl, travelled, duration);
+            if (S->n_recorders > 0 && container != hit)
+                tally(S, A, PVT_REC_REFLECTED, hit, seen, nrm, lp, angle, wl, travelled, duration);
+            continue;
+        } else {
+            if (fres && !(coat >= 0 && S->coat_transmit_mode[coat] == 1)) {
+                fresnel_refract(dir, nf, n1, n2, nd);
+                dir[0] = nd[0]; dir[1] = nd[1]; dir[2] = nd[2];
+            }
+            record(L, max_events, base, &nevents, PVT_EV_TRANSMIT, hit, container, adjacent, -1, source,
+                   pos, dir, nrm, wl, travelled, duration);
+            if (S->n_recorders > 0) {
+                int sel = (container == hit) ? PVT_REC_ESCAPING : PVT_REC_ENTERING;
+                tally(S, A, sel, hit, seen, nrm, lp, angle, wl, travelled, duration);
+            }
+            continue;
+        }
+    }
+    return nevents;
+}
+
+/* ---- bundle driver (_kernel.pyx:903-1115) -------------------------------
+ * Rays are read from `rays` (never mutated; the reference copies them too,
+ * :1064-1066).  Tallies are ADDED into the caller's arrays; the event log is
+ * pre-filled here like the reference's np.zeros / np.full(-1) allocations. */
+int pvt_oracle_trace(const PvtSceneTables* S, const PvtRays* rays, const PvtTraceParams* P,
+                     const PvtTallies* out, const PvtEventLog* L, int num_threads, int math_mode) {
+    if (S->n_nodes > PVT_MAX_NODES) return PVT_ERR_TOO_MANY_NODES;
+    if (S->n_recorders > PVT_MAX_RECORDERS) return PVT_ERR_INVALID;
+    long n = (long)P->n_rays;
+    long rec_every = (long)P->record_every;
+    long n_recorded = rec_every > 0 ? (n + rec_every - 1) / rec_every : 0;
+    long rows = n_recorded * P->max_events;
+    int nthr = num_threads > 0 ? num_threads : 1;
+    int nrec = S->n_recorders > 0 ? S->n_recorders : 1;
+    int nbins = S->total_bins > 0 ? S->total_bins : 1;
+    MathSel M = {math_mode};
+
+    if (rows > 0 && L) {
+        memset(L->counts, 0, sizeof(int32_t) * (size_t)n_recorded);
+        memset(L->kind, 0, (size_t)rows);
+        memset(L->hit, 0xFF, sizeof(int32_t) * (size_t)rows);
+        memset(L->container, 0xFF, sizeof(int32_t) * (size_t)rows);
+        memset(L->adjacent, 0xFF, sizeof(int32_t) * (size_t)rows);
+        memset(L->component, 0xFF, sizeof(int32_t) * (size_t)rows);
+        memset(L->source, 0xFF, sizeof(int32_t) * (size_t)rows);
+        memset(L->position, 0, sizeof(double) * 3 * (size_t)rows);
+        memset(L->direction, 0, sizeof(double) * 3 * (size_t)rows);
+        memset(L->normal, 0, sizeof(double) * 3 * (size_t)rows);
+        memset(L->wavelength, 0, sizeof(double) * (size_t)rows);
+        memset(L->travelled, 0, sizeof(double) * (size_t)rows);
+        memset(L->duration, 0, sizeof(double) * (size_t)rows);
+    }
+
+    int64_t* a_dist = calloc((size_t)nthr * nrec, sizeof(int64_t));
+    int64_t* a_cross = calloc((size_t)nthr * nrec, sizeof(int64_t));
+    double* a_sums = calloc((size_t)nthr * nrec * 8, sizeof(double));
+    int64_t* a_bins = calloc((size_t)nthr * nbins, sizeof(int64_t));
+    if (!a_dist || !a_cross || !a_sums || !a_bins) return PVT_ERR_INVALID;
+
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthr)
+    for (long i = 0; i < n; i++) {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        Acc A = {a_dist + (size_t)tid * nrec, a_cross + (size_t)tid * nrec,
+                 a_sums + (size_t)tid * nrec * 8, a_bins + (size_t)tid * nbins};
+        long base = -1;
+        if (rec_every > 0 && i % rec_every == 0) base = (i / rec_every) * P->max_events;
+        double pos[3] = {rays->position[i * 3], rays->position[i * 3 + 1], rays->position[i * 3 + 2]};
+        double dir[3] = {rays->direction[i * 3], rays->direction[i * 3 + 1], rays->direction[i * 3 + 2]};
+        int nev = trace_one(S, &M, L, P->max_events, base, &A, pos, dir, rays->wavelength[i],
+                            P->seed + P->ray_offset + (uint64_t)i, P->maxsteps, P->emit_method);
+        if (base >= 0) L->counts[i / rec_every] = nev;
+    }
+
+    /* merge per-thread accumulators in thread order (ndarray.sum(axis=0), :1099-1102) */
+    for (int r = 0; r < S->n_recorders; r++) {
+        int64_t d = 0, c = 0;
+        for (int t = 0; t < nthr; t++) { d += a_dist[(size_t)t * nrec + r]; c += a_cross[(size_t)t * nrec + r]; }
+        out->rec_distinct[r] += d;
+        out->rec_crossings[r] += c;
+        for (int k = 0; k < 8; k++) {
+            double s = 0.0;
+            for (int t = 0; t < nthr; t++) s += a_sums[((size_t)t * nrec + r) * 8 + k];
+            out->rec_sums[r * 8 + k] += s;
+        }
+    }
+    for (int b = 0; b < S->total_bins; b++) {
+        int64_t s = 0;
+        for (int t = 0; t < nthr; t++) s += a_bins[(size_t)t * nbins + b];
+        out->rec_bins[b] += s;
+    }
+    free(a_dist); free(a_cross); free(a_sums); free(a_bins);
+    return PVT_OK;
+}
+
+/* ---- EXTENSION: per-ray-stream emission ---------------------------------
+ * Same distributions as the reference's numpy emitter (emit.py:22-89: constant
+ * / spectrum wavelength; point / rectangle / circle / cube position; +z / cone
+ * / isotropic / lambertian / Henyey-Greenstein direction; local -> world by the
+ * light node's matrix, emit.py:126-131) but each ray draws from its own
+ * xoshiro stream keyed by (emit_seed, global index) so any shard of any GPU
+ * reproduces it.  Draw order: wavelength, position, direction. */
+#define PVT_EMIT_STREAM_SALT 0xA5A5A5A55A5A5A5Aull
+
+static void emit_one(const PvtEmitterTables* E, const MathSel* M, uint64_t emit_seed, uint64_t gi,
+                     double* pos, double* dir, double* wl) {
+    Rng rng;
+    rng_seed(&rng, (emit_seed + gi) ^ PVT_EMIT_STREAM_SALT);
+    int li = (int)(gi % (uint64_t)E->n_lights);
+    if (E->wl_type[li] == PVT_WL_SPECTRUM) {
+        double u = rng_uniform(&rng);
+        *wl = interp_clamped(u, E->spec_cdf + E->wl_spec_start[li], E->spec_x + E->wl_spec_start[li],
+                             E->wl_spec_n[li]);
+    } else {
+        *wl = E->wl_value[li];
+    }
+    double lp[3] = {0.0, 0.0, 0.0}, ld[3] = {0.0, 0.0, 1.0};
+    const double* pp = E->pos_param + li * 3;
+    switch (E->pos_type[li]) {
+        case PVT_POS_RECT:
+            lp[0] = -pp[0] + 2.0 * pp[0] * rng_uniform(&rng);
+            lp[1] = -pp[1] + 2.0 * pp[1] * rng_uniform(&rng);
+            break;
+        case PVT_POS_CIRCLE: {
+            double ang = 2.0 * M_PI * rng_uniform(&rng);
+            double rad = sqrt(rng_uniform(&rng)) * pp[0];
+            lp[0] = rad * m_cos(M, ang);
+            lp[1] = rad * m_sin(M, ang);
+            break;
+        }
+        case PVT_POS_CUBE:
+            lp[0] = -pp[0] + 2.0 * pp[0] * rng_uniform(&rng);
+            lp[1] = -pp[1] + 2.0 * pp[1] * rng_uniform(&rng);
+            lp[2] = -pp[2] + 2.0 * pp[2] * rng_uniform(&rng);
+            break;
+        default: break;
+    }
+    double prm = E->dir_param[li];
+    switch (E->dir_type[li]) {
+        case PVT_DIR_CONE: sample_phase(M, PVT_PHASE_CONE, prm, &rng, ld); break;
+        case PVT_DIR_ISOTROPIC: sample_phase(M, PVT_PHASE_ISOTROPIC, 0.0, &rng, ld); break;
+        case PVT_DIR_HG: sample_phase(M, PVT_PHASE_HG, prm, &rng, ld); break;
+        case PVT_DIR_LAMBERTIAN: {
+            double p1 = rng_uniform(&rng), p2 = rng_uniform(&rng);
+            sphere_direction(M, m_asin(M, sqrt(p1)), 2.0 * M_PI * p2, ld);
+            break;
+        }
+        default: break;
+    }
+    xform_point(E->light_to_world + li * 16, lp, pos);
+    xform_vector(E->light_to_world + li * 16, ld, dir);
+}
+
+int pvt_oracle_emit(const PvtEmitterTables* E, const PvtTraceParams* P, double* position,
+                    double* direction, double* wavelength, int math_mode) {
+    if (E->n_lights <= 0) return PVT_ERR_INVALID;
+    MathSel M = {math_mode};
+    for (long i = 0; i < (long)P->n_rays; i++)
+        emit_one(E, &M, P->emit_seed, P->ray_offset + (uint64_t)i, position + i * 3, direction + i * 3,
+                 wavelength + i);
+    return PVT_OK;
+}
+
+/* vector wrappers so tests can compare pvt_math.h against libm and the GPU */
+void pvt_oracle_math(int fn, int math_mode, const double* x, double* y, long n) {
+    MathSel M = {math_mode};
+    for (long i = 0; i < n; i++) {
+        switch (fn) {
+            case 0: y[i] = m_log(&M, x[i]); break;
+            case 1: y[i] = m_sin(&M, x[i]); break;
+            case 2: y[i] = m_cos(&M, x[i]); break;
+            case 3: y[i] = m_asin(&M, x[i]); break;
+            case 4: y[i] = m_acos(&M, x[i]); break;
+            case 5: y[i] = sqrt(x[i]); break;
+            default: y[i] = 1.0 / x[i]; break;
+        }
+    }
+}
+
+/* unit-level access for known-answer tests */
+double pvt_oracle_fresnel_reflectivity(double angle, double n1, double n2, int math_mode) {
+    MathSel M = {math_mode};
+    return fresnel_reflectivity(&M, angle, n1, n2);
+}
+void pvt_oracle_fresnel_refract(const double* d, const double* nflipped, double n1, double n2, double* out) {
+    fresnel_refract(d, nflipped, n1, n2, out);
+}
+void pvt_oracle_specular_reflect(const double* d, const double* normal, double* out) {
+    specular_reflect(d, normal, out);
+}
+double pvt_oracle_interp(double x, const double* xs, const double* ys, int n) {
+    return interp_clamped(x, xs, ys, n);
+}
+int pvt_oracle_intersect(int geom_type, const double* params, const double* o, const double* d, double* ts) {
+    switch (geom_type) {
+        case PVT_GEOM_BOX: return hit_box(params, o, d, ts);
+        case PVT_GEOM_SPHERE: return hit_sphere(params, o, d, ts);
+        default: return hit_cylinder(params, o, d, ts);
+    }
+}
+void pvt_oracle_normal(int geom_type, const double* params, const double* p, double* out) {
+    PvtSceneTables S;
+    memset(&S, 0, sizeof S);
+    int32_t g = geom_type;
+    S.geom_type = &g;
+    S.geom_params = params;
+    local_normal(&S, 0, p, out);
+}
+void pvt_oracle_uniforms(uint64_t seed, double* out, int n) {
+    Rng r;
+    rng_seed(&r, seed);
+    for (int i = 0; i < n; i++) out[i] = rng_uniform(&r);
+}

@@ -1,0 +1,23 @@
+"""MI355X photon-tracing engine behind pvtrace's `engine` API.
+
+`simulate(scene, num_rays, ...)` flattens the scene graph to SoA tables,
+uploads them once, and runs the per-photon loop as a HIP kernel on gfx950
+(see DESIGN.md).  Public names match the reference's pvtrace/engine/__init__.py.
+"""
+from pvtrace_amd.engine.compiler import CompiledScene, UnsupportedSceneError, compile_scene
+from pvtrace_amd.engine.recorder import Heatmap, Histogram, Recorder
+from pvtrace_amd.engine.tally import tally_histories
+from pvtrace_amd.engine.native import EngineUnavailableError
+from pvtrace_amd.engine.api import (
+    EngineResult,
+    RecorderResult,
+    is_available,
+    simulate,
+    simulate_stream,
+)
+
+__all__ = [
+    "CompiledScene", "UnsupportedSceneError", "compile_scene", "Recorder", "Histogram",
+    "Heatmap", "EngineResult", "RecorderResult", "EngineUnavailableError", "is_available",
+    "simulate", "simulate_stream", "tally_histories",
+]

@@ -1,0 +1,391 @@
+"""ctypes binding to libpvtrace_hip.so (the C ABI in include/pvtrace_hip.h).
+
+This is the only place the Python host touches the native engine.  There is NO
+CPU fallback: if the shared library is missing, or no GPU is visible, tracing
+raises `EngineUnavailableError` — it never silently routes somewhere else.
+
+`torch` is used purely as plumbing: device buffers are torch tensors (so they
+can be all-reduced with torch.distributed over RCCL) and the kernel is enqueued
+on torch's current HIP stream.  Pointers and sizes are all the library sees.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpvtrace_hip.so")
+
+_p_i32 = C.POINTER(C.c_int32)
+_p_f64 = C.POINTER(C.c_double)
+_p_i64 = C.POINTER(C.c_int64)
+_p_u8 = C.POINTER(C.c_uint8)
+
+
+class EngineUnavailableError(RuntimeError):
+    """The HIP engine cannot run here (library not built, or no MI355X visible)."""
+
+
+class PvtSceneTables(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("root_id", C.c_int32), ("n_components", C.c_int32),
+        ("n_abs", C.c_int32), ("n_ems", C.c_int32), ("n_recorders", C.c_int32),
+        ("n_hists", C.c_int32), ("total_bins", C.c_int32), ("n_coatings", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("geom_type", _p_i32), ("geom_params", _p_f64), ("local_to_world", _p_f64),
+        ("world_to_local", _p_f64), ("refractive_index", _p_f64), ("surface_type", _p_i32),
+        ("comp_start", _p_i32), ("comp_count", _p_i32), ("coat_start", _p_i32),
+        ("coat_count", _p_i32),
+        ("comp_type", _p_i32), ("comp_qy", _p_f64), ("comp_tau_rad", _p_f64),
+        ("comp_tau_nr", _p_f64), ("comp_phase_type", _p_i32), ("comp_phase_param", _p_f64),
+        ("comp_abs_start", _p_i32), ("comp_abs_n", _p_i32), ("comp_ems_start", _p_i32),
+        ("comp_ems_n", _p_i32),
+        ("abs_x", _p_f64), ("abs_y", _p_f64), ("ems_x", _p_f64), ("ems_cdf", _p_f64),
+        ("rec_node", _p_i32), ("rec_event", _p_i32), ("rec_has_facet", _p_i32),
+        ("rec_facet", _p_f64), ("rec_atol", _p_f64), ("rec_hist_start", _p_i32),
+        ("rec_hist_n", _p_i32),
+        ("hist_prop_a", _p_i32), ("hist_prop_b", _p_i32), ("hist_na", _p_i32),
+        ("hist_nb", _p_i32), ("hist_lo_a", _p_f64), ("hist_hi_a", _p_f64),
+        ("hist_lo_b", _p_f64), ("hist_hi_b", _p_f64), ("hist_offset", _p_i32),
+        ("coat_facet", _p_f64), ("coat_lo", _p_f64), ("coat_hi", _p_f64),
+        ("coat_reflectivity", _p_f64), ("coat_reflect_mode", _p_i32),
+        ("coat_transmit_mode", _p_i32),
+    ]
+
+
+class PvtEmitterTables(C.Structure):
+    _fields_ = [
+        ("n_lights", C.c_int32), ("n_spec", C.c_int32),
+        ("wl_type", _p_i32), ("wl_value", _p_f64), ("wl_spec_start", _p_i32),
+        ("wl_spec_n", _p_i32), ("pos_type", _p_i32), ("pos_param", _p_f64),
+        ("dir_type", _p_i32), ("dir_param", _p_f64), ("light_to_world", _p_f64),
+        ("spec_x", _p_f64), ("spec_cdf", _p_f64),
+    ]
+
+
+class PvtTraceParams(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_int64), ("seed", C.c_uint64), ("ray_offset", C.c_uint64),
+        ("emit_seed", C.c_uint64), ("record_every", C.c_int64), ("maxsteps", C.c_int32),
+        ("max_events", C.c_int32), ("emit_method", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class PvtRays(C.Structure):
+    _fields_ = [("position", _p_f64), ("direction", _p_f64), ("wavelength", _p_f64)]
+
+
+class PvtTallies(C.Structure):
+    _fields_ = [
+        ("rec_distinct", _p_i64), ("rec_crossings", _p_i64), ("rec_sums", _p_f64),
+        ("rec_bins", _p_i64),
+    ]
+
+
+class PvtEventLog(C.Structure):
+    _fields_ = [
+        ("counts", _p_i32), ("kind", _p_u8), ("hit", _p_i32), ("container", _p_i32),
+        ("adjacent", _p_i32), ("component", _p_i32), ("source", _p_i32),
+        ("position", _p_f64), ("direction", _p_f64), ("normal", _p_f64),
+        ("wavelength", _p_f64), ("travelled", _p_f64), ("duration", _p_f64),
+    ]
+
+
+_CTYPE_OF = {
+    np.dtype(np.int32): C.c_int32, np.dtype(np.float64): C.c_double,
+    np.dtype(np.int64): C.c_int64, np.dtype(np.uint8): C.c_uint8,
+}
+
+
+def np_ptr(array):
+    """ctypes pointer to a C-contiguous numpy array's data."""
+    return array.ctypes.data_as(C.POINTER(_CTYPE_OF[array.dtype]))
+
+
+def addr_ptr(address, ctype):
+    """ctypes pointer from a raw (device) address."""
+    return C.cast(C.c_void_p(int(address)), C.POINTER(ctype))
+
+
+_TABLE_POINTER_FIELDS = [
+    name for name, ctype in PvtSceneTables._fields_ if ctype in (_p_i32, _p_f64)
+]
+
+
+def scene_tables_struct(compiled):
+    """Build a PvtSceneTables over the arrays of a CompiledScene.
+
+    Returns (struct, keepalive): `keepalive` holds the contiguous arrays the
+    pointers refer to and must outlive every use of `struct`."""
+    keep = {}
+    st = PvtSceneTables()
+    st.n_nodes = int(compiled.geom_type.shape[0])
+    st.root_id = int(compiled.root_id)
+    st.n_components = int(compiled.comp_type.shape[0])
+    st.n_abs = int(compiled.abs_x.shape[0])
+    st.n_ems = int(compiled.ems_x.shape[0])
+    st.n_recorders = int(compiled.rec_node.shape[0])
+    st.n_hists = int(compiled.hist_prop_a.shape[0])
+    st.total_bins = int(compiled.total_bins)
+    st.n_coatings = int(getattr(compiled, "n_coatings", 0))
+    for name in _TABLE_POINTER_FIELDS:
+        want = np.int32 if dict(PvtSceneTables._fields_)[name] is _p_i32 else np.float64
+        value = getattr(compiled, name, None)
+        if value is None:  # tables from an engine without the coating extension
+            value = np.zeros(max(st.n_nodes, 1) * 3, dtype=want)
+        arr = np.ascontiguousarray(value, dtype=want)
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=want)  # never hand out NULL for an empty table
+        keep[name] = arr
+        setattr(st, name, np_ptr(arr))
+    return st, keep
+
+
+def emitter_tables_struct(emitter):
+    """PvtEmitterTables over an `emit.EmitterTables` object -> (struct, keepalive)."""
+    keep = {}
+    st = PvtEmitterTables()
+    st.n_lights = int(emitter.n_lights)
+    st.n_spec = int(emitter.spec_x.shape[0])
+    fields = dict(PvtEmitterTables._fields_)
+    for name, ctype in fields.items():
+        if ctype not in (_p_i32, _p_f64):
+            continue
+        want = np.int32 if ctype is _p_i32 else np.float64
+        arr = np.ascontiguousarray(getattr(emitter, name), dtype=want)
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=want)
+        keep[name] = arr
+        setattr(st, name, np_ptr(arr))
+    return st, keep
+
+
+def trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps, max_events,
+                 emit_method):
+    mask = (1 << 64) - 1
+    return PvtTraceParams(
+        int(n_rays), int(seed) & mask, int(ray_offset) & mask, int(emit_seed) & mask,
+        int(record_every), int(maxsteps), int(max_events), int(emit_method), 0,
+    )
+
+
+def num_recorded(n_rays, record_every):
+    return (n_rays + record_every - 1) // record_every if record_every > 0 else 0
+
+
+EVENT_LOG_COLUMNS = (
+    # name, dtype, per-row width
+    ("kind", np.uint8, 1), ("hit", np.int32, 1), ("container", np.int32, 1),
+    ("adjacent", np.int32, 1), ("component", np.int32, 1), ("source", np.int32, 1),
+    ("position", np.float64, 3), ("direction", np.float64, 3), ("normal", np.float64, 3),
+    ("wavelength", np.float64, 1), ("travelled", np.float64, 1), ("duration", np.float64, 1),
+)
+
+
+def declare_signatures(lib, names):
+    """Set argtypes/restype of the C-ABI entry points present in `lib`."""
+    vp = C.c_void_p
+    sigs = {
+        "pvt_abi_version": ([], C.c_int),
+        "pvt_last_error": ([], C.c_char_p),
+        "pvt_device_count": ([], C.c_int),
+        "pvt_scene_create": ([C.POINTER(PvtSceneTables), C.c_int, C.POINTER(vp)], C.c_int),
+        "pvt_scene_set_emitter": ([vp, C.POINTER(PvtEmitterTables)], C.c_int),
+        "pvt_scene_destroy": ([vp], None),
+        "pvt_trace_device": (
+            [vp, C.POINTER(PvtRays), C.POINTER(PvtTraceParams), C.POINTER(PvtTallies),
+             C.POINTER(PvtEventLog), vp], C.c_int),
+        "pvt_trace_bundle": (
+            [C.POINTER(PvtSceneTables), C.POINTER(PvtEmitterTables), C.POINTER(PvtRays),
+             C.POINTER(PvtTraceParams), C.POINTER(PvtTallies), C.POINTER(PvtEventLog), C.c_int,
+             C.POINTER(C.c_double)], C.c_int),
+        "pvt_emit_device": ([vp, C.POINTER(PvtTraceParams), vp, vp, vp, vp], C.c_int),
+        "pvt_scene_launch_info": (
+            [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
+    }
+    for name in names:
+        argtypes, restype = sigs[name]
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return sigs
+
+
+ABI_SYMBOLS = (
+    "pvt_abi_version", "pvt_last_error", "pvt_device_count", "pvt_scene_create",
+    "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
+    "pvt_emit_device", "pvt_scene_launch_info",
+)
+
+_lib = None
+
+
+def library_built():
+    return os.path.exists(LIB_PATH)
+
+
+def load_library():
+    """dlopen the engine (needs libamdhip64 from /opt/rocm, present on CPU boxes too)."""
+    global _lib
+    if _lib is None:
+        if not library_built():
+            raise EngineUnavailableError(
+                f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`"
+                " (hipcc --offload-arch=gfx950)."
+            )
+        lib = C.CDLL(LIB_PATH)
+        declare_signatures(lib, ABI_SYMBOLS)
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code == 0:
+        return
+    lib = load_library()
+    detail = lib.pvt_last_error()
+    detail = detail.decode() if detail else ""
+    if code == -2:
+        raise ValueError("Engine supports at most 128 geometry nodes.")
+    if code == -1:
+        raise ValueError(f"{what}: invalid argument ({detail})")
+    raise EngineUnavailableError(f"{what} failed with code {code}: {detail}")
+
+
+def device_count():
+    return int(load_library().pvt_device_count())
+
+
+def is_available():
+    """True iff the HIP library is built AND at least one GPU is visible."""
+    if not library_built():
+        return False
+    try:
+        return device_count() > 0
+    except OSError:
+        return False
+
+
+class DeviceScene:
+    """Scene tables resident in HBM on one GPU (uploaded once, reused per bundle)."""
+
+    def __init__(self, compiled, device=0, emitter=None):
+        self.lib = load_library()
+        if device_count() <= 0:
+            raise EngineUnavailableError("No HIP device visible; the engine has no CPU path.")
+        self.compiled = compiled
+        self.device = int(device)
+        st, keep = scene_tables_struct(compiled)
+        handle = C.c_void_p()
+        check(self.lib.pvt_scene_create(C.byref(st), self.device, C.byref(handle)),
+              "pvt_scene_create")
+        self.handle = handle
+        self.has_emitter = False
+        if emitter is not None:
+            self.set_emitter(emitter)
+
+    def set_emitter(self, emitter):
+        st, keep = emitter_tables_struct(emitter)
+        check(self.lib.pvt_scene_set_emitter(self.handle, C.byref(st)), "pvt_scene_set_emitter")
+        self.has_emitter = True
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pvt_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def launch_info(self):
+        g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.lib.pvt_scene_launch_info(self.handle, C.byref(g), C.byref(b), C.byref(l)),
+              "pvt_scene_launch_info")
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+    # -- device buffers (torch tensors) ----------------------------------
+    def new_tallies(self):
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        c = self.compiled
+        nrec = max(int(c.rec_node.shape[0]), 1)
+        nbins = max(int(c.total_bins), 1)
+        return {
+            "rec_distinct": torch.zeros(nrec, dtype=torch.int64, device=dev),
+            "rec_crossings": torch.zeros(nrec, dtype=torch.int64, device=dev),
+            "rec_sums": torch.zeros(nrec * 8, dtype=torch.float64, device=dev),
+            "rec_bins": torch.zeros(nbins, dtype=torch.int64, device=dev),
+        }
+
+    def new_event_log(self, n_rays, record_every, max_events):
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        nrec = num_recorded(n_rays, record_every)
+        rows = nrec * max_events
+        log = {"counts": torch.empty(max(nrec, 1), dtype=torch.int32, device=dev)}
+        tmap = {np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
+        for name, dtype, width in EVENT_LOG_COLUMNS:
+            log[name] = torch.empty(max(rows, 1) * width, dtype=tmap[dtype], device=dev)
+        return log
+
+    def trace(self, rays, n_rays, seed, tallies, log=None, ray_offset=0, emit_seed=0,
+              record_every=0, maxsteps=1000, max_events=128, emit_method=0, stream=None):
+        """Enqueue one bundle.  `rays` is None (device emission) or a tuple of
+        three float64 CUDA tensors (positions (n,3), directions (n,3), wavelengths (n))."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        params = trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps,
+                              max_events, emit_method)
+        tl = PvtTallies(
+            addr_ptr(tallies["rec_distinct"].data_ptr(), C.c_int64),
+            addr_ptr(tallies["rec_crossings"].data_ptr(), C.c_int64),
+            addr_ptr(tallies["rec_sums"].data_ptr(), C.c_double),
+            addr_ptr(tallies["rec_bins"].data_ptr(), C.c_int64),
+        )
+        rays_ref = None
+        if rays is not None:
+            pos, direc, wl = rays
+            for t in (pos, direc, wl):
+                if t.dtype != torch.float64 or not t.is_contiguous() or t.device.index != self.device:
+                    raise ValueError("rays must be contiguous float64 tensors on the scene's GPU")
+            rays_ref = C.byref(PvtRays(addr_ptr(pos.data_ptr(), C.c_double),
+                                       addr_ptr(direc.data_ptr(), C.c_double),
+                                       addr_ptr(wl.data_ptr(), C.c_double)))
+        elif not self.has_emitter:
+            raise ValueError("device emission requested but the scene has no emitter tables")
+        log_ref = None
+        if record_every > 0:
+            if log is None:
+                raise ValueError("record_every > 0 needs event-log buffers")
+            el = PvtEventLog()
+            el.counts = addr_ptr(log["counts"].data_ptr(), C.c_int32)
+            for name, dtype, _ in EVENT_LOG_COLUMNS:
+                setattr(el, name, addr_ptr(log[name].data_ptr(), _CTYPE_OF[np.dtype(dtype)]))
+            log_ref = C.byref(el)
+        check(self.lib.pvt_trace_device(self.handle, rays_ref, C.byref(params), C.byref(tl),
+                                        log_ref, C.c_void_p(stream)), "pvt_trace_device")
+
+    def emit(self, n_rays, emit_seed, ray_offset=0, stream=None):
+        """Device-side emission only -> (positions, directions, wavelengths) CUDA tensors."""
+        import torch
+
+        if not self.has_emitter:
+            raise ValueError("scene has no emitter tables")
+        dev = torch.device("cuda", self.device)
+        pos = torch.empty((n_rays, 3), dtype=torch.float64, device=dev)
+        direc = torch.empty((n_rays, 3), dtype=torch.float64, device=dev)
+        wl = torch.empty(n_rays, dtype=torch.float64, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        params = trace_params(n_rays, 0, ray_offset, emit_seed, 0, 0, 0, 0)
+        check(self.lib.pvt_emit_device(self.handle, C.byref(params), C.c_void_p(pos.data_ptr()),
+                                       C.c_void_p(direc.data_ptr()), C.c_void_p(wl.data_ptr()),
+                                       C.c_void_p(stream)), "pvt_emit_device")
+        return pos, direc, wl

@@ -1,0 +1,507 @@
+"""Materials: refractive index, surface delegates and volume components.
+
+Constructor-level mirror of the reference's material package
+(pvtrace/material/material.py:10-63, component.py:33-440, distribution.py:8-193,
+surface.py:13-272, utils.py:8-186).  These objects only *describe* a material:
+the flattener (`pvtrace_amd.engine.compiler`) lowers them to SoA tables and the
+HIP kernel does all per-photon sampling.  The scalar helper functions
+(`fresnel_reflectivity`, `cone`, ...) are kept because user scenes pass them as
+delegates (e.g. ``functools.partial(cone, theta)``) and tests use them as known
+answers.
+"""
+import abc
+import math
+
+import numpy as np
+
+Q_E = 1.60217662e-19  # C
+KB_EV = 1.380649e-23 / Q_E  # eV / K   (reference component.py:25-26)
+
+
+# ----------------------------------------------------------------------
+# Optics helpers (reference material/utils.py:8-45)
+
+def fresnel_reflectivity(angle, n1, n2):
+    """Unpolarised Fresnel reflectivity; 1.0 beyond the critical angle."""
+    if n2 < n1 and angle > math.asin(n2 / n1):
+        return 1.0
+    c, s = math.cos(angle), math.sin(angle)
+    k = math.sqrt(1.0 - (n1 / n2 * s) ** 2)
+    rs = ((n1 * c - n2 * k) / (n1 * c + n2 * k)) ** 2
+    rp = ((n1 * k - n2 * c) / (n1 * k + n2 * c)) ** 2
+    return 0.5 * (rs + rp)
+
+
+def specular_reflection(direction, normal):
+    d = np.asarray(direction, dtype=np.float64)
+    n = np.asarray(normal, dtype=np.float64)
+    if np.dot(n, d) < 0.0:
+        n = -n
+    return d - 2.0 * np.dot(n, d) * n
+
+
+def fresnel_refraction(direction, normal, n1, n2):
+    """Snell refraction, vector form; `normal` must point along the ray."""
+    d = np.asarray(direction, dtype=np.float64)
+    nrm = np.asarray(normal, dtype=np.float64)
+    n = n1 / n2
+    dd = float(np.dot(d, nrm))
+    c = math.sqrt(1.0 - n * n * (1.0 - dd * dd))
+    sign = -1.0 if dd < 0.0 else 1.0
+    return n * d + sign * (c - sign * n * dd) * nrm
+
+
+def gaussian(x, c1, c2, c3):
+    return c1 * np.exp(-(((c2 - x) / c3) ** 2))
+
+
+def bandgap(x, cutoff, alpha):
+    return (1 - np.heaviside(x - cutoff, 0.5)) * alpha
+
+
+def spherical_to_cart(theta, phi, r=1.0):
+    st = np.sin(theta)
+    cart = np.column_stack((r * st * np.cos(phi), r * st * np.sin(phi), r * np.cos(theta)))
+    return cart[0, :] if cart.size == 3 else cart
+
+
+# ----------------------------------------------------------------------
+# Phase functions / angular distributions (reference material/utils.py:104-186).
+# The engine recognises these by identity / type and samples them on the
+# device; calling them directly draws from numpy's global generator.
+
+def isotropic():
+    g1, g2 = np.random.uniform(0, 1, 2)
+    return spherical_to_cart(math.acos(2.0 * g2 - 1.0), 2.0 * math.pi * g1)
+
+
+def henyey_greenstein(g=0.0):
+    p = np.random.uniform(0, 1)
+    if abs(g) < 2.220446049250313e-13:
+        return isotropic()
+    s = 2.0 * p - 1.0
+    mu = (1.0 + g * g - ((1.0 - g * g) / (1.0 + g * s)) ** 2) / (2.0 * g)
+    phi = 2.0 * math.pi * np.random.uniform()
+    return spherical_to_cart(math.acos(mu), phi)
+
+
+def cone(theta_max):
+    if np.isclose(theta_max, 0.0) or theta_max > math.pi / 2:
+        raise ValueError("Expected 0 < theta_max <= pi/2")
+    p1, p2 = np.random.uniform(0, 1, 2)
+    theta = math.asin(math.sqrt(p1) * math.sin(theta_max))
+    return spherical_to_cart(theta, 2.0 * math.pi * p2)
+
+
+def lambertian():
+    p1, p2 = np.random.uniform(0, 1, 2)
+    return spherical_to_cart(math.asin(math.sqrt(p1)), 2.0 * math.pi * p2)
+
+
+class HenyeyGreenstein(object):
+    def __init__(self, g):
+        self.g = float(g)
+
+    def __call__(self):
+        return henyey_greenstein(self.g)
+
+
+class Cone(object):
+    def __init__(self, theta_max):
+        self.theta_max = float(theta_max)
+
+    def __call__(self):
+        return cone(self.theta_max)
+
+
+# ----------------------------------------------------------------------
+# Spectral distribution (reference material/distribution.py:8-193)
+
+class Distribution(object):
+    """A sampled spectrum y(x) with its cumulative distribution.
+
+    With ``hist=False`` the CDF is the trapezoid integral normalised to 1 with a
+    leading 0 (`_cdf` has the same length as `_x`); this is what the device
+    kernel inverts for emission-wavelength sampling.  A constant is represented
+    by ``x=None`` and a float `y`.
+    """
+
+    def __init__(self, x, y, hist=False):
+        self.hist = hist
+        if x is None and isinstance(y, float):
+            self._x, self._y = None, y
+            return
+        x = np.asarray(x)
+        y = np.asarray(y)
+        if not np.all(np.diff(x) > 0):
+            raise ValueError("x must be sorted and ascending.")
+        if not np.isfinite(y).any():
+            raise ValueError("All values of y must be finite.")
+        if np.any(y < 0.0):
+            raise ValueError(
+                "Distributions are like histograms all counts must be positive."
+            )
+        self._x_range = (np.min(x), np.max(x))
+        self._x, self._y = x, y
+        if hist:
+            cdf = np.cumsum(y, dtype=float)
+            cdf *= 1.0 / cdf[-1]
+            self._cdf = cdf
+            self._edges = np.insert(x, x.size, 2 * x[-1] - x[-2])
+        else:
+            cdf = np.cumsum((y[:-1] + y[1:]) * 0.5)
+            cdf = cdf / np.max(cdf)
+            self._cdf = np.hstack([0.0, cdf])
+
+    def _check(self, v, lo, hi, what):
+        arr = np.asarray(v)
+        if np.any(arr < lo) or np.any(arr > hi):
+            raise ValueError(what, {"value": v, "range": (lo, hi)})
+
+    def __call__(self, x):
+        if self._x is None:
+            if isinstance(x, (list, tuple, np.ndarray)):
+                return np.zeros(len(x)) + self._y
+            return self._y
+        self._check(x, *self._x_range, "x is outside data range.")
+        if self.hist:
+            return self._y[np.searchsorted(self._edges[:-1], x)]
+        return np.interp(x, self._x, self._y, left=np.nan, right=np.nan)
+
+    def lookup(self, x):
+        """CDF value at x."""
+        self._check(x, *self._x_range, "x is outside data range.")
+        if self.hist:
+            return self._cdf[np.searchsorted(self._edges[:-1], x)]
+        prob = np.interp(x, self._x, self._cdf, left=np.nan, right=np.nan)
+        return prob.tolist() if np.size(prob) == 1 else prob
+
+    def sample(self, p):
+        """Inverse CDF."""
+        self._check(p, 0.0, 1.0, "p is outside valid range.")
+        if self.hist:
+            idx = np.searchsorted(self._cdf, p)
+            try:
+                return self._x[idx]
+            except IndexError:
+                return self._x[-1]
+        xval = np.interp(p, self._cdf, self._x, left=np.nan, right=np.nan)
+        return xval.tolist() if np.size(xval) == 1 else xval
+
+    @classmethod
+    def from_functions(cls, x, callables, hist=False):
+        x = np.array(x)
+        if x.ndim != 1:
+            raise ValueError("Requires a 1D array.")
+        y = np.zeros(len(x))
+        for f in callables:
+            part = f(x)
+            part[np.where(~np.isfinite(part))] = 0.0
+            y += part
+        return cls(x=x, y=y, hist=hist)
+
+
+# ----------------------------------------------------------------------
+# Surfaces (reference material/surface.py:13-272)
+
+class SurfaceDelegate(abc.ABC):
+    """Per-interaction surface behaviour.  Arbitrary Python delegates cannot
+    run on the device; the flattener accepts the built-in delegates below and
+    declarative `CoatedSurfaceDelegate` objects, and rejects everything else
+    with `UnsupportedSceneError` (as the reference compiler does,
+    pvtrace/engine/compiler.py:237-247)."""
+
+    @abc.abstractmethod
+    def reflectivity(self, surface, ray, geometry, container, adjacent):
+        pass
+
+    @abc.abstractmethod
+    def reflected_direction(self, surface, ray, geometry, container, adjacent):
+        pass
+
+    @abc.abstractmethod
+    def transmitted_direction(self, surface, ray, geometry, container, adjacent):
+        pass
+
+
+def _flipped_normal(geometry, ray):
+    normal = np.asarray(geometry.normal(ray.position), dtype=np.float64)
+    if np.dot(normal, ray.direction) < 0.0:
+        normal = -normal
+    return normal
+
+
+class FresnelSurfaceDelegate(SurfaceDelegate):
+    """Fresnel reflection / Snell refraction from the two refractive indices."""
+
+    def reflectivity(self, surface, ray, geometry, container, adjacent):
+        n1 = container.geometry.material.refractive_index
+        n2 = adjacent.geometry.material.refractive_index
+        normal = _flipped_normal(geometry, ray)
+        cosang = float(np.clip(np.dot(normal, ray.direction), -1.0, 1.0))
+        return float(fresnel_reflectivity(math.acos(cosang), n1, n2))
+
+    def reflected_direction(self, surface, ray, geometry, container, adjacent):
+        normal = geometry.normal(ray.position)
+        return tuple(specular_reflection(ray.direction, normal).tolist())
+
+    def transmitted_direction(self, surface, ray, geometry, container, adjacent):
+        n1 = container.geometry.material.refractive_index
+        n2 = adjacent.geometry.material.refractive_index
+        normal = _flipped_normal(geometry, ray)
+        return tuple(fresnel_refraction(ray.direction, normal, n1, n2).tolist())
+
+
+class NullSurfaceDelegate(SurfaceDelegate):
+    """Transmits everything without refraction (useful for counting)."""
+
+    def reflectivity(self, surface, ray, geometry, container, adjacent):
+        return 0.0
+
+    def reflected_direction(self, surface, ray, geometry, container, adjacent):
+        raise NotImplementedError("This surface delegate does not reflect.")
+
+    def transmitted_direction(self, surface, ray, geometry, container, adjacent):
+        return ray.direction
+
+
+class Coating(object):
+    """Declarative override of the optics on part of a node's surface.
+
+    The reference expresses coatings as Python subclasses of
+    `FresnelSurfaceDelegate` that inspect the hit normal / position per ray
+    (e.g. pvtrace/device/lsc.py:22-86, examples/006 Coatings.ipynb cell 3);
+    callbacks cannot run on the GPU, so the same behaviours are written as data:
+
+    facet : outward face normal in the node's LOCAL frame the coating covers
+        (matched like ``np.allclose``: |n_i - facet_i| <= 1e-8 + 1e-5 |facet_i|).
+    region : optional ((xlo, xhi), (ylo, yhi), (zlo, zhi)) open intervals in the
+        local frame restricting where on that face it applies (None = unbounded).
+    reflectivity : probability of reflection in [0, 1], or None to keep Fresnel.
+    reflection : "specular" or "lambertian" (cosine-weighted about the outward
+        facet normal, in the local frame).
+    transmission : "fresnel" (Snell refraction) or "matched" (index-matched:
+        direction unchanged, e.g. a perfectly coupled solar cell).
+    """
+
+    REFLECTION_MODES = {"specular": 0, "lambertian": 1}
+    TRANSMISSION_MODES = {"fresnel": 0, "matched": 1}
+
+    def __init__(
+        self,
+        facet,
+        reflectivity=None,
+        region=None,
+        reflection="specular",
+        transmission="fresnel",
+    ):
+        self.facet = tuple(float(v) for v in facet)
+        if len(self.facet) != 3:
+            raise ValueError("facet must be a 3-vector")
+        if reflectivity is not None and not 0.0 <= float(reflectivity) <= 1.0:
+            raise ValueError("reflectivity must be in [0, 1] or None")
+        self.reflectivity = None if reflectivity is None else float(reflectivity)
+        if reflection not in self.REFLECTION_MODES:
+            raise ValueError(f"reflection must be one of {sorted(self.REFLECTION_MODES)}")
+        if transmission not in self.TRANSMISSION_MODES:
+            raise ValueError(
+                f"transmission must be one of {sorted(self.TRANSMISSION_MODES)}"
+            )
+        self.reflection = reflection
+        self.transmission = transmission
+        bounds = []
+        for axis in range(3):
+            pair = None if region is None else region[axis]
+            lo, hi = (None, None) if pair is None else pair
+            bounds.append(
+                (-math.inf if lo is None else float(lo), math.inf if hi is None else float(hi))
+            )
+        self.region = tuple(bounds)
+
+    def covers(self, normal, position):
+        for a in range(3):
+            if abs(normal[a] - self.facet[a]) > 1e-8 + 1e-5 * abs(self.facet[a]):
+                return False
+            lo, hi = self.region[a]
+            if not (lo < position[a] < hi):
+                return False
+        return True
+
+
+class CoatedSurfaceDelegate(FresnelSurfaceDelegate):
+    """Fresnel surface with an ordered list of `Coating` overrides; the first
+    coating covering the hit point wins, uncovered points are plain Fresnel."""
+
+    def __init__(self, coatings=None):
+        super(CoatedSurfaceDelegate, self).__init__()
+        self._coatings = [] if coatings is None else list(coatings)
+
+    @property
+    def coatings(self):
+        return list(self._coatings)
+
+    def _match(self, ray, geometry):
+        normal = geometry.normal(ray.position)
+        for coating in self.coatings:
+            if coating.covers(normal, ray.position):
+                return coating
+        return None
+
+    def reflectivity(self, surface, ray, geometry, container, adjacent):
+        coating = self._match(ray, geometry)
+        if coating is not None and coating.reflectivity is not None:
+            return coating.reflectivity
+        return super(CoatedSurfaceDelegate, self).reflectivity(
+            surface, ray, geometry, container, adjacent
+        )
+
+    def transmitted_direction(self, surface, ray, geometry, container, adjacent):
+        coating = self._match(ray, geometry)
+        if coating is not None and coating.transmission == "matched":
+            return tuple(ray.direction)
+        return super(CoatedSurfaceDelegate, self).transmitted_direction(
+            surface, ray, geometry, container, adjacent
+        )
+
+
+class Surface(object):
+    def __init__(self, delegate=None):
+        super(Surface, self).__init__()
+        self._delegate = FresnelSurfaceDelegate() if delegate is None else delegate
+
+    @property
+    def delegate(self):
+        return self._delegate
+
+
+# ----------------------------------------------------------------------
+# Volume components (reference material/component.py:33-440)
+
+class Component(object):
+    def __init__(self, name="Component"):
+        super(Component, self).__init__()
+        self.name = name
+
+
+class Scatterer(Component):
+    """Scattering centre with attenuation coefficient (cm^-1), constant or spectral."""
+
+    def __init__(
+        self,
+        coefficient,
+        x=None,
+        quantum_yield=1.0,
+        tau_rad=None,
+        tau_nr=None,
+        phase_function=None,
+        hist=False,
+        name="Scatterer",
+    ):
+        super(Scatterer, self).__init__(name=name)
+        if coefficient is None:
+            raise ValueError("Coefficient must be specified.")
+        if isinstance(coefficient, (int, np.integer, np.floating)) and not isinstance(coefficient, bool):
+            coefficient = float(coefficient)
+        self._coefficient = coefficient
+        if isinstance(coefficient, float):
+            self._abs_dist = Distribution(x=None, y=coefficient, hist=hist)
+        elif isinstance(coefficient, np.ndarray):
+            self._abs_dist = Distribution(
+                x=coefficient[:, 0], y=coefficient[:, 1], hist=hist
+            )
+        elif isinstance(coefficient, (list, tuple)):
+            if x is None:
+                raise ValueError("Requires `x`.")
+            self._abs_dist = Distribution.from_functions(x, coefficient, hist=hist)
+        else:
+            raise ValueError("coefficient must be a float, an (n, 2) array or callables.")
+
+        qy = float("nan")
+        if tau_rad is not None and tau_nr is not None:
+            qy = tau_nr / (tau_nr + tau_rad)
+        elif quantum_yield is not None:
+            qy = quantum_yield
+        if not np.isfinite(qy):
+            raise ValueError(
+                "Specify either `quantum yield` or both `tau_rad` and `tau_nr`"
+            )
+        self.quantum_yield = qy
+        self.tau_rad = tau_rad
+        self.tau_nr = tau_nr
+        self.phase_function = isotropic if phase_function is None else phase_function
+
+    def coefficient(self, wavelength):
+        return self._abs_dist(wavelength)
+
+
+class Absorber(Scatterer):
+    """Non-radiative absorber (quantum yield 0)."""
+
+    def __init__(self, coefficient, x=None, tau_nr=None, name="Absorber", hist=False):
+        super(Absorber, self).__init__(
+            coefficient,
+            x=x,
+            quantum_yield=0.0,
+            tau_nr=tau_nr,
+            tau_rad=0.0,
+            phase_function=None,
+            hist=hist,
+            name=name,
+        )
+
+
+class Reactor(Absorber):
+    """Absorber whose absorptions are tallied as photochemical reactions."""
+
+    def __init__(self, coefficient, x=None, name="Reactor", hist=False):
+        super(Reactor, self).__init__(coefficient, x=x, hist=hist, name=name)
+
+
+class Luminophore(Scatterer):
+    """Absorbs and re-emits with a new wavelength drawn from `emission`."""
+
+    def __init__(
+        self,
+        coefficient,
+        emission=None,
+        x=None,
+        hist=False,
+        quantum_yield=1.0,
+        tau_rad=None,
+        tau_nr=None,
+        phase_function=None,
+        name="Luminophore",
+    ):
+        super(Luminophore, self).__init__(
+            coefficient,
+            x=x,
+            quantum_yield=quantum_yield,
+            tau_rad=tau_rad,
+            tau_nr=tau_nr,
+            phase_function=phase_function,
+            hist=hist,
+            name=name,
+        )
+        self._emission = emission
+        if emission is None:
+            self._ems_dist = Distribution.from_functions(
+                x, [lambda v: gaussian(v, 1.0, 600.0, 40.0)], hist=hist
+            )
+        elif isinstance(emission, np.ndarray):
+            self._ems_dist = Distribution(x=emission[:, 0], y=emission[:, 1], hist=hist)
+        elif isinstance(emission, (tuple, list)):
+            if x is None:
+                raise ValueError("Requires `x`.")
+            self._ems_dist = Distribution.from_functions(x, emission, hist=hist)
+        else:
+            raise ValueError("Luminophore `emission` arg has wrong type.")
+
+
+class Material(object):
+    def __init__(self, refractive_index, surface=None, components=None):
+        self.refractive_index = refractive_index
+        self.surface = Surface() if surface is None else surface
+        self.components = [] if components is None else components
+
+    def total_attenutation_coefficient(self, wavelength):
+        return float(np.sum([c.coefficient(wavelength) for c in self.components]))

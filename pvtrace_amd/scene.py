@@ -1,0 +1,215 @@
+"""Scene graph: `Node` (a coordinate frame that may carry a geometry, a light
+and recorders) and `Scene` (a root node).
+
+API mirror of the reference's pvtrace/scene/node.py:15-201 and
+pvtrace/scene/scene.py:92-151, without the third-party tree library: parent /
+children bookkeeping, pre-order and level-order walks are implemented here.
+Tracing itself is not done on these objects — `pvtrace_amd.engine` flattens the
+graph into SoA tables and runs the HIP kernel.
+"""
+import numpy as np
+
+from pvtrace_amd.common import AppError
+from pvtrace_amd.geometry import Transformable, rotation_matrix
+
+
+class Node(Transformable):
+    """A frame positioned relative to its parent node."""
+
+    def __init__(
+        self,
+        name=None,
+        parent=None,
+        location=None,
+        geometry=None,
+        light=None,
+        recorders=None,
+    ):
+        super(Node, self).__init__(location=location)
+        self.name = name
+        self._parent = None
+        self._children = []
+        self.parent = parent
+        self.geometry = geometry
+        self.light = light
+        self.recorders = [] if recorders is None else list(recorders)
+
+    def __repr__(self):
+        return "Node({})".format(self.name)
+
+    # -- tree bookkeeping ------------------------------------------------
+    @property
+    def parent(self):
+        return self._parent
+
+    @parent.setter
+    def parent(self, node):
+        if node is not None:
+            if not isinstance(node, Node):
+                raise AppError("Parent must be a Node.")
+            probe = node
+            while probe is not None:
+                if probe is self:
+                    raise AppError("A node cannot be its own ancestor.")
+                probe = probe._parent
+        if self._parent is not None:
+            self._parent._children.remove(self)
+        self._parent = node
+        if node is not None:
+            node._children.append(self)
+
+    @property
+    def children(self):
+        return tuple(self._children)
+
+    @property
+    def is_root(self):
+        return self._parent is None
+
+    @property
+    def is_leaf(self):
+        return len(self._children) == 0
+
+    @property
+    def root(self):
+        node = self
+        while node._parent is not None:
+            node = node._parent
+        return node
+
+    @property
+    def path(self):
+        """Nodes from the root down to (and including) this node."""
+        chain = []
+        node = self
+        while node is not None:
+            chain.append(node)
+            node = node._parent
+        return tuple(reversed(chain))
+
+    @property
+    def ancestors(self):
+        return self.path[:-1]
+
+    @property
+    def leaves(self):
+        return tuple(n for n in self.preorder() if n.is_leaf)
+
+    def preorder(self):
+        """Depth-first, parent before children, children in insertion order."""
+        stack = [self]
+        while stack:
+            node = stack.pop()
+            yield node
+            stack.extend(reversed(node._children))
+
+    def levelorder(self):
+        queue = [self]
+        while queue:
+            node = queue.pop(0)
+            yield node
+            queue.extend(node._children)
+
+    # -- orientation -----------------------------------------------------
+    def look_at(self, vector):
+        """Rotate so the node's +z axis points along `vector`."""
+        a = np.array([0.0, 0.0, 1.0])
+        b = np.asarray(vector, dtype=np.float64)
+        b = b / np.linalg.norm(b)
+        c = float(np.dot(a, b))
+        if np.isclose(c, -1.0):
+            self.rotate(np.pi, [0, 1, 0])
+            return
+        if np.isclose(c, 1.0):
+            return
+        axis = np.cross(a, b)
+        angle = float(np.arccos(np.clip(c, -1.0, 1.0)))
+        self.rotate(angle, axis)
+
+    # -- frame conversion ------------------------------------------------
+    def walk_to(self, node):
+        """(upwards, common, downwards) node tuples between self and `node`."""
+        mine, theirs = self.path, node.path
+        if mine[0] is not theirs[0]:
+            raise AppError("Nodes are not in the same tree.")
+        k = 0
+        while k < min(len(mine), len(theirs)) and mine[k] is theirs[k]:
+            k += 1
+        common = mine[k - 1]
+        upwards = tuple(reversed(mine[k:]))
+        downwards = tuple(theirs[k:])
+        return upwards, common, downwards
+
+    def path_to(self, node):
+        upwards, common, downwards = self.walk_to(node)
+        return upwards + (common,) + downwards
+
+    def transformation_to(self, node):
+        """4x4 matrix taking coordinates in this node's frame to `node`'s frame."""
+        if self is node:
+            return np.identity(4)
+        upwards, _, downwards = self.walk_to(node)
+        chain = [n.pose for n in upwards] + [np.linalg.inv(n.pose) for n in downwards]
+        if len(chain) == 1:
+            return chain[0]
+        return np.linalg.multi_dot(chain[::-1])
+
+    def point_to_node(self, point, node):
+        m = self.transformation_to(node)
+        p = np.ones(4)
+        p[:3] = point
+        return tuple((m @ p)[:3])
+
+    def vector_to_node(self, vector, node):
+        m = self.transformation_to(node)[:3, :3]
+        return tuple(m @ np.asarray(tuple(vector), dtype=np.float64))
+
+    # -- light -----------------------------------------------------------
+    def emit(self, num_rays=None):
+        if self.light is None:
+            raise AppError("Not a lighting node.")
+        for ray in self.light.emit(num_rays=num_rays):
+            yield ray
+
+
+class Scene(object):
+    """A scene graph of nodes rooted at `root`."""
+
+    def __init__(self, root=None):
+        super(Scene, self).__init__()
+        self.root = root
+
+    @property
+    def light_nodes(self):
+        """Nodes carrying a Light, in level order (the order rays cycle in)."""
+        from pvtrace_amd.light import Light
+
+        if self.root is None:
+            return []
+        return [n for n in self.root.levelorder() if isinstance(n.light, Light)]
+
+    @property
+    def component_nodes(self):
+        found = []
+        for node in self.root.levelorder():
+            if node.geometry is not None and node.geometry.material is not None:
+                found.extend(node.geometry.material.components)
+        return found
+
+    def emit(self, num_rays):
+        """Rays in the root frame, cycling round-robin over the lights."""
+        lights = self.light_nodes
+        for idx in range(num_rays):
+            node = lights[idx % len(lights)]
+            for ray in node.emit(1):
+                yield ray.representation(node, self.root)
+
+    def simulate(self, num_rays, seed=None, **kwargs):
+        """Trace on the MI355X engine; returns an `EngineResult`.
+
+        (The reference's Scene.simulate, pvtrace/scene/scene.py:197-313, fans the
+        Python tracer over a process pool; here the device engine is the tracer.)
+        """
+        from pvtrace_amd import engine
+
+        return engine.simulate(self, num_rays, seed=seed, **kwargs)

@@ -1,0 +1,323 @@
+"""Scene library shared by the tests, the golden-fixture generator and bench.py.
+
+Each builder returns a fresh `pvtrace_amd.Scene`.  The first five are the
+BASELINE.json configs; the rest exercise branches those do
+not reach (every phase function, scatterer/reactor, lifetimes, Null surfaces,
+rotated children, touching boxes, heatmap recorders).
+"""
+import functools
+
+import numpy as np
+
+from pvtrace_amd import (
+    Absorber, Box, Coating, CoatedSurfaceDelegate, Cylinder, Light, Luminophore, Material, Node,
+    NullSurfaceDelegate, Reactor, Scatterer, Scene, Sphere, Surface, cone, isotropic, lambertian,
+    rectangular_mask,
+)
+from pvtrace_amd.data import lumogen_f_red_305
+from pvtrace_amd.engine import Heatmap, Histogram, Recorder
+from pvtrace_amd.light import (
+    CircularMask, ConstantWavelengthMask, CubeMask, SpectrumWavelengthMask,
+)
+from pvtrace_amd.material import Cone, Distribution, HenyeyGreenstein, gaussian
+
+FACES = {
+    "top": (0, 0, 1), "bottom": (0, 0, -1), "right": (1, 0, 0), "left": (-1, 0, 0),
+    "far": (0, 1, 0), "near": (0, -1, 0),
+}
+
+
+def face_recorders(prefix="", hist=True):
+    """escaping x 6 facets (+80-bin wavelength histogram), lost, entering, reflected, killed."""
+    recs = []
+    for label, normal in FACES.items():
+        hs = [Histogram("wavelength", 400, 800, 80)] if hist else []
+        recs.append(Recorder(f"{prefix}{label}", event="escaping", facet=normal, histograms=hs))
+    recs += [
+        Recorder(f"{prefix}lost", event="lost"),
+        Recorder(f"{prefix}entering", event="entering"),
+        Recorder(f"{prefix}reflected", event="reflected"),
+        Recorder(f"{prefix}killed", event="killed"),
+    ]
+    return recs
+
+
+# -- config 1 -----------------------------------------------------------------
+def hello_world():
+    """examples/hello_world.py:8-32: glass ball in an air sphere, pi/8 cone."""
+    world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    ball = Node(name="ball-lens", geometry=Sphere(radius=1.0, material=Material(refractive_index=1.5)),
+                parent=world)
+    ball.location = (0, 0, 2)
+    Node(name="green-laser",
+         light=Light(direction=functools.partial(cone, np.pi / 8), name="green-laser"),
+         parent=world)
+    return Scene(world)
+
+
+# -- config 2 / 3 ---------------------------------------------------------------
+def lsc_equivalent(recorders=True, size=(5.0, 5.0, 1.0)):
+    """The plain-Fresnel equivalent of LSC((5,5,1)) (device/lsc.py:115-219):
+    world box 100x, slab n=1.5 with Lumogen F Red (10 cm^-1 peak, qy 1) + 0.1 cm^-1
+    background, point light at (0,0,5) flipped, 20-degree cone, 555 nm."""
+    l, w, d = size
+    x = np.arange(400, 800)
+    world = Node(name="World", geometry=Box((l * 100, w * 100, d * 100),
+                                            material=Material(refractive_index=1.0)))
+    Node(
+        name="LSC",
+        geometry=Box(
+            (l, w, d),
+            material=Material(
+                refractive_index=1.5,
+                components=[
+                    Luminophore(
+                        coefficient=np.column_stack((x, lumogen_f_red_305.absorption(x) * 10.0)),
+                        emission=np.column_stack((x, lumogen_f_red_305.emission(x))),
+                        quantum_yield=1.0, name="Lumogen F Red 305"),
+                    Absorber(0.1, name="Background"),
+                ],
+            ),
+        ),
+        parent=world,
+        recorders=face_recorders() if recorders else None,
+    )
+    light = Node(name="Light", parent=world,
+                 light=Light(direction=functools.partial(cone, np.radians(20)), name="Light"))
+    light.location = (0.0, 0.0, d * 5)
+    light.rotate(np.radians(180), (1, 0, 0))
+    return Scene(world)
+
+
+# -- config 4 -------------------------------------------------------------------
+def nested_cylinders(recorders=True):
+    """examples/nested_cylinders.py:21-64: two glass cylinders, the child rotated
+    and protruding from its parent, 30-degree cone from z=-1."""
+    world = Node(name="World", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    a = Node(name="A", geometry=Cylinder(length=2, radius=0.5, material=Material(refractive_index=1.5)),
+             parent=world)
+    a.translate((0, 0, 2))
+    a.rotate(np.pi * 0.2, (0, 1, 0))
+    b = Node(name="B", geometry=Cylinder(length=2.0, radius=0.4, material=Material(refractive_index=1.5)),
+             parent=a)
+    b.rotate(np.pi / 2, (1, 0, 0))
+    light = Node(name="Light (555nm)", parent=world,
+                 light=Light(direction=functools.partial(cone, np.radians(30)), name="Light (555nm)"))
+    light.translate((0, 0, -1))
+    if recorders:
+        a.recorders = [Recorder("A-escaping", event="escaping"), Recorder("A-entering", event="entering")]
+        b.recorders = [Recorder("B-escaping", event="escaping"), Recorder("B-entering", event="entering")]
+        world.recorders = [Recorder("exit", event="exit",
+                                    histograms=[Histogram("angle", 0.0, np.pi / 2, 18)])]
+    return Scene(world)
+
+
+# -- config 5 -------------------------------------------------------------------
+def coated_slab(recorders=True, scatter=1.0):
+    """examples/006 Coatings.ipynb cell 5: 10x10x1 slab with a perfect mirror on the
+    x>0, y>0 quadrant of the top face, rectangular 5x5 source above it, plus an
+    isotropic Scatterer of `scatter` cm^-1 (qy 1) in the slab (BASELINE config 5)."""
+    world = Node(name="world (air)", geometry=Box((15.0, 15.0, 15.0), material=Material(refractive_index=1.0)))
+    mirror = Coating((0, 0, 1), reflectivity=1.0, region=((0.0, None), (0.0, None), None))
+    comps = [Scatterer(float(scatter), name="Scatterer")] if scatter else []
+    slab = Node(
+        name="box (glass)",
+        geometry=Box((10.0, 10.0, 1.0),
+                     material=Material(refractive_index=1.5, components=comps,
+                                       surface=Surface(delegate=CoatedSurfaceDelegate([mirror])))),
+        parent=world,
+    )
+    if recorders:
+        slab.recorders = face_recorders(hist=False) + [
+            Recorder("top-reflect-map", event="reflected", facet=(0, 0, 1),
+                     histograms=[Heatmap("x", "y", (-5, 5, 20), (-5, 5, 20))])]
+    light = Node(name="Light", parent=world,
+                 light=Light(position=functools.partial(rectangular_mask, 5, 5), name="Light"))
+    light.location = (0, 0, 2)
+    light.rotate(np.radians(180), (1, 0, 0))
+    return Scene(world)
+
+
+# -- reference test / benchmark scenes ---------------------------------------------
+def fresnel_box():
+    """tests/test_engine.py:36-54: glass cube at z=2, pi/16 cone."""
+    world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    box = Node(name="box", geometry=Box((1.0, 1.0, 1.0), material=Material(refractive_index=1.5)),
+               parent=world)
+    box.location = (0.0, 0.0, 2.0)
+    Node(name="light", light=Light(direction=functools.partial(cone, np.pi / 16)), parent=world)
+    return Scene(world)
+
+
+def bench_slab(recorders=False):
+    """benchmarks/benchmark_engine.py:26-55 == tests/test_engine.py:57-93:
+    Gaussian dye qy 0.9 + 0.3 cm^-1 background, collimated light from below."""
+    x = np.linspace(300.0, 1000.0, 200)
+    absorption = np.column_stack((x, 5.0 * gaussian(x, 1.0, 480.0, 40.0)))
+    emission = np.column_stack((x, gaussian(x, 1.0, 600.0, 40.0)))
+    world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    slab = Node(
+        name="slab",
+        geometry=Box((5.0, 5.0, 1.0), material=Material(
+            refractive_index=1.5,
+            components=[
+                Luminophore(coefficient=absorption, emission=emission, quantum_yield=0.9, name="dye"),
+                Absorber(coefficient=0.3, name="background"),
+            ])),
+        parent=world,
+    )
+    light = Node(name="light", light=Light(), parent=world)
+    light.location = (0.0, 0.0, -3.0)
+    if recorders:
+        slab.recorders = [
+            Recorder("entering", event="entering", histograms=[Histogram("wavelength", 400, 900, 50)]),
+            Recorder("top", event="escaping", facet=(0, 0, 1),
+                     histograms=[Heatmap("x", "y", (-2.5, 2.5, 20), (-2.5, 2.5, 20))]),
+            Recorder("lost", event="lost"),
+        ]
+        world.recorders = [Recorder("exit", event="exit",
+                                    histograms=[Histogram("angle", 0.0, np.pi / 2, 18)])]
+    return Scene(world)
+
+
+# -- branch coverage --------------------------------------------------------------
+def kitchen_sink():
+    """Every component type, phase function, lifetime and surface tag at once:
+    a rotated box with HG scatterer + lossy luminophore with lifetimes, a sphere
+    with a Reactor and cone-phase scatterer, a Null-surface cylinder probe, two
+    lights (spectrum + circular mask, isotropic + cube mask) and 2-D recorders."""
+    x = np.linspace(350.0, 900.0, 111)
+    world = Node(name="world", geometry=Box((40.0, 40.0, 40.0), material=Material(
+        refractive_index=1.0, components=[Absorber(0.002, name="air-haze")])))
+    slab = Node(
+        name="slab",
+        geometry=Box((6.0, 4.0, 1.5), material=Material(
+            refractive_index=1.49,
+            components=[
+                Luminophore(np.column_stack((x, 2.5 * gaussian(x, 1.0, 520.0, 45.0))),
+                            emission=np.column_stack((x, gaussian(x, 1.0, 640.0, 35.0))),
+                            quantum_yield=0.85, tau_rad=6e-9, tau_nr=2e-9,
+                            phase_function=None, name="dye"),
+                Scatterer(0.4, phase_function=HenyeyGreenstein(0.7), quantum_yield=0.95, name="hg"),
+                Absorber(np.column_stack((x, 0.05 + 0.0005 * (x - 350.0))), tau_nr=1e-9, name="host"),
+            ])),
+        parent=world,
+    )
+    slab.translate((0.5, -0.3, 1.0))
+    slab.rotate(0.35, (1.0, 0.4, 0.2))
+    ball = Node(
+        name="ball",
+        geometry=Sphere(1.2, material=Material(
+            refractive_index=1.33,
+            components=[Reactor(0.6, name="reactor"),
+                        Scatterer(0.8, phase_function=Cone(0.5), name="cone-scatter")])),
+        parent=world,
+    )
+    ball.location = (-4.0, 1.0, -2.0)
+    probe = Node(
+        name="probe",
+        geometry=Cylinder(3.0, 0.8, material=Material(
+            refractive_index=1.0, surface=Surface(delegate=NullSurfaceDelegate()))),
+        parent=world,
+    )
+    probe.location = (3.0, 3.0, -3.0)
+    probe.rotate(1.1, (0.0, 1.0, 0.3))
+    inner = Node(
+        name="inner",
+        geometry=Cylinder(1.0, 0.3, material=Material(
+            refractive_index=1.7, components=[Absorber(1.5, name="core")])),
+        parent=slab,
+    )
+    inner.rotate(np.pi / 3, (0, 1, 0))
+    spectrum = Distribution(x, gaussian(x, 1.0, 500.0, 60.0))
+    l1 = Node(name="lamp", parent=world, light=Light(
+        wavelength=SpectrumWavelengthMask(spectrum), position=CircularMask(1.5),
+        direction=Cone(0.3), name="lamp"))
+    l1.location = (0.0, 0.0, 8.0)
+    l1.rotate(np.pi, (1, 0, 0))
+    l2 = Node(name="glow", parent=world, light=Light(
+        wavelength=ConstantWavelengthMask(480.0), position=CubeMask(0.5, 0.5, 0.5),
+        direction=isotropic, name="glow"))
+    l2.location = (-3.0, -2.0, 0.5)
+    slab.recorders = [
+        Recorder("slab-in", event="entering", histograms=[
+            Histogram("wavelength", 350, 900, 55), Heatmap("x", "y", (-3, 3, 12), (-2, 2, 8))]),
+        Recorder("slab-out-top", event="escaping", facet=tuple(
+            np.asarray(slab.transformation_to(world))[:3, :3] @ np.array([0.0, 0.0, 1.0])),
+            histograms=[Histogram("angle", 0, np.pi / 2, 9), Histogram("duration", 0, 5e-8, 25)]),
+        Recorder("slab-lost", event="lost", histograms=[Histogram("pathlength", 0, 40, 20),
+                                                        Histogram("z", -0.75, 0.75, 6)]),
+        Recorder("slab-reflected", event="reflected"),
+    ]
+    ball.recorders = [Recorder("ball-reacted", event="reacted"),
+                      Recorder("ball-entering", event="entering")]
+    probe.recorders = [Recorder("probe-cross", event="entering"),
+                       Recorder("probe-leave", event="escaping")]
+    inner.recorders = [Recorder("core-lost", event="lost")]
+    world.recorders = [Recorder("world-exit", event="exit",
+                                histograms=[Heatmap("angle", "wavelength", (0, np.pi / 2, 6), (350, 900, 11))]),
+                       Recorder("world-lost", event="lost"), Recorder("world-killed", event="killed")]
+    return Scene(world)
+
+
+def touching_boxes():
+    """Two glass cubes sharing a face (reference tests/test_refractored_tracer.py:253-299)
+    inside a box world; a slightly divergent beam runs through both."""
+    world = Node(name="world", geometry=Box((10.0, 10.0, 10.0), material=Material(refractive_index=1.0)))
+    a = Node(name="a", geometry=Box((1.0, 1.0, 1.0), material=Material(refractive_index=1.5)), parent=world)
+    a.location = (0.0, 0.0, 0.5)
+    b = Node(name="b", geometry=Box((1.0, 1.0, 1.0), material=Material(refractive_index=1.5)), parent=world)
+    b.location = (0.0, 0.0, 1.5)
+    light = Node(name="light", light=Light(direction=Cone(0.1)), parent=world)
+    light.location = (0.0, 0.0, -1.0)
+    for node in (a, b):
+        node.recorders = [Recorder(f"{node.name}-in", event="entering"),
+                          Recorder(f"{node.name}-out", event="escaping")]
+    return Scene(world)
+
+
+def trapped_light():
+    """Emitter INSIDE a lossless high-index sphere: total internal reflection forever,
+    so photons die by the maxsteps / event-budget KILL paths."""
+    world = Node(name="world", geometry=Sphere(10.0, material=Material(refractive_index=1.0)))
+    Node(name="orb", geometry=Sphere(1.0, material=Material(refractive_index=2.4)), parent=world,
+         recorders=[Recorder("orb-killed", event="killed"), Recorder("orb-out", event="escaping")])
+    light = Node(name="light", light=Light(direction=isotropic), parent=world)
+    light.location = (0.0, 0.0, 0.9)
+    world.recorders = [Recorder("exit", event="exit")]
+    return Scene(world)
+
+
+def lambertian_sheet():
+    """A Lambertian perfect mirror sheet (AirGapMirror-style coating on every face)
+    lit by a lambertian source from above."""
+    world = Node(name="world", geometry=Box((20.0, 20.0, 20.0), material=Material(refractive_index=1.0)))
+    coats = [Coating(n, reflectivity=1.0, reflection="lambertian") for n in FACES.values()]
+    sheet = Node(name="sheet", parent=world, geometry=Box(
+        (4.0, 4.0, 0.25), material=Material(refractive_index=1.0,
+                                            surface=Surface(delegate=CoatedSurfaceDelegate(coats)))))
+    sheet.rotate(0.4, (0.0, 1.0, 0.0))
+    sheet.recorders = [Recorder("sheet-reflected", event="reflected",
+                                histograms=[Histogram("angle", 0, np.pi / 2, 9)])]
+    light = Node(name="light", parent=world, light=Light(direction=lambertian, name="light"))
+    light.location = (0.0, 0.0, 3.0)
+    light.rotate(np.pi, (1, 0, 0))
+    world.recorders = [Recorder("exit", event="exit", histograms=[Histogram("z", -10, 10, 4)])]
+    return Scene(world)
+
+
+REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
+    "hello_world": hello_world,
+    "lsc_equivalent": lsc_equivalent,
+    "nested_cylinders": nested_cylinders,
+    "fresnel_box": fresnel_box,
+    "bench_slab": lambda: bench_slab(recorders=True),
+    "kitchen_sink": kitchen_sink,
+    "touching_boxes": touching_boxes,
+    "trapped_light": trapped_light,
+}
+EXTENSION_SCENES = {   # need the coating extension
+    "coated_slab": coated_slab,
+    "lambertian_sheet": lambertian_sheet,
+}
+ALL_SCENES = dict(REFERENCE_SCENES, **EXTENSION_SCENES)
