@@ -1,0 +1,1283 @@
+// pvt_trace.hip — the photon loop of pvtrace on CDNA4 (gfx950), and the C ABI
+// declared in include/pvtrace_hip.h.
+//
+// What it replaces: reference pvtrace/engine/_kernel.pyx trace_one / trace_bundle
+// (:603-1115), i.e. the per-photon while-alive loop behind engine.simulate().
+// This is not a translation of that file: the reference walks one ray per CPU
+// thread through per-thread scratch arrays; here
+//
+//   * one wavefront LANE owns one live photon; a persistent workgroup keeps all
+//     64 lanes of each wave busy by refilling dead lanes from a global ray
+//     cursor (wave-level ballot + prefix rank, one atomic per 64 rays);
+//   * the scene tables (a few KB) are packed once into two blobs in HBM and
+//     staged into LDS per workgroup; wave-uniform reads (the node loop, the
+//     recorder loop) go through the scalar cache from the global copy, lane-
+//     divergent reads (spectra binary search, per-lane node rows) hit LDS;
+//   * hit classification is streaming (nearest / second nearest / container are
+//     folded while the nodes are intersected) — no per-ray hit arrays;
+//   * every lane's event (row to log, recorder to tally) is deferred to ONE
+//     re-converged block at the end of the step instead of being emitted from
+//     each divergent branch;
+//   * recorders accumulate in LDS (integer + f64 atomics) and are flushed with
+//     one global atomic per slot per workgroup;
+//   * all arithmetic is FP64 with FMA contraction off and the transcendental
+//     functions of pvt_math.h, so a photon's whole history is bit-identical to
+//     the CPU referee (oracle/pvt_oracle.c, math_mode 1).
+//
+// No MFMA: there is no dense contraction anywhere on this path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pvtrace_hip.h"
+#include "pvt_math.h"
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 wavefronts
+constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
+constexpr double kEps = 2.220446049250313e-13;       // _kernel.pyx:29
+constexpr double kAlphaZero = 1e-8;                  // :32
+constexpr double kCcm = 2.99792458e10;               // :33
+constexpr double kPi = 3.14159265358979323846;
+constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
+
+// Offsets (in elements) of every table inside the double / int32 blobs.
+struct Off {
+    // doubles
+    int geom_params, w2l, l2w, nidx, comp_qy, comp_tau_rad, comp_tau_nr, comp_phase_param;
+    int abs_x, abs_y, ems_x, ems_cdf, rec_facet, rec_atol, h_lo_a, h_hi_a, h_lo_b, h_hi_b;
+    int coat_facet, coat_lo, coat_hi, coat_refl;
+    // int32
+    int geom_type, surf_type, comp_start, comp_count, coat_start, coat_count, comp_type;
+    int comp_phase_type, abs_start, abs_n, ems_start, ems_n, rec_node, rec_event, rec_has_facet;
+    int rec_hist_start, rec_hist_n, h_prop_a, h_prop_b, h_na, h_nb, h_offset, coat_rmode, coat_tmode;
+};
+
+struct EmitOff {  // emitter blobs (global only; read once per photon)
+    int wl_value, pos_param, dir_param, l2w, spec_x, spec_cdf;         // doubles
+    int wl_type, wl_spec_start, wl_spec_n, pos_type, dir_type;        // int32
+};
+
+struct KArgs {
+    const double* gd;   // scene double blob (HBM)
+    const int* gi;      // scene int blob
+    const double* ed;   // emitter blobs (may be null)
+    const int* ei;
+    Off off;
+    EmitOff eoff;
+    int nd, ni;         // blob lengths
+    int n_nodes, root, n_rec, total_bins, n_coat, n_lights;
+    // rays in (null -> device emission)
+    const double* pos;
+    const double* dir;
+    const double* wl;
+    unsigned int n_rays;
+    unsigned int* cursor;
+    unsigned long long seed;       // + ray_offset folded in by the host
+    unsigned long long emit_seed;  // + nothing; global index added per ray
+    unsigned long long ray_offset;
+    int maxsteps, max_events, emit_method;
+    long long record_every;
+    // outputs
+    long long* rec_distinct;
+    long long* rec_crossings;
+    double* rec_sums;
+    long long* rec_bins;
+    PvtEventLog log;
+    int bins_in_lds;
+};
+
+// ------------------------------------------------------------------ RNG
+struct Rng {
+    unsigned long long s0, s1, s2, s3;
+};
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& st) {
+    st += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void rng_seed(Rng& r, unsigned long long seed) {
+    unsigned long long st = seed;
+    r.s0 = splitmix64(st);
+    r.s1 = splitmix64(st);
+    r.s2 = splitmix64(st);
+    r.s3 = splitmix64(st);
+}
+__device__ __forceinline__ double rng_uniform(Rng& r) {
+    unsigned long long result = r.s0 + r.s3;
+    unsigned long long t = r.s1 << 17;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = (r.s3 << 45) | (r.s3 >> 19);
+    return (double)(result >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------ table access
+// TAB_LDS: divergent reads come from the LDS copy; uniform reads always come
+// from the global blob so the compiler can use scalar loads.
+template <bool TAB_LDS>
+struct Tables {
+    const double* __restrict__ gd;
+    const int* __restrict__ gi;
+    const double* ld;  // LDS copies (== gd/gi when !TAB_LDS)
+    const int* li;
+    __device__ __forceinline__ double du(int i) const { return gd[i]; }  // uniform index
+    __device__ __forceinline__ int iu(int i) const { return gi[i]; }
+    __device__ __forceinline__ double dv(int i) const { return TAB_LDS ? ld[i] : gd[i]; }  // per-lane index
+    __device__ __forceinline__ int iv(int i) const { return TAB_LDS ? li[i] : gi[i]; }
+};
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ double dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// np.interp-like clamped interpolation, binary search `xs[mid] <= x` (_kernel.pyx:219-238)
+template <bool TAB_LDS>
+__device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n) {
+    if (n == 1) return T.dv(ys);
+    double x0 = T.dv(xs), xl = T.dv(xs + n - 1);
+    if (x <= x0) return T.dv(ys);
+    if (x >= xl) return T.dv(ys + n - 1);
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (T.dv(xs + mid) <= x) lo = mid; else hi = mid;
+    }
+    double xlo = T.dv(xs + lo), xhi = T.dv(xs + hi), ylo = T.dv(ys + lo), yhi = T.dv(ys + hi);
+    if (xhi == xlo) return ylo;
+    return ylo + (yhi - ylo) * (x - xlo) / (xhi - xlo);
+}
+// same, tables in global memory (emitter spectra)
+__device__ __forceinline__ double interp_global(const double* xs, const double* ys, int n, double x) {
+    if (n == 1) return ys[0];
+    if (x <= xs[0]) return ys[0];
+    if (x >= xs[n - 1]) return ys[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xs[mid] <= x) lo = mid; else hi = mid;
+    }
+    if (xs[hi] == xs[lo]) return ys[lo];
+    return ys[lo] + (ys[hi] - ys[lo]) * (x - xs[lo]) / (xs[hi] - xs[lo]);
+}
+
+__device__ __forceinline__ V3 sphere_direction(double theta, double phi) {
+    double st, ct, sp, cp;
+    pvt_sincos(theta, &st, &ct);
+    pvt_sincos(phi, &sp, &cp);
+    return V3{st * cp, st * sp, ct};
+}
+
+// phase functions (_kernel.pyx:455-476); draw order is part of the contract
+__device__ __forceinline__ V3 sample_phase(int type, double param, Rng& rng) {
+    double theta, phi;
+    if (type == PVT_PHASE_HG && pvt_fabs(param) >= kEps) {
+        double g = param;
+        double g1 = rng_uniform(rng);
+        double s = 2.0 * g1 - 1.0;
+        double q = (1.0 - g * g) / (1.0 + g * s);
+        double mu = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
+        phi = 2.0 * kPi * rng_uniform(rng);
+        theta = pvt_acos(mu);
+    } else if (type == PVT_PHASE_CONE) {
+        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+        theta = pvt_asin(pvt_sqrt(g1) * pvt_sin(param));
+        phi = 2.0 * kPi * g2;
+    } else {
+        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+        phi = 2.0 * kPi * g1;
+        theta = pvt_acos(2.0 * g2 - 1.0);
+    }
+    return sphere_direction(theta, phi);
+}
+
+// Fresnel (_kernel.pyx:406-419)
+__device__ __forceinline__ double fresnel_reflectivity(double angle, double n1, double n2) {
+    if (n2 < n1 && angle > pvt_asin(n2 / n1)) return 1.0;
+    double s, c;
+    pvt_sincos(angle, &s, &c);
+    double q = n1 / n2 * s;
+    double k = pvt_sqrt(1.0 - q * q);
+    double rs1 = n1 * c - n2 * k, rs2 = n1 * c + n2 * k;
+    double rs = (rs1 / rs2) * (rs1 / rs2);
+    double rp1 = n1 * k - n2 * c, rp2 = n1 * k + n2 * c;
+    double rp = (rp1 / rp2) * (rp1 / rp2);
+    return 0.5 * (rs + rp);
+}
+
+// ----------------------------------------------------------- emission
+// One ray from its own stream (mirrors oracle pvt_oracle_emit; distributions of
+// reference pvtrace/engine/emit.py:22-89).
+__device__ __forceinline__ void emit_one(const KArgs& A, unsigned long long gi, V3& pos, V3& dir, double& wl) {
+    const double* ed = A.ed;
+    const int* ei = A.ei;
+    const EmitOff& E = A.eoff;
+    Rng rng;
+    rng_seed(rng, (A.emit_seed + gi) ^ kEmitSalt);
+    int li = (int)(gi % (unsigned long long)A.n_lights);
+    if (ei[E.wl_type + li] == PVT_WL_SPECTRUM) {
+        double u = rng_uniform(rng);
+        int s = ei[E.wl_spec_start + li];
+        wl = interp_global(ed + E.spec_cdf + s, ed + E.spec_x + s, ei[E.wl_spec_n + li], u);
+    } else {
+        wl = ed[E.wl_value + li];
+    }
+    V3 lp{0.0, 0.0, 0.0}, ld{0.0, 0.0, 1.0};
+    const double* pp = ed + E.pos_param + li * 3;
+    int pt = ei[E.pos_type + li];
+    if (pt == PVT_POS_RECT) {
+        lp.x = -pp[0] + 2.0 * pp[0] * rng_uniform(rng);
+        lp.y = -pp[1] + 2.0 * pp[1] * rng_uniform(rng);
+    } else if (pt == PVT_POS_CIRCLE) {
+        double ang = 2.0 * kPi * rng_uniform(rng);
+        double rad = pvt_sqrt(rng_uniform(rng)) * pp[0];
+        double s, c;
+        pvt_sincos(ang, &s, &c);
+        lp.x = rad * c;
+        lp.y = rad * s;
+    } else if (pt == PVT_POS_CUBE) {
+        lp.x = -pp[0] + 2.0 * pp[0] * rng_uniform(rng);
+        lp.y = -pp[1] + 2.0 * pp[1] * rng_uniform(rng);
+        lp.z = -pp[2] + 2.0 * pp[2] * rng_uniform(rng);
+    }
+    double prm = ed[E.dir_param + li];
+    int dt = ei[E.dir_type + li];
+    if (dt == PVT_DIR_CONE) ld = sample_phase(PVT_PHASE_CONE, prm, rng);
+    else if (dt == PVT_DIR_ISOTROPIC) ld = sample_phase(PVT_PHASE_ISOTROPIC, 0.0, rng);
+    else if (dt == PVT_DIR_HG) ld = sample_phase(PVT_PHASE_HG, prm, rng);
+    else if (dt == PVT_DIR_LAMBERTIAN) {
+        double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
+        ld = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
+    }
+    const double* m = ed + E.l2w + li * 16;
+    pos.x = m[0] * lp.x + m[1] * lp.y + m[2] * lp.z + m[3];
+    pos.y = m[4] * lp.x + m[5] * lp.y + m[6] * lp.z + m[7];
+    pos.z = m[8] * lp.x + m[9] * lp.y + m[10] * lp.z + m[11];
+    dir.x = m[0] * ld.x + m[1] * ld.y + m[2] * ld.z;
+    dir.y = m[4] * ld.x + m[5] * ld.y + m[6] * ld.z;
+    dir.z = m[8] * ld.x + m[9] * ld.y + m[10] * ld.z;
+}
+
+__global__ void __launch_bounds__(kBlock) emit_kernel(KArgs A, double* opos, double* odir, double* owl) {
+    unsigned int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= A.n_rays) return;
+    V3 p, d;
+    double wl;
+    emit_one(A, A.ray_offset + i, p, d, wl);
+    opos[i * 3] = p.x; opos[i * 3 + 1] = p.y; opos[i * 3 + 2] = p.z;
+    odir[i * 3] = d.x; odir[i * 3 + 1] = d.y; odir[i * 3 + 2] = d.z;
+    owl[i] = wl;
+}
+
+// ----------------------------------------------------------- event log
+template <bool RECORD>
+__device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev, int kind, int hit,
+                                        int container, int adjacent, int component, int source,
+                                        const V3& pos, const V3& dir, bool has_normal, const V3& nrm,
+                                        double wl, double travelled, double duration) {
+    if constexpr (RECORD) {
+        if (base < 0 || nev >= A.max_events) return;
+        long long row = base + nev;
+        const PvtEventLog& L = A.log;
+        L.kind[row] = (uint8_t)kind;
+        L.hit[row] = hit;
+        L.container[row] = container;
+        L.adjacent[row] = adjacent;
+        L.component[row] = component;
+        L.source[row] = source;
+        L.position[row * 3] = pos.x; L.position[row * 3 + 1] = pos.y; L.position[row * 3 + 2] = pos.z;
+        L.direction[row * 3] = dir.x; L.direction[row * 3 + 1] = dir.y; L.direction[row * 3 + 2] = dir.z;
+        L.normal[row * 3] = has_normal ? nrm.x : 0.0;
+        L.normal[row * 3 + 1] = has_normal ? nrm.y : 0.0;
+        L.normal[row * 3 + 2] = has_normal ? nrm.z : 0.0;
+        L.wavelength[row] = wl;
+        L.travelled[row] = travelled;
+        L.duration[row] = duration;
+        nev += 1;
+    }
+}
+
+// LDS accumulator layout (per workgroup), after the table copies:
+//   u32 cross[n_rec] | u32 distinct[n_rec] | f64 sums[n_rec*8] | u32 bins[total_bins] (if they fit)
+struct Accum {
+    unsigned int* cross;
+    unsigned int* distinct;
+    double* sums;
+    unsigned int* bins;  // null -> straight to global
+};
+
+template <int SEENW>
+struct Seen {
+    unsigned long long w[SEENW];
+};
+
+// --------------------------------------------------------------- kernel
+template <bool RECORD, bool TAB_LDS, int SEENW, bool COATED>
+__global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
+    extern __shared__ double smem[];
+    const Off& O = A.off;
+
+    // ---- stage tables + zero accumulators --------------------------------
+    double* lds_d = smem;
+    int nd_lds = TAB_LDS ? A.nd : 0;
+    int ni_lds = TAB_LDS ? ((A.ni + 1) & ~1) : 0;  // keep 8-byte alignment after the ints
+    int* lds_i = reinterpret_cast<int*>(lds_d + nd_lds);
+    double* acc_sums = reinterpret_cast<double*>(lds_i + ni_lds);
+    unsigned int* acc_cross = reinterpret_cast<unsigned int*>(acc_sums + A.n_rec * 8);
+    unsigned int* acc_distinct = acc_cross + A.n_rec;
+    unsigned int* acc_bins = acc_distinct + A.n_rec;
+    if constexpr (TAB_LDS) {
+        for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
+        for (int i = threadIdx.x; i < A.ni; i += kBlock) lds_i[i] = A.gi[i];
+    }
+    for (int i = threadIdx.x; i < A.n_rec * 8; i += kBlock) acc_sums[i] = 0.0;
+    for (int i = threadIdx.x; i < A.n_rec * 2; i += kBlock) acc_cross[i] = 0u;
+    if (A.bins_in_lds)
+        for (int i = threadIdx.x; i < A.total_bins; i += kBlock) acc_bins[i] = 0u;
+    __syncthreads();
+
+    Tables<TAB_LDS> T{A.gd, A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi};
+
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    // ---- per-photon state --------------------------------------------------
+    bool alive = false;
+    V3 pos{0, 0, 0}, dir{0, 0, 1};
+    double wl = 0.0, travelled = 0.0, duration = 0.0;
+    Rng rng{0, 0, 0, 0};
+    int count = 0, source = -1, nev = 0;
+    long long base = -1;
+    long long rec_slot = 0;
+    Seen<SEENW> seen;
+#pragma unroll
+    for (int w = 0; w < SEENW; w++) seen.w[w] = 0ull;
+
+    // wave-uniform ray window claimed from the global cursor
+    unsigned int w_next = 0, w_end = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // ================= refill dead lanes ==============================
+        unsigned long long need = __ballot(!alive);
+        for (int pass = 0; pass < 2 && need != 0ull; pass++) {
+            if (w_next >= w_end) {
+                if (exhausted) break;
+                unsigned int b = 0;
+                if (lane == 0) b = atomicAdd(A.cursor, (unsigned int)kChunk);
+                b = __builtin_amdgcn_readfirstlane(b);
+                if (b >= A.n_rays) { exhausted = true; break; }
+                w_next = b;
+                w_end = (A.n_rays - b < (unsigned int)kChunk) ? A.n_rays : b + kChunk;
+            }
+            unsigned int avail = w_end - w_next;
+            unsigned int rank = __popcll(need & lane_lt);
+            unsigned int want = __popcll(need);
+            if (!alive && rank < avail) {
+                unsigned int i = w_next + rank;
+                if (A.pos != nullptr) {
+                    pos = V3{A.pos[i * 3ull], A.pos[i * 3ull + 1], A.pos[i * 3ull + 2]};
+                    dir = V3{A.dir[i * 3ull], A.dir[i * 3ull + 1], A.dir[i * 3ull + 2]};
+                    wl = A.wl[i];
+                } else {
+                    emit_one(A, A.ray_offset + i, pos, dir, wl);
+                }
+                rng_seed(rng, A.seed + (unsigned long long)i);
+                travelled = 0.0;
+                duration = 0.0;
+                count = 0;
+                source = -1;
+                nev = 0;
+#pragma unroll
+                for (int w = 0; w < SEENW; w++) seen.w[w] = 0ull;
+                alive = true;
+                if constexpr (RECORD) {
+                    base = -1;
+                    if (A.record_every > 0 && (long long)i % A.record_every == 0) {
+                        rec_slot = (long long)i / A.record_every;
+                        base = rec_slot * A.max_events;
+                    }
+                    log_row<RECORD>(A, base, nev, PVT_EV_GENERATE, -1, -1, -1, -1, source, pos, dir, false,
+                                    pos, wl, travelled, duration);
+                }
+            }
+            w_next += (want < avail) ? want : avail;
+            need = __ballot(!alive);
+        }
+        if (__ballot(alive) == 0ull) break;  // wave drained and cursor exhausted
+
+        // ================= one step for every live lane ==================
+        // deferred event of this step
+        int ev_kind = -1, ev_hit = -1, ev_container = -1, ev_adjacent = -1, ev_component = -1;
+        bool ev_normal = false, terminal = false;
+        int t_sel = -1, t_node = -1;
+        bool t_normal = false;
+        double t_angle = 0.0;
+        V3 nrm{0, 0, 0}, lpos{0, 0, 0};
+
+        if (alive) {
+            count += 1;
+            bool budget_kill = false;
+            if constexpr (RECORD) budget_kill = (base >= 0 && nev >= A.max_events - 1);
+            if (budget_kill) {
+                // event budget exhausted: KILL row, no tally (_kernel.pyx:658-663)
+                ev_kind = PVT_EV_KILL;
+                terminal = true;
+            } else {
+                // ---- intersect every node, fold nearest/second/container ----
+                int nhits = 0, n1 = -1, n2 = -1, cnode = -1;
+                double t1 = INFINITY, t2 = INFINITY, cbest = INFINITY;
+                for (int node = 0; node < A.n_nodes; node++) {
+                    const int m = O.w2l + node * 12;
+                    V3 o, d;
+                    o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + T.du(m + 3);
+                    o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + T.du(m + 7);
+                    o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + T.du(m + 11);
+                    d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
+                    d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
+                    d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
+                    const int gp = O.geom_params + node * 4;
+                    const int gt = T.iu(O.geom_type + node);
+                    // Hits are folded as they are found, in the reference's (node, k)
+                    // order, so no per-ray hit list exists; the tie-breaks equal the
+                    // reference's argmin scans over its hit arrays (:684-714).
+                    int nl = 0;
+                    double tfirst = 0.0;
+                    auto fold = [&](double t) {
+                        if (nl == 0) tfirst = t;
+                        nl += 1;
+                        if (nhits == 0) { t1 = t; n1 = node; }
+                        else if (t < t1) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
+                        else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
+                        nhits += 1;
+                    };
+                    if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
+                        double tmin = -INFINITY, tmax = INFINITY;
+                        bool miss = false;
+                        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            double sz = T.du(gp + a);
+                            double lo = -0.5 * sz, hi = 0.5 * sz;
+                            if (pvt_fabs(dd[a]) < 1e-300) {
+                                if (oo[a] < lo || oo[a] > hi) miss = true;
+                            } else {
+                                double inv = 1.0 / dd[a];
+                                double ta = (lo - oo[a]) * inv, tb = (hi - oo[a]) * inv;
+                                if (ta > tb) { double tmp = ta; ta = tb; tb = tmp; }
+                                if (ta > tmin) tmin = ta;
+                                if (tb < tmax) tmax = tb;
+                            }
+                        }
+                        if (!miss && !(tmax < tmin)) {
+                            if (tmin > kEps) fold(tmin);
+                            if (tmax > kEps) fold(tmax);
+                        }
+                    } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
+                        double radius = T.du(gp);
+                        double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
+                        double disc = b * b - 4.0 * a * c;
+                        if (!(disc < 0.0)) {
+                            double sq = pvt_sqrt(disc);
+                            double t = (-b - sq) / (2.0 * a);
+                            if (t > kEps) fold(t);
+                            t = (-b + sq) / (2.0 * a);
+                            if (t > kEps) fold(t);
+                        }
+                    } else {  // capped z cylinder (:301-345)
+                        double half = 0.5 * T.du(gp), radius = T.du(gp + 1);
+                        double a = d.x * d.x + d.y * d.y;
+                        if (a > 1e-300) {
+                            double b = 2.0 * (o.x * d.x + o.y * d.y);
+                            double c = o.x * o.x + o.y * o.y - radius * radius;
+                            double disc = b * b - 4.0 * a * c;
+                            if (disc >= 0.0) {
+                                double sq = pvt_sqrt(disc);
+                                double t = (-b - sq) / (2.0 * a);
+                                double z = o.z + t * d.z;
+                                if (z > -half && z < half && t > kEps) fold(t);
+                                t = (-b + sq) / (2.0 * a);
+                                z = o.z + t * d.z;
+                                if (z > -half && z < half && t > kEps) fold(t);
+                            }
+                        }
+                        if (pvt_fabs(d.z) > 1e-300) {
+                            double t = (-half - o.z) / d.z;
+                            double x = o.x + t * d.x, y = o.y + t * d.y;
+                            if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                            t = (half - o.z) / d.z;
+                            x = o.x + t * d.x;
+                            y = o.y + t * d.y;
+                            if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                        }
+                    }
+                    if (nl == 1 && tfirst < cbest) { cbest = tfirst; cnode = node; }
+                }
+
+                if (nhits == 0) {
+                    terminal = true;  // nothing ahead: the ray vanishes silently (:681-682)
+                } else {
+                    const int hit = n1;
+                    const double t0 = t1;
+                    int container, adjacent;
+                    if (nhits == 1) { container = hit; adjacent = -1; }
+                    else {
+                        container = (cnode >= 0) ? cnode : hit;
+                        adjacent = (container == hit) ? n2 : hit;
+                    }
+                    ev_container = container;
+
+                    if (count > A.maxsteps) {  // (:716-723)
+                        ev_kind = PVT_EV_KILL;
+                        terminal = true;
+                        t_sel = PVT_REC_KILLED; t_node = container;
+                    } else {
+                        const double n_container = T.dv(O.nidx + container);
+                        if (hit == A.root) {  // leaves the scene (:728-744)
+                            pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
+                            travelled += t0;
+                            duration += t0 * n_container / kCcm;
+                            ev_kind = PVT_EV_EXIT; ev_hit = hit; ev_adjacent = adjacent;
+                            terminal = true;
+                            t_sel = PVT_REC_EXIT; t_node = hit; t_normal = true;
+                        } else {
+                            // ---- volume absorption (:746-760) ----------------
+                            const int cbase = T.iv(O.comp_start + container);
+                            const int ccount = T.iv(O.comp_count + container);
+                            double alpha = 0.0;
+                            for (int k = 0; k < ccount; k++) {
+                                int c = cbase + k;
+                                int s = T.iv(O.abs_start + c);
+                                alpha += interp_clamped(T, wl, O.abs_x + s, O.abs_y + s, T.iv(O.abs_n + c));
+                            }
+                            double depth = INFINITY;
+                            if (alpha > kAlphaZero) depth = -pvt_log(1.0 - rng_uniform(rng)) / alpha;
+
+                            if (depth < t0) {  // absorbed (:762-832)
+                                pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
+                                travelled += depth;
+                                duration += depth * n_container / kCcm;
+                                double target = rng_uniform(rng) * alpha, running = 0.0;
+                                int comp = cbase;
+                                for (int k = 0; k < ccount; k++) {
+                                    int c = cbase + k;
+                                    int s = T.iv(O.abs_start + c);
+                                    running += interp_clamped(T, wl, O.abs_x + s, O.abs_y + s, T.iv(O.abs_n + c));
+                                    if (target <= running) { comp = c; break; }
+                                }
+                                log_row<RECORD>(A, base, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
+                                                dir, false, pos, wl, travelled, duration);
+                                const int ctype = T.iv(O.comp_type + comp);
+                                ev_component = comp;
+                                bool radiative = false;
+                                if (ctype == PVT_COMP_SCATTERER || ctype == PVT_COMP_LUMINOPHORE)
+                                    radiative = rng_uniform(rng) < T.dv(O.comp_qy + comp);
+                                if (radiative) {
+                                    dir = sample_phase(T.iv(O.comp_phase_type + comp), T.dv(O.comp_phase_param + comp), rng);
+                                    source = comp;
+                                    if (ctype == PVT_COMP_LUMINOPHORE) {
+                                        const int es = T.iv(O.ems_start + comp), en = T.iv(O.ems_n + comp);
+                                        double p1;
+                                        if (A.emit_method == PVT_EMIT_FULL) {
+                                            p1 = 0.0;
+                                        } else {
+                                            double e_nm = wl;
+                                            if (A.emit_method == PVT_EMIT_KT) {
+                                                const double kb_ev = 1.380649e-23 / 1.60217662e-19;
+                                                double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
+                                                e_nm = 1240.0 / e_ev;
+                                            }
+                                            p1 = interp_clamped(T, e_nm, O.ems_x + es, O.ems_cdf + es, en);
+                                        }
+                                        double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
+                                        wl = interp_clamped(T, gamma, O.ems_cdf + es, O.ems_x + es, en);
+                                        double tau = T.dv(O.comp_tau_rad + comp);
+                                        if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
+                                        ev_kind = PVT_EV_EMIT;
+                                    } else {
+                                        ev_kind = PVT_EV_SCATTER;
+                                    }
+                                } else {
+                                    double tau = T.dv(O.comp_tau_nr + comp);
+                                    if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
+                                    if (ctype == PVT_COMP_REACTOR) { ev_kind = PVT_EV_REACT; t_sel = PVT_REC_REACTED; }
+                                    else { ev_kind = PVT_EV_NONRADIATIVE; t_sel = PVT_REC_LOST; }
+                                    t_node = container;
+                                    terminal = true;
+                                }
+                            } else {
+                                // ---- surface interaction (:834-895) ---------
+                                pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
+                                travelled += t0;
+                                duration += t0 * n_container / kCcm;
+                                ev_hit = hit;
+                                if (adjacent < 0) {  // malformed scene (:840-845)
+                                    ev_kind = PVT_EV_KILL;
+                                    terminal = true;
+                                } else {
+                                    ev_adjacent = adjacent;
+                                    t_node = hit; t_normal = true; ev_normal = true;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- local point + outward world normal of the node the event refers to.
+        // Shared by EXIT and surface events (re-converged: one copy of the code).
+        const bool need_frame = alive && (t_normal || (t_sel >= 0 && t_node >= 0));
+        V3 nloc{0, 0, 0};
+        if (need_frame) {
+            const int m = O.w2l + t_node * 12;
+            lpos.x = T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(m + 3);
+            lpos.y = T.dv(m + 4) * pos.x + T.dv(m + 5) * pos.y + T.dv(m + 6) * pos.z + T.dv(m + 7);
+            lpos.z = T.dv(m + 8) * pos.x + T.dv(m + 9) * pos.y + T.dv(m + 10) * pos.z + T.dv(m + 11);
+            if (t_normal) {  // outward normal (_kernel.pyx:359-400)
+                const int gp = O.geom_params + t_node * 4;
+                const int gt = T.iv(O.geom_type + t_node);
+                if (gt == PVT_GEOM_BOX) {
+                    double best = INFINITY;
+                    int baxis = 0;
+                    double bsign = 1.0;
+                    const double pp[3] = {lpos.x, lpos.y, lpos.z};
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        double hs = 0.5 * T.dv(gp + a);
+                        double dm = pvt_fabs(pp[a] - (-1.0) * hs);
+                        if (dm < best) { best = dm; baxis = a; bsign = -1.0; }
+                        double dp = pvt_fabs(pp[a] - hs);
+                        if (dp < best) { best = dp; baxis = a; bsign = 1.0; }
+                    }
+                    nloc.x = (baxis == 0) ? bsign : 0.0;
+                    nloc.y = (baxis == 1) ? bsign : 0.0;
+                    nloc.z = (baxis == 2) ? bsign : 0.0;
+                } else if (gt == PVT_GEOM_SPHERE) {
+                    double mag = pvt_sqrt(dot3(lpos, lpos));
+                    nloc = V3{lpos.x / mag, lpos.y / mag, lpos.z / mag};
+                } else {
+                    double half = 0.5 * T.dv(gp);
+                    double tol = 1e-8 + 1e-5 * pvt_fabs(half);
+                    if (pvt_fabs(lpos.z + half) <= tol) nloc = V3{0.0, 0.0, -1.0};
+                    else if (pvt_fabs(lpos.z - half) <= tol) nloc = V3{0.0, 0.0, 1.0};
+                    else {
+                        double r = pvt_sqrt(lpos.x * lpos.x + lpos.y * lpos.y);
+                        nloc = V3{lpos.x / r, lpos.y / r, 0.0};
+                    }
+                }
+                const int q = O.l2w + t_node * 9;
+                nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
+                nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
+                nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
+            }
+        }
+
+        if (alive && t_normal) {
+            if (ev_kind == PVT_EV_EXIT) {
+                double dd = pvt_fabs(dot3(nrm, dir));
+                if (dd > 1.0) dd = 1.0;
+                t_angle = pvt_acos(dd);
+            } else {
+                // ---- Fresnel / coating decision at the surface ------------
+                const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
+                V3 nf = nrm;
+                if (dot3(nf, dir) < 0.0) nf = V3{-nf.x, -nf.y, -nf.z};
+                double ddot = dot3(nf, dir);
+                if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
+                const double angle = pvt_acos(ddot);
+                t_angle = angle;
+                const bool fres = T.iv(O.surf_type + hit) == PVT_SURF_FRESNEL;
+                double r = 0.0, n1 = 0.0, n2 = 0.0;
+                if (fres) {
+                    n1 = T.dv(O.nidx + container);
+                    n2 = T.dv(O.nidx + adjacent);
+                    r = fresnel_reflectivity(angle, n1, n2);
+                }
+                int coat = -1;
+                if constexpr (COATED) {
+                    if (fres) {
+                        const int cs = T.iv(O.coat_start + hit), ce = cs + T.iv(O.coat_count + hit);
+                        const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
+                        for (int c = cs; c < ce && coat < 0; c++) {
+                            bool ok = true;
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                double f = T.dv(O.coat_facet + c * 3 + a);
+                                if (pvt_fabs(nl3[a] - f) > 1e-8 + 1e-5 * pvt_fabs(f)) ok = false;
+                                if (!(pl3[a] > T.dv(O.coat_lo + c * 3 + a) && pl3[a] < T.dv(O.coat_hi + c * 3 + a))) ok = false;
+                            }
+                            if (ok) coat = c;
+                        }
+                        if (coat >= 0) {
+                            double cr = T.dv(O.coat_refl + coat);
+                            if (cr >= 0.0) r = cr;
+                        }
+                    }
+                }
+                double u = 1.0;
+                if (r > 0.0) u = rng_uniform(rng);
+                if (u < r) {
+                    bool lamb = false;
+                    if constexpr (COATED) lamb = (coat >= 0 && T.iv(O.coat_rmode + coat) == 1);
+                    if (lamb) {
+                        // cosine-weighted about the incoming side's normal, in the node frame
+                        double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
+                        V3 mm{side * nloc.x, side * nloc.y, side * nloc.z};
+                        double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
+                        V3 s = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
+                        double sign = mm.z < 0.0 ? -1.0 : 1.0;
+                        double a = -1.0 / (sign + mm.z);
+                        double b = mm.x * mm.y * a;
+                        V3 t1v{1.0 + sign * mm.x * mm.x * a, sign * b, -sign * mm.x};
+                        V3 t2v{b, sign + mm.y * mm.y * a, -mm.y};
+                        V3 dl{s.x * t1v.x + s.y * t2v.x + s.z * mm.x, s.x * t1v.y + s.y * t2v.y + s.z * mm.y,
+                              s.x * t1v.z + s.y * t2v.z + s.z * mm.z};
+                        const int q = O.l2w + hit * 9;
+                        dir.x = T.dv(q + 0) * dl.x + T.dv(q + 1) * dl.y + T.dv(q + 2) * dl.z;
+                        dir.y = T.dv(q + 3) * dl.x + T.dv(q + 4) * dl.y + T.dv(q + 5) * dl.z;
+                        dir.z = T.dv(q + 6) * dl.x + T.dv(q + 7) * dl.y + T.dv(q + 8) * dl.z;
+                    } else {  // specular (:422-433): nf is nrm flipped along dir
+                        double dd = dot3(nf, dir);
+                        dir = V3{dir.x - 2.0 * dd * nf.x, dir.y - 2.0 * dd * nf.y, dir.z - 2.0 * dd * nf.z};
+                    }
+                    ev_kind = PVT_EV_REFLECT;
+                    t_sel = (container != hit) ? PVT_REC_REFLECTED : -1;
+                } else {
+                    bool matched = false;
+                    if constexpr (COATED) matched = (coat >= 0 && T.iv(O.coat_tmode + coat) == 1);
+                    if (fres && !matched) {  // Snell, vector form (:436-446)
+                        double n = n1 / n2;
+                        double dd = dot3(dir, nf);
+                        double c = pvt_sqrt(1.0 - n * n * (1.0 - dd * dd));
+                        double sign = dd < 0.0 ? -1.0 : 1.0;
+                        double k = sign * (c - sign * n * dd);
+                        dir = V3{n * dir.x + k * nf.x, n * dir.y + k * nf.y, n * dir.z + k * nf.z};
+                    }
+                    ev_kind = PVT_EV_TRANSMIT;
+                    t_sel = (container == hit) ? PVT_REC_ESCAPING : PVT_REC_ENTERING;
+                }
+            }
+        }
+
+        // ================= deferred event: log row + tallies ==============
+        if (alive && ev_kind >= 0)
+            log_row<RECORD>(A, base, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
+                            dir, ev_normal, nrm, wl, travelled, duration);
+
+        if (A.n_rec > 0 && __ballot(alive && t_sel >= 0) != 0ull) {
+            const bool want = alive && t_sel >= 0;
+#pragma unroll
+            for (int w = 0; w < SEENW; w++) {
+                const int rlo = w * 64;
+                const int rhi = (A.n_rec - rlo) < 64 ? (A.n_rec - rlo) : 64;
+                for (int b = 0; b < rhi; b++) {
+                    const int r = rlo + b;
+                    bool match = want && T.iu(O.rec_node + r) == t_node && T.iu(O.rec_event + r) == t_sel;
+                    if (match && T.iu(O.rec_has_facet + r) != 0) {
+                        const double atol = T.du(O.rec_atol + r);
+                        if (!t_normal) match = false;
+                        else if (pvt_fabs(T.du(O.rec_facet + r * 3) - nrm.x) > atol) match = false;
+                        else if (pvt_fabs(T.du(O.rec_facet + r * 3 + 1) - nrm.y) > atol) match = false;
+                        else if (pvt_fabs(T.du(O.rec_facet + r * 3 + 2) - nrm.z) > atol) match = false;
+                    }
+                    if (match) {
+                        atomicAdd(&acc_cross[r], 1u);
+                        const unsigned long long bit = 1ull << b;
+                        if (!(seen.w[w] & bit)) {
+                            seen.w[w] |= bit;
+                            atomicAdd(&acc_distinct[r], 1u);
+                            double* s = acc_sums + r * 8;
+                            atomicAdd(&s[0], wl); atomicAdd(&s[1], wl * wl);
+                            atomicAdd(&s[2], t_angle); atomicAdd(&s[3], t_angle * t_angle);
+                            atomicAdd(&s[4], duration); atomicAdd(&s[5], duration * duration);
+                            atomicAdd(&s[6], travelled); atomicAdd(&s[7], travelled * travelled);
+                            const int h0 = T.iu(O.rec_hist_start + r), h1 = h0 + T.iu(O.rec_hist_n + r);
+                            for (int h = h0; h < h1; h++) {
+                                const int pa = T.iu(O.h_prop_a + h), pb = T.iu(O.h_prop_b + h);
+                                const int na = T.iu(O.h_na + h), nb = T.iu(O.h_nb + h);
+                                auto prop = [&](int p) -> double {
+                                    switch (p) {
+                                        case 0: return wl;
+                                        case 1: return t_angle;
+                                        case 2: return duration;
+                                        case 3: return travelled;
+                                        case 4: return lpos.x;
+                                        case 5: return lpos.y;
+                                        default: return lpos.z;
+                                    }
+                                };
+                                double la = T.du(O.h_lo_a + h), ha = T.du(O.h_hi_a + h);
+                                int ia = (int)((prop(pa) - la) / (ha - la) * na);
+                                if (ia < 0 || ia >= na) continue;
+                                int slot = T.iu(O.h_offset + h) + ia;
+                                if (pb >= 0) {
+                                    double lb = T.du(O.h_lo_b + h), hb = T.du(O.h_hi_b + h);
+                                    int ib = (int)((prop(pb) - lb) / (hb - lb) * nb);
+                                    if (ib < 0 || ib >= nb) continue;
+                                    slot = T.iu(O.h_offset + h) + ia * nb + ib;
+                                }
+                                if (A.bins_in_lds) atomicAdd(&acc_bins[slot], 1u);
+                                else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + slot, 1ull);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        if (alive && terminal) {
+            if constexpr (RECORD) {
+                if (base >= 0) A.log.counts[rec_slot] = nev;
+            }
+            alive = false;
+        }
+    }
+
+    // ---- flush workgroup accumulators -------------------------------------
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.n_rec; i += kBlock) {
+        unsigned int c = acc_cross[i], d = acc_distinct[i];
+        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_crossings) + i, (unsigned long long)c);
+        if (d) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_distinct) + i, (unsigned long long)d);
+    }
+    for (int i = threadIdx.x; i < A.n_rec * 8; i += kBlock) {
+        double v = acc_sums[i];
+        if (v != 0.0) atomicAdd(A.rec_sums + i, v);
+    }
+    if (A.bins_in_lds)
+        for (int i = threadIdx.x; i < A.total_bins; i += kBlock) {
+            unsigned int v = acc_bins[i];
+            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + i, (unsigned long long)v);
+        }
+}
+
+// ============================================================== host side
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(PVT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+int push(std::vector<T>& blob, const T* src, size_t n) {
+    int at = (int)blob.size();
+    if (n && src) blob.insert(blob.end(), src, src + n);
+    return at;
+}
+
+}  // namespace
+
+struct PvtScene {
+    int device = 0;
+    Off off{};
+    EmitOff eoff{};
+    int nd = 0, ni = 0;
+    int n_nodes = 0, root = 0, n_rec = 0, total_bins = 0, n_coat = 0, n_lights = 0;
+    double* d_gd = nullptr;
+    int* d_gi = nullptr;
+    double* d_ed = nullptr;
+    int* d_ei = nullptr;
+    unsigned int* d_cursor = nullptr;
+    int num_cu = 0;
+    int last_grid = 0, last_lds = 0;
+    size_t lds_limit = 0;
+};
+
+extern "C" {
+
+int pvt_abi_version(void) { return PVT_ABI_VERSION; }
+const char* pvt_last_error(void) { return g_error.c_str(); }
+
+int pvt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
+    if (!t || !out) return fail(PVT_ERR_INVALID, "null argument");
+    if (t->n_nodes <= 0) return fail(PVT_ERR_INVALID, "scene has no nodes");
+    if (t->n_nodes > PVT_MAX_NODES) return fail(PVT_ERR_TOO_MANY_NODES, "more than 128 geometry nodes");
+    if (t->n_recorders > PVT_MAX_RECORDERS) return fail(PVT_ERR_INVALID, "more than 256 recorders");
+    if (pvt_device_count() <= device) return fail(PVT_ERR_NO_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+
+    const int N = t->n_nodes, C = t->n_components, R = t->n_recorders, H = t->n_hists, K = t->n_coatings;
+    std::vector<double> gd;
+    std::vector<int> gi;
+    Off o{};
+    o.geom_params = push(gd, t->geom_params, (size_t)N * 4);
+    // rigid transforms: keep the 3x4 of world_to_local and the 3x3 of local_to_world
+    o.w2l = (int)gd.size();
+    for (int n = 0; n < N; n++)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) gd.push_back(t->world_to_local[n * 16 + r * 4 + c]);
+    o.l2w = (int)gd.size();
+    for (int n = 0; n < N; n++)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) gd.push_back(t->local_to_world[n * 16 + r * 4 + c]);
+    o.nidx = push(gd, t->refractive_index, N);
+    o.comp_qy = push(gd, t->comp_qy, C);
+    o.comp_tau_rad = push(gd, t->comp_tau_rad, C);
+    o.comp_tau_nr = push(gd, t->comp_tau_nr, C);
+    o.comp_phase_param = push(gd, t->comp_phase_param, C);
+    o.abs_x = push(gd, t->abs_x, t->n_abs);
+    o.abs_y = push(gd, t->abs_y, t->n_abs);
+    o.ems_x = push(gd, t->ems_x, t->n_ems);
+    o.ems_cdf = push(gd, t->ems_cdf, t->n_ems);
+    o.rec_facet = push(gd, t->rec_facet, (size_t)R * 3);
+    o.rec_atol = push(gd, t->rec_atol, R);
+    o.h_lo_a = push(gd, t->hist_lo_a, H);
+    o.h_hi_a = push(gd, t->hist_hi_a, H);
+    o.h_lo_b = push(gd, t->hist_lo_b, H);
+    o.h_hi_b = push(gd, t->hist_hi_b, H);
+    o.coat_facet = push(gd, t->coat_facet, (size_t)K * 3);
+    o.coat_lo = push(gd, t->coat_lo, (size_t)K * 3);
+    o.coat_hi = push(gd, t->coat_hi, (size_t)K * 3);
+    o.coat_refl = push(gd, t->coat_reflectivity, K);
+
+    o.geom_type = push(gi, t->geom_type, N);
+    o.surf_type = push(gi, t->surface_type, N);
+    o.comp_start = push(gi, t->comp_start, N);
+    o.comp_count = push(gi, t->comp_count, N);
+    if (K > 0) {
+        o.coat_start = push(gi, t->coat_start, N);
+        o.coat_count = push(gi, t->coat_count, N);
+    }
+    o.comp_type = push(gi, t->comp_type, C);
+    o.comp_phase_type = push(gi, t->comp_phase_type, C);
+    o.abs_start = push(gi, t->comp_abs_start, C);
+    o.abs_n = push(gi, t->comp_abs_n, C);
+    o.ems_start = push(gi, t->comp_ems_start, C);
+    o.ems_n = push(gi, t->comp_ems_n, C);
+    o.rec_node = push(gi, t->rec_node, R);
+    o.rec_event = push(gi, t->rec_event, R);
+    o.rec_has_facet = push(gi, t->rec_has_facet, R);
+    o.rec_hist_start = push(gi, t->rec_hist_start, R);
+    o.rec_hist_n = push(gi, t->rec_hist_n, R);
+    o.h_prop_a = push(gi, t->hist_prop_a, H);
+    o.h_prop_b = push(gi, t->hist_prop_b, H);
+    o.h_na = push(gi, t->hist_na, H);
+    o.h_nb = push(gi, t->hist_nb, H);
+    o.h_offset = push(gi, t->hist_offset, H);
+    o.coat_rmode = push(gi, t->coat_reflect_mode, K);
+    o.coat_tmode = push(gi, t->coat_transmit_mode, K);
+    gd.push_back(0.0);  // never zero-sized
+    gi.push_back(0);
+
+    PvtScene* s = new PvtScene();
+    s->device = device;
+    s->off = o;
+    s->nd = (int)gd.size();
+    s->ni = (int)gi.size();
+    s->n_nodes = N;
+    s->root = t->root_id;
+    s->n_rec = R;
+    s->total_bins = t->total_bins;
+    s->n_coat = K;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->num_cu = prop.multiProcessorCount;
+    s->lds_limit = prop.sharedMemPerBlock;
+    HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
+    HIP_TRY(hipMalloc(&s->d_cursor, 64));
+    HIP_TRY(hipMemcpy(s->d_gd, gd.data(), gd.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_gi, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice));
+    *out = s;
+    return PVT_OK;
+}
+
+int pvt_scene_set_emitter(PvtScene* s, const PvtEmitterTables* e) {
+    if (!s || !e || e->n_lights <= 0) return fail(PVT_ERR_INVALID, "bad emitter");
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<double> ed;
+    std::vector<int> ei;
+    EmitOff o{};
+    const int Lt = e->n_lights;
+    o.wl_value = push(ed, e->wl_value, Lt);
+    o.pos_param = push(ed, e->pos_param, (size_t)Lt * 3);
+    o.dir_param = push(ed, e->dir_param, Lt);
+    o.l2w = push(ed, e->light_to_world, (size_t)Lt * 16);
+    o.spec_x = push(ed, e->spec_x, e->n_spec);
+    o.spec_cdf = push(ed, e->spec_cdf, e->n_spec);
+    o.wl_type = push(ei, e->wl_type, Lt);
+    o.wl_spec_start = push(ei, e->wl_spec_start, Lt);
+    o.wl_spec_n = push(ei, e->wl_spec_n, Lt);
+    o.pos_type = push(ei, e->pos_type, Lt);
+    o.dir_type = push(ei, e->dir_type, Lt);
+    ed.push_back(0.0);
+    ei.push_back(0);
+    if (s->d_ed) { (void)hipFree(s->d_ed); s->d_ed = nullptr; }
+    if (s->d_ei) { (void)hipFree(s->d_ei); s->d_ei = nullptr; }
+    HIP_TRY(hipMalloc(&s->d_ed, ed.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&s->d_ei, ei.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(s->d_ed, ed.data(), ed.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_ei, ei.data(), ei.size() * sizeof(int), hipMemcpyHostToDevice));
+    s->eoff = o;
+    s->n_lights = Lt;
+    return PVT_OK;
+}
+
+void pvt_scene_destroy(PvtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->d_gd) (void)hipFree(s->d_gd);
+    if (s->d_gi) (void)hipFree(s->d_gi);
+    if (s->d_ed) (void)hipFree(s->d_ed);
+    if (s->d_ei) (void)hipFree(s->d_ei);
+    if (s->d_cursor) (void)hipFree(s->d_cursor);
+    delete s;
+}
+
+}  // extern "C"
+
+namespace {
+
+KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
+    KArgs a{};
+    a.gd = s->d_gd; a.gi = s->d_gi; a.ed = s->d_ed; a.ei = s->d_ei;
+    a.off = s->off; a.eoff = s->eoff;
+    a.nd = s->nd; a.ni = s->ni;
+    a.n_nodes = s->n_nodes; a.root = s->root; a.n_rec = s->n_rec; a.total_bins = s->total_bins;
+    a.n_coat = s->n_coat; a.n_lights = s->n_lights;
+    a.n_rays = (unsigned int)p->n_rays;
+    a.cursor = s->d_cursor;
+    a.seed = p->seed + p->ray_offset;
+    a.emit_seed = p->emit_seed;
+    a.ray_offset = p->ray_offset;
+    a.maxsteps = p->maxsteps; a.max_events = p->max_events; a.emit_method = p->emit_method;
+    a.record_every = p->record_every;
+    return a;
+}
+
+template <bool RECORD, bool TAB_LDS, int SEENW>
+hipError_t launch_variant(bool coated, int grid, size_t lds, hipStream_t st, const KArgs& a) {
+    if (coated) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    return hipGetLastError();
+}
+
+template <bool RECORD, bool TAB_LDS>
+hipError_t launch_seen(int n_rec, bool coated, int grid, size_t lds, hipStream_t st, const KArgs& a) {
+    if (n_rec <= 64) return launch_variant<RECORD, TAB_LDS, 1>(coated, grid, lds, st, a);
+    return launch_variant<RECORD, TAB_LDS, 4>(coated, grid, lds, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
+                     const PvtEventLog* log, void* stream) {
+    if (!s || !p || !tl) return fail(PVT_ERR_INVALID, "null argument");
+    if (p->n_rays < 0 || p->n_rays > 0x7fffffffLL)
+        return fail(PVT_ERR_INVALID, "n_rays must fit in 31 bits per bundle");
+    if (p->max_events < 2 && p->record_every > 0) return fail(PVT_ERR_INVALID, "max_events must be >= 2");
+    if (!rays && !s->d_ed) return fail(PVT_ERR_INVALID, "no rays and no emitter");
+    if (p->record_every > 0 && !log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+    if (p->n_rays == 0) return PVT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    KArgs a = base_args(s, p);
+    if (rays) { a.pos = rays->position; a.dir = rays->direction; a.wl = rays->wavelength; }
+    a.rec_distinct = reinterpret_cast<long long*>(tl->rec_distinct);
+    a.rec_crossings = reinterpret_cast<long long*>(tl->rec_crossings);
+    a.rec_sums = tl->rec_sums;
+    a.rec_bins = reinterpret_cast<long long*>(tl->rec_bins);
+    const bool record = p->record_every > 0;
+    if (record) {
+        a.log = *log;
+        const size_t nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
+        const size_t rows = nrec * (size_t)p->max_events;
+        HIP_TRY(hipMemsetAsync(log->counts, 0, nrec * 4, st));
+        HIP_TRY(hipMemsetAsync(log->kind, 0, rows, st));
+        HIP_TRY(hipMemsetAsync(log->hit, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->container, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->adjacent, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->component, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->source, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->position, 0, rows * 24, st));
+        HIP_TRY(hipMemsetAsync(log->direction, 0, rows * 24, st));
+        HIP_TRY(hipMemsetAsync(log->normal, 0, rows * 24, st));
+        HIP_TRY(hipMemsetAsync(log->wavelength, 0, rows * 8, st));
+        HIP_TRY(hipMemsetAsync(log->travelled, 0, rows * 8, st));
+        HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
+    }
+    HIP_TRY(hipMemsetAsync(s->d_cursor, 0, 4, st));
+
+    // LDS budget: tables (if they fit) + recorder accumulators (+ bins if they fit)
+    const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 2 * 4);
+    const size_t tab_bytes = (size_t)s->nd * 8 + (size_t)((s->ni + 1) & ~1) * 4;
+    const size_t bins_bytes = (size_t)s->total_bins * 4;
+    const size_t budget = 64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit;  // keep >= 2 workgroups per CU
+    bool tab_lds = acc_bytes + tab_bytes <= budget;
+    size_t lds = acc_bytes + (tab_lds ? tab_bytes : 0);
+    a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
+    if (a.bins_in_lds) lds += bins_bytes;
+    if (lds > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
+    lds = (lds + 15) & ~(size_t)15;
+
+    // persistent grid: enough workgroups to fill every CU a few times over,
+    // never more than the rays can feed
+    long long blocks_for_rays = (p->n_rays + kBlock - 1) / kBlock;
+    long long grid = (long long)s->num_cu * 4;
+    if (grid > blocks_for_rays) grid = blocks_for_rays;
+    if (grid < 1) grid = 1;
+    s->last_grid = (int)grid;
+    s->last_lds = (int)lds;
+
+    const bool coated = s->n_coat > 0;
+    hipError_t e;
+    if (record) {
+        e = tab_lds ? launch_seen<true, true>(s->n_rec, coated, (int)grid, lds, st, a)
+                    : launch_seen<true, false>(s->n_rec, coated, (int)grid, lds, st, a);
+    } else {
+        e = tab_lds ? launch_seen<false, true>(s->n_rec, coated, (int)grid, lds, st, a)
+                    : launch_seen<false, false>(s->n_rec, coated, (int)grid, lds, st, a);
+    }
+    if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
+    return PVT_OK;
+}
+
+int pvt_emit_device(PvtScene* s, const PvtTraceParams* p, double* position, double* direction,
+                    double* wavelength, void* stream) {
+    if (!s || !p || !s->d_ed) return fail(PVT_ERR_INVALID, "scene has no emitter");
+    if (p->n_rays <= 0) return PVT_OK;
+    if (p->n_rays > 0x7fffffffLL) return fail(PVT_ERR_INVALID, "n_rays must fit in 31 bits per bundle");
+    HIP_TRY(hipSetDevice(s->device));
+    KArgs a = base_args(s, p);
+    int grid = (int)((p->n_rays + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), a,
+                       position, direction, wavelength);
+    HIP_TRY(hipGetLastError());
+    return PVT_OK;
+}
+
+int pvt_scene_launch_info(PvtScene* s, int32_t* grid, int32_t* block, int32_t* lds_bytes) {
+    if (!s) return fail(PVT_ERR_INVALID, "null scene");
+    if (grid) *grid = s->last_grid;
+    if (block) *block = kBlock;
+    if (lds_bytes) *lds_bytes = s->last_lds;
+    return PVT_OK;
+}
+
+// Host-buffer entry: the literal stand-in for _kernel.trace_bundle.
+int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitter, const PvtRays* rays,
+                     const PvtTraceParams* p, const PvtTallies* tl, const PvtEventLog* log, int device,
+                     double* kernel_ms) {
+    if (!tables || !p || !tl) return fail(PVT_ERR_INVALID, "null argument");
+    PvtScene* s = nullptr;
+    int rc = pvt_scene_create(tables, device, &s);
+    if (rc != PVT_OK) return rc;
+    struct Guard {
+        PvtScene* s;
+        std::vector<void*> bufs;
+        ~Guard() {
+            for (void* b : bufs) (void)hipFree(b);
+            pvt_scene_destroy(s);
+        }
+    } g{s, {}};
+    if (emitter) {
+        rc = pvt_scene_set_emitter(s, emitter);
+        if (rc != PVT_OK) return rc;
+    }
+    auto dalloc = [&](size_t bytes, void** out) -> hipError_t {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+        if (e == hipSuccess) g.bufs.push_back(*out);
+        return e;
+    };
+    const size_t n = (size_t)p->n_rays;
+    const size_t R = (size_t)(tables->n_recorders > 0 ? tables->n_recorders : 1);
+    const size_t B = (size_t)(tables->total_bins > 0 ? tables->total_bins : 1);
+    PvtRays drays{};
+    if (rays) {
+        void *dp, *dd, *dw;
+        HIP_TRY(dalloc(n * 24, &dp)); HIP_TRY(dalloc(n * 24, &dd)); HIP_TRY(dalloc(n * 8, &dw));
+        HIP_TRY(hipMemcpy(dp, rays->position, n * 24, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dd, rays->direction, n * 24, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dw, rays->wavelength, n * 8, hipMemcpyHostToDevice));
+        drays = PvtRays{(const double*)dp, (const double*)dd, (const double*)dw};
+    }
+    PvtTallies dt{};
+    void *t0, *t1, *t2, *t3;
+    HIP_TRY(dalloc(R * 8, &t0)); HIP_TRY(dalloc(R * 8, &t1)); HIP_TRY(dalloc(R * 64, &t2)); HIP_TRY(dalloc(B * 8, &t3));
+    // the trace ADDS into the caller's tallies: seed the device copies with them
+    HIP_TRY(hipMemcpy(t0, tl->rec_distinct, (size_t)tables->n_recorders * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t1, tl->rec_crossings, (size_t)tables->n_recorders * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t2, tl->rec_sums, (size_t)tables->n_recorders * 64, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t3, tl->rec_bins, (size_t)tables->total_bins * 8, hipMemcpyHostToDevice));
+    dt = PvtTallies{(int64_t*)t0, (int64_t*)t1, (double*)t2, (int64_t*)t3};
+
+    PvtEventLog dl{};
+    size_t nrec = 0, rows = 0;
+    const bool record = p->record_every > 0;
+    if (record) {
+        if (!log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+        nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
+        rows = nrec * (size_t)p->max_events;
+        void* b[13];
+        const size_t sz[13] = {nrec * 4, rows, rows * 4, rows * 4, rows * 4, rows * 4, rows * 4,
+                               rows * 24, rows * 24, rows * 24, rows * 8, rows * 8, rows * 8};
+        for (int i = 0; i < 13; i++) HIP_TRY(dalloc(sz[i], &b[i]));
+        dl = PvtEventLog{(int32_t*)b[0], (uint8_t*)b[1], (int32_t*)b[2], (int32_t*)b[3], (int32_t*)b[4],
+                         (int32_t*)b[5], (int32_t*)b[6], (double*)b[7], (double*)b[8], (double*)b[9],
+                         (double*)b[10], (double*)b[11], (double*)b[12]};
+    }
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, nullptr));
+    rc = pvt_trace_device(s, rays ? &drays : nullptr, p, &dt, record ? &dl : nullptr, nullptr);
+    if (rc != PVT_OK) return rc;
+    HIP_TRY(hipEventRecord(ev1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+
+    HIP_TRY(hipMemcpy(tl->rec_distinct, t0, (size_t)tables->n_recorders * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tl->rec_crossings, t1, (size_t)tables->n_recorders * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tl->rec_sums, t2, (size_t)tables->n_recorders * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tl->rec_bins, t3, (size_t)tables->total_bins * 8, hipMemcpyDeviceToHost));
+    if (record) {
+        HIP_TRY(hipMemcpy(log->counts, dl.counts, nrec * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->kind, dl.kind, rows, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->hit, dl.hit, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->container, dl.container, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->adjacent, dl.adjacent, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->component, dl.component, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->source, dl.source, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->position, dl.position, rows * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->direction, dl.direction, rows * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->normal, dl.normal, rows * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->wavelength, dl.wavelength, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->travelled, dl.travelled, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->duration, dl.duration, rows * 8, hipMemcpyDeviceToHost));
+    }
+    return PVT_OK;
+}
+
+}  // extern "C"
