@@ -217,6 +217,12 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
 int pvt_emit_device(PvtScene* scene, const PvtTraceParams* params, double* position,
                     double* direction, double* wavelength, void* stream);
 
+/* Self-test: y[i] = f(x[i]) evaluated ON THE DEVICE (host buffers in/out).
+ * fn: 0 log, 1 sin, 2 cos, 3 asin, 4 acos, 5 sqrt, 6 1/x, 7 sin*cos via sincos,
+ * 8 second xoshiro256+ uniform of stream (uint64)x, 9 x/(x+3).  Lets the tests
+ * prove the bit-reproducibility premise of csrc/pvt_math.h on gfx950. */
+int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, int device);
+
 /* Launch geometry actually used by the last trace on this scene (diagnostics). */
 int pvt_scene_launch_info(PvtScene* scene, int32_t* grid, int32_t* block, int32_t* lds_bytes);
 

@@ -747,7 +747,10 @@ void pvt_oracle_math(int fn, int math_mode, const double* x, double* y, long n) 
             case 3: y[i] = m_asin(&M, x[i]); break;
             case 4: y[i] = m_acos(&M, x[i]); break;
             case 5: y[i] = sqrt(x[i]); break;
-            default: y[i] = 1.0 / x[i]; break;
+            case 6: y[i] = 1.0 / x[i]; break;
+            case 7: y[i] = m_sin(&M, x[i]) * m_cos(&M, x[i]); break;
+            case 8: { Rng g; rng_seed(&g, (uint64_t)x[i]); rng_uniform(&g); y[i] = rng_uniform(&g); break; }
+            default: y[i] = x[i] / (x[i] + 3.0); break;
         }
     }
 }

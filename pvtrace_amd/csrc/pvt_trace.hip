@@ -280,6 +280,28 @@ __global__ void __launch_bounds__(kBlock) emit_kernel(KArgs A, double* opos, dou
     owl[i] = wl;
 }
 
+// Self-test hook: evaluates one elementary function per element on the device so the
+// tests can prove the premise of the whole parity scheme (IEEE divide / sqrt and the
+// pvt_math.h functions produce the same bits on gfx950 as on the host).
+__global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, double* y, long long n) {
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double v = x[i], r;
+    switch (fn) {
+        case 0: r = pvt_log(v); break;
+        case 1: r = pvt_sin(v); break;
+        case 2: r = pvt_cos(v); break;
+        case 3: r = pvt_asin(v); break;
+        case 4: r = pvt_acos(v); break;
+        case 5: r = pvt_sqrt(v); break;
+        case 6: r = 1.0 / v; break;
+        case 7: { double s, c; pvt_sincos(v, &s, &c); r = s * c; break; }
+        case 8: { Rng g; rng_seed(g, (unsigned long long)v); rng_uniform(g); r = rng_uniform(g); break; }
+        default: r = v / (v + 3.0); break;
+    }
+    y[i] = r;
+}
+
 // ----------------------------------------------------------- event log
 template <bool RECORD>
 __device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev, int kind, int hit,
@@ -1171,6 +1193,24 @@ int pvt_emit_device(PvtScene* s, const PvtTraceParams* p, double* position, doub
     hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), a,
                        position, direction, wavelength);
     HIP_TRY(hipGetLastError());
+    return PVT_OK;
+}
+
+int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, int device) {
+    if (!x_host || !y_host || n < 0) return fail(PVT_ERR_INVALID, "bad argument");
+    if (n == 0) return PVT_OK;
+    if (pvt_device_count() <= device) return fail(PVT_ERR_NO_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *dx = nullptr, *dy = nullptr;
+    HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dx, x_host, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, fn, dx, dy,
+                       (long long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(y_host, dy, (size_t)n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dx);
+    (void)hipFree(dy);
     return PVT_OK;
 }
 

@@ -1,0 +1,138 @@
+"""Photons sharded across the GPUs of a node: one process per GPU, tallies summed
+with a single RCCL all-reduce over xGMI.
+
+The reference has no collective anywhere; its only "reduction"
+is the per-thread -> global sum of the recorder accumulators
+(pvtrace/engine/_kernel.pyx:1099-1102) and its streaming rule is "bundle b
+traces rays with seeds seed + traced + i" (api.py:249-264).  Both map directly:
+
+* rank r owns the contiguous index range [n*r/W, n*(r+1)/W); ray i always uses
+  RNG stream ``seed + i`` and (device emission) emission stream
+  ``(emit_seed + i)``, so the set of photon histories is identical for every
+  world size;
+* there is NO data-path exchange while tracing; after the kernel, the integer
+  tallies (distinct | crossings | bins as one int64 buffer) and the f64 moment
+  sums are all-reduced (sum).  Payload is O(recorders + bins) — tens of KB —
+  so the collective is latency-bound (~tens of microseconds), independent of
+  the photon count;
+* sampled event logs stay on the rank that traced them.
+
+`backend="nccl"` is RCCL on ROCm.  The CPU tests run the same code path with
+gloo and an injected tracer.
+"""
+import time
+
+import numpy as np
+
+from pvtrace_amd.engine import native
+from pvtrace_amd.engine.compiler import EMIT_METHODS, compile_scene
+
+
+def shard_range(num_rays, rank, world_size):
+    """[start, stop) of the global ray indices owned by `rank`."""
+    return (num_rays * rank) // world_size, (num_rays * (rank + 1)) // world_size
+
+
+def all_reduce_tallies(tallies, group=None):
+    """Sum recorder accumulators over all ranks, in place (2 collectives: one
+    int64 buffer holding distinct | crossings | bins, one f64 buffer of moment sums)."""
+    import torch
+    import torch.distributed as dist
+
+    if "_ints" in tallies:  # DeviceScene.new_tallies(): the tables are views of two buffers
+        dist.all_reduce(tallies["_ints"], op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(tallies["_sums"], op=dist.ReduceOp.SUM, group=group)
+        return tallies
+    nrec = tallies["rec_distinct"].numel()
+    ints = torch.cat([tallies["rec_distinct"], tallies["rec_crossings"], tallies["rec_bins"]])
+    dist.all_reduce(ints, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(tallies["rec_sums"], op=dist.ReduceOp.SUM, group=group)
+    tallies["rec_distinct"].copy_(ints[:nrec])
+    tallies["rec_crossings"].copy_(ints[nrec:2 * nrec])
+    tallies["rec_bins"].copy_(ints[2 * nrec:])
+    return tallies
+
+
+def simulate_sharded(scene, num_rays, seed, emit_seed=0, maxsteps=1000, max_events=128,
+                     emit_method="kT", record_every=0, device=None, group=None, tracer=None,
+                     rays=None):
+    """Trace this rank's shard of a `num_rays` job and all-reduce the tallies.
+
+    Must be called by every rank of an initialised torch.distributed group.
+    Rays come from device-side emission (shard-invariant by construction) unless
+    `rays` = (positions, directions, wavelengths) host arrays of the WHOLE job
+    are given, in which case each rank slices its range.
+
+    Returns an `EngineResult` whose recorder tallies are GLOBAL and whose event
+    log (if any) covers the local shard; `.shard` = (start, stop).
+
+    `tracer` (tests only) replaces the GPU: ``tracer(compiled, pos, dirs, wl,
+    seed, ray_offset, maxsteps, max_events, emit_method, record_every) -> data``.
+    """
+    import torch
+    import torch.distributed as dist
+
+    from pvtrace_amd.engine import emit as emit_mod
+    from pvtrace_amd.engine.api import EngineResult, _default_device, download
+
+    if emit_method not in EMIT_METHODS:
+        raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    start, stop = shard_range(num_rays, rank, world)
+    n_local = stop - start
+    compiled = compile_scene(scene)
+    sources = emit_mod.sources_for(scene, num_rays)[start:stop]
+
+    if tracer is not None:
+        # CPU plumbing path (gloo): same sharding + reduction, injected tracer
+        if rays is None:
+            raise ValueError("the injected-tracer path needs explicit rays")
+        pos, dirs, wl = (np.asarray(a)[start:stop] for a in rays)
+        tic = time.perf_counter()
+        data = tracer(compiled, pos, dirs, wl, seed, start, maxsteps, max_events,
+                      EMIT_METHODS[emit_method], record_every)
+        tallies = {k: torch.from_numpy(np.ascontiguousarray(data[k]).reshape(-1).copy())
+                   for k in ("rec_distinct", "rec_crossings", "rec_sums", "rec_bins")}
+        all_reduce_tallies(tallies, group=group)
+        nrec = int(compiled.rec_node.shape[0])
+        data = dict(data)
+        data["rec_distinct"] = tallies["rec_distinct"].numpy()
+        data["rec_crossings"] = tallies["rec_crossings"].numpy()
+        data["rec_sums"] = tallies["rec_sums"].numpy().reshape(nrec, 4, 2)
+        data["rec_bins"] = tallies["rec_bins"].numpy()
+        result = EngineResult(compiled, data, sources, max_events, record_every,
+                              time.perf_counter() - tic)
+        result.shard = (start, stop)
+        return result
+
+    if device is None:
+        device = _default_device()
+    emitter = emit_mod.EmitterTables(scene, strict=True) if rays is None else None
+    dscene = native.DeviceScene(compiled, device=device, emitter=emitter)
+    try:
+        with torch.cuda.device(device):
+            dev = torch.device("cuda", device)
+            dev_rays = None
+            if rays is not None:
+                dev_rays = tuple(
+                    torch.from_numpy(np.ascontiguousarray(np.asarray(a)[start:stop])).to(dev)
+                    for a in rays)
+            tallies = dscene.new_tallies()
+            log = (dscene.new_event_log(n_local, record_every, max_events)
+                   if record_every > 0 and n_local > 0 else None)
+            torch.cuda.synchronize(device)
+            tic = time.perf_counter()
+            if n_local > 0:
+                dscene.trace(dev_rays, n_local, int(seed), tallies, log=log, ray_offset=start,
+                             emit_seed=int(emit_seed), record_every=int(record_every),
+                             maxsteps=int(maxsteps), max_events=int(max_events),
+                             emit_method=EMIT_METHODS[emit_method])
+            all_reduce_tallies(tallies, group=group)
+            torch.cuda.synchronize(device)
+            elapsed = time.perf_counter() - tic
+            data = download(compiled, tallies, log, n_local, record_every, max_events)
+    finally:
+        dscene.close()
+    result = EngineResult(compiled, data, sources, max_events, record_every, elapsed)
+    result.shard = (start, stop)
+    return result

@@ -200,6 +200,7 @@ def declare_signatures(lib, names):
              C.POINTER(PvtTraceParams), C.POINTER(PvtTallies), C.POINTER(PvtEventLog), C.c_int,
              C.POINTER(C.c_double)], C.c_int),
         "pvt_emit_device": ([vp, C.POINTER(PvtTraceParams), vp, vp, vp, vp], C.c_int),
+        "pvt_selftest_math": ([C.c_int, vp, vp, C.c_int64, C.c_int], C.c_int),
         "pvt_scene_launch_info": (
             [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
     }
@@ -214,7 +215,7 @@ def declare_signatures(lib, names):
 ABI_SYMBOLS = (
     "pvt_abi_version", "pvt_last_error", "pvt_device_count", "pvt_scene_create",
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
-    "pvt_emit_device", "pvt_scene_launch_info",
+    "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info",
 )
 
 _lib = None
@@ -222,6 +223,31 @@ _lib = None
 
 def library_built():
     return os.path.exists(LIB_PATH)
+
+
+def _preload_torch_hip_runtime():
+    """One process must not hold two HIP/HSA runtimes.  PyTorch wheels bundle their own
+    libamdhip64.so.7 (+ libhsa-runtime64) under torch/lib; our library's NEEDED entry has
+    the same SONAME and a RUNPATH to /opt/rocm.  If ours loaded first, the system runtime
+    would be mapped and torch's bundled HSA would later fail with "No HIP GPUs are
+    available".  So when torch is installed, map ITS runtime first (without importing
+    torch); the dynamic loader then resolves our NEEDED entry to that same copy, whatever
+    the import order.  Without torch the RUNPATH copy is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
 
 
 def load_library():
@@ -233,6 +259,7 @@ def load_library():
                 f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`"
                 " (hipcc --offload-arch=gfx950)."
             )
+        _preload_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         declare_signatures(lib, ABI_SYMBOLS)
         _lib = lib
@@ -264,6 +291,16 @@ def is_available():
         return device_count() > 0
     except OSError:
         return False
+
+
+def selftest_math(fn, x, device=0):
+    """y = f(x) evaluated on the GPU (see pvt_selftest_math in the header)."""
+    lib = load_library()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    check(lib.pvt_selftest_math(int(fn), x.ctypes.data, y.ctypes.data, x.size, int(device)),
+          "pvt_selftest_math")
+    return y
 
 
 class DeviceScene:
@@ -308,17 +345,25 @@ class DeviceScene:
 
     # -- device buffers (torch tensors) ----------------------------------
     def new_tallies(self):
+        """Zeroed recorder accumulators on the GPU.  The three integer tables are
+        views of ONE int64 buffer (`_ints`: distinct | crossings | bins) and the
+        moment sums are `_sums`, so a whole tally set is zeroed by two memsets
+        and all-reduced by two collectives."""
         import torch
 
         dev = torch.device("cuda", self.device)
         c = self.compiled
         nrec = max(int(c.rec_node.shape[0]), 1)
         nbins = max(int(c.total_bins), 1)
+        ints = torch.zeros(2 * nrec + nbins, dtype=torch.int64, device=dev)
+        sums = torch.zeros(nrec * 8, dtype=torch.float64, device=dev)
         return {
-            "rec_distinct": torch.zeros(nrec, dtype=torch.int64, device=dev),
-            "rec_crossings": torch.zeros(nrec, dtype=torch.int64, device=dev),
-            "rec_sums": torch.zeros(nrec * 8, dtype=torch.float64, device=dev),
-            "rec_bins": torch.zeros(nbins, dtype=torch.int64, device=dev),
+            "rec_distinct": ints[:nrec],
+            "rec_crossings": ints[nrec:2 * nrec],
+            "rec_sums": sums,
+            "rec_bins": ints[2 * nrec:],
+            "_ints": ints,
+            "_sums": sums,
         }
 
     def new_event_log(self, n_rays, record_every, max_events):

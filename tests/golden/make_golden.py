@@ -1,0 +1,185 @@
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Nothing of the reference is copied: its modules are imported from where they
+lie and only numeric inputs/outputs are saved.
+
+* The reference's native kernel (pvtrace/engine/_kernel.pyx, compiled by
+  oracle/build_ref.py) is driven with OUR flattened tables and seeded rays; its
+  complete event logs and tallies are the expected outputs (trace_*.npz,
+  tallies_lsc_1e6.npz).
+* The reference's pure-Python leaf modules that import without third-party
+  packages (data spectra, Distribution, Fresnel/phase helpers, Transformable,
+  Sphere, Cylinder) give known answers for spectra.npz, optics.npz,
+  geometry.npz and transforms.npz.  The package __init__ is bypassed with a
+  namespace stub (it would pull anytree/trimesh/meshcat, absent here; no
+  stand-ins for those are written).
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+REF = "/root/reference/pvtrace"
+
+
+def ref_module(name):
+    if "pvtrace" not in sys.modules:
+        pkg = types.ModuleType("pvtrace")
+        pkg.__path__ = [REF]
+        sys.modules["pvtrace"] = pkg
+    return importlib.import_module(name)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def make_spectra():
+    lum = ref_module("pvtrace.data.lumogen_f_red_305")
+    flu = ref_module("pvtrace.data.fluro_red")
+    dist = ref_module("pvtrace.material.distribution")
+    x = np.arange(400, 800)
+    xw = np.linspace(300.0, 900.0, 241)
+    ems = lum.emission(x)
+    d = dist.Distribution(x, ems)
+    p = np.linspace(0.0, 1.0, 101)
+    xs = np.linspace(400.0, 799.0, 57)
+    save(
+        "spectra.npz",
+        x=x, lumogen_abs=lum.absorption(x), lumogen_ems=ems,
+        xw=xw, lumogen_abs_w=lum.absorption(xw), lumogen_ems_w=lum.emission(xw),
+        fluro_abs_w=flu.absorption(xw), fluro_ems_w=flu.emission(xw),
+        lumogen_ems_cdf=np.asarray(d._cdf),
+        sample_p=p, sample_x=np.asarray(d.sample(p)),
+        lookup_x=xs, lookup_p=np.asarray(d.lookup(xs)), call_y=np.asarray(d(xs)),
+    )
+
+
+def make_optics():
+    mu = ref_module("pvtrace.material.utils")
+    rng = np.random.default_rng(11)
+    angles = np.concatenate(([0.0], np.sort(rng.uniform(0, np.pi / 2, 400)), [np.pi / 2 - 1e-9]))
+    pairs = np.array([(1.0, 1.5), (1.5, 1.0), (1.0, 1.33), (1.49, 1.7), (2.4, 1.0), (1.0, 1.0)])
+    refl = np.array([[mu.fresnel_reflectivity(a, n1, n2) for a in angles] for n1, n2 in pairs])
+    d = rng.normal(size=(300, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    n = rng.normal(size=(300, 3)); n /= np.linalg.norm(n, axis=1)[:, None]
+    spec = np.array([mu.specular_reflection(a, b) for a, b in zip(d, n)])
+    # refraction needs the normal flipped along the ray and no TIR
+    nf = np.where((np.einsum("ij,ij->i", d, n) < 0)[:, None], -n, n)
+    refr_up = np.array([mu.fresnel_refraction(a, b, 1.0, 1.5) for a, b in zip(d, nf)])
+    cosang = np.einsum("ij,ij->i", d, nf)
+    ok = np.arccos(np.clip(cosang, -1, 1)) < np.arcsin(1.0 / 1.5) - 1e-6
+    refr_down = np.array([mu.fresnel_refraction(a, b, 1.5, 1.0) for a, b in zip(d[ok], nf[ok])])
+    save("optics.npz", angles=angles, pairs=pairs, reflectivity=refl, d=d, n=n, nf=nf,
+         specular=spec, refract_up=refr_up, down_mask=ok, refract_down=refr_down)
+
+
+def make_geometry():
+    sph = ref_module("pvtrace.geometry.sphere")
+    cyl = ref_module("pvtrace.geometry.cylinder")
+    rng = np.random.default_rng(3)
+    n = 400
+    o = rng.uniform(-3, 3, size=(n, 3))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    sphere = sph.Sphere(1.7)
+    cylinder = cyl.Cylinder(2.5, 0.9)
+
+    def hits(geometry):
+        out = np.full((n, 4, 3), np.nan)
+        cnt = np.zeros(n, dtype=np.int32)
+        for i in range(n):
+            pts = geometry.intersections(tuple(o[i]), tuple(d[i]))
+            cnt[i] = len(pts)
+            for k, p in enumerate(pts):
+                out[i, k] = p
+        return cnt, out
+
+    sc, sp = hits(sphere)
+    cc, cp = hits(cylinder)
+    sn = np.array([sphere.normal(tuple(p)) for p in sp[sc > 0, 0]])
+    cn = np.array([cylinder.normal(tuple(p)) for p in cp[cc > 0, 0]])
+    save("geometry.npz", origin=o, direction=d, sphere_radius=1.7, cyl_length=2.5, cyl_radius=0.9,
+         sphere_count=sc, sphere_points=sp, sphere_normals=sn,
+         cyl_count=cc, cyl_points=cp, cyl_normals=cn)
+
+
+def make_transforms():
+    tr = ref_module("pvtrace.geometry.transformable")
+    # nested_cylinders: A then child B; LSC light; kitchen-sink slab
+    a = tr.Transformable(); a.translate((0, 0, 2)); a.rotate(np.pi * 0.2, (0, 1, 0))
+    b = tr.Transformable(); b.rotate(np.pi / 2, (1, 0, 0))
+    light = tr.Transformable(); light.location = (0.0, 0.0, 5.0); light.rotate(np.radians(180), (1, 0, 0))
+    slab = tr.Transformable(); slab.translate((0.5, -0.3, 1.0)); slab.rotate(0.35, (1.0, 0.4, 0.2))
+    located = tr.Transformable(location=(1.0, 2.0, 3.0)); located.rotate(1.1, (0.0, 1.0, 0.3))
+    located.translate((0.5, 0.5, -2.0))
+    save("transforms.npz", A=a.pose, B=b.pose, B_in_world=np.dot(a.pose, b.pose), light=light.pose,
+         slab=slab.pose, located=located.pose)
+
+
+def table_dump(compiled):
+    return {f"tab_{k}": np.asarray(v) for k, v in compiled.tables().items()}
+
+
+def make_traces():
+    from oracle import oracle as O
+    from pvtrace_amd.engine import compile_scene
+    from pvtrace_amd.engine.emit import emit_bundle
+    from tests import scenes
+
+    for name, mk in scenes.REFERENCE_SCENES.items():
+        scene = mk()
+        compiled = compile_scene(scene)
+        n = 256
+        pos, dirs, wl, _ = emit_bundle(scene, n, seed=2024)
+        params = dict(seed=99, maxsteps=60 if name == "trapped_light" else 1000, max_events=48,
+                      emit_method={"bench_slab": 1, "kitchen_sink": 2}.get(name, 0), record_every=1)
+        ref = O.reference_trace_bundle(compiled, pos, dirs, wl, params["seed"], params["maxsteps"],
+                                       params["max_events"], params["emit_method"], 1,
+                                       params["record_every"])
+        arrays = {f"ref_{k}": np.asarray(v) for k, v in ref.items()}
+        arrays.update(table_dump(compiled))
+        arrays.update(in_pos=pos, in_dir=dirs, in_wl=wl,
+                      **{f"par_{k}": np.int64(v) for k, v in params.items()})
+        save(f"trace_{name}.npz", **arrays)
+
+
+def make_lsc_tallies():
+    """10^6 photons through the REFERENCE kernel on the headline scene (tallies only)."""
+    from oracle import oracle as O
+    from pvtrace_amd.engine import compile_scene
+    from pvtrace_amd.engine.emit import emit_bundle
+    from tests import scenes
+
+    scene = scenes.lsc_equivalent()
+    compiled = compile_scene(scene)
+    n = 1_000_000
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=777)
+    ref = O.reference_trace_bundle(compiled, pos, dirs, wl, 1, 1000, 128, 0, os.cpu_count(), 0)
+    checksum = np.array([pos.sum(), dirs.sum(), wl.sum(), np.abs(dirs).sum()])
+    save("tallies_lsc_1e6.npz", n=np.int64(n), emit_seed=np.int64(777), seed=np.int64(1),
+         input_checksum=checksum, recorder_names=np.array(compiled.recorder_names),
+         rec_distinct=ref["rec_distinct"], rec_crossings=ref["rec_crossings"],
+         rec_sums=ref["rec_sums"], rec_bins=ref["rec_bins"], **table_dump(compiled))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
+    make_spectra()
+    make_optics()
+    make_geometry()
+    make_transforms()
+    make_traces()
+    make_lsc_tallies()

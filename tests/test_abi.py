@@ -1,0 +1,101 @@
+"""The C-ABI shared library: builds for gfx950 without a GPU, loads, exports every
+symbol include/pvtrace_hip.h declares, agrees with the ctypes mirror on struct
+layout, and fails LOUDLY (never falls back) when no GPU is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pvtrace_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pvt_[a-z_]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol(built):
+    from pvtrace_amd.engine import native
+
+    names = declared_functions()
+    assert len(names) >= 9 and "pvt_trace_bundle" in names and "pvt_trace_device" in names
+    assert set(names) == set(native.ABI_SYMBOLS)
+    lib = native.load_library()
+    for name in names:
+        assert hasattr(lib, name), name
+    assert lib.pvt_abi_version() == 1
+    # the embedded device code object really targets gfx950
+    blob = open(native.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    from pvtrace_amd.engine import native as N
+
+    structs = ["PvtSceneTables", "PvtEmitterTables", "PvtTraceParams", "PvtRays", "PvtTallies",
+               "PvtEventLog"]
+    probes = {"PvtSceneTables": ["n_nodes", "geom_type", "comp_type", "abs_x", "rec_node",
+                                 "hist_prop_a", "coat_facet", "coat_transmit_mode"],
+              "PvtEmitterTables": ["wl_type", "spec_cdf"],
+              "PvtTraceParams": ["seed", "ray_offset", "record_every", "maxsteps", "emit_method"],
+              "PvtRays": ["wavelength"], "PvtTallies": ["rec_bins"], "PvtEventLog": ["kind", "duration"]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for s in structs:
+        lines.append(f'printf("{s} %zu\\n", sizeof({s}));')
+        for f in probes[s]:
+            lines.append(f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));')
+    lines.append("return 0;}")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    for line in out.strip().splitlines():
+        key, value = line.split()
+        if "." in key:
+            s, f = key.split(".")
+            assert getattr(getattr(N, s), f).offset == int(value), key
+        else:
+            assert C.sizeof(getattr(N, key)) == int(value), key
+
+
+def test_header_cites_the_reference_interface():
+    text = open(HEADER).read()
+    assert "_kernel.pyx:903-1115" in text and "compiler.py" in text and "extern \"C\"" in text
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built):
+    from pvtrace_amd import engine
+    from pvtrace_amd.engine import native
+    from tests import scenes
+
+    if native.is_available():
+        pytest.skip("a GPU is visible here")
+    assert engine.is_available() is False
+    with pytest.raises(engine.EngineUnavailableError):
+        engine.simulate(scenes.fresnel_box(), 10, seed=1)
+    from pvtrace_amd.engine import _kernel, compile_scene
+    c = compile_scene(scenes.fresnel_box())
+    with pytest.raises(engine.EngineUnavailableError):
+        _kernel.trace_bundle(c, np.zeros((1, 3)), np.tile((0.0, 0.0, 1.0), (1, 1)), np.full(1, 555.0),
+                             1, 10, 8, 0, 1, 0)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no file of the product package may reference it."""
+    pkg = os.path.join(ROOT, "pvtrace_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "pvt_oracle" in text.replace(
+                        "oracle/pvt_oracle.c", "").replace("pvt_oracle_emit", ""):
+                    offenders.append(os.path.join(dirpath, f))
+    assert offenders == []

@@ -1,0 +1,159 @@
+"""Unit-level golden vectors made by tests/golden/make_golden.py from the REFERENCE's
+own Python modules (spectra, Distribution, Fresnel helpers, Sphere/Cylinder,
+Transformable), checked against (a) the host API of pvtrace_amd and (b) the oracle's
+C functions — the same functions whose GPU twins the -m gpu tests compare bit-for-bit."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pvtrace_amd import Box, Cylinder, Node, Sphere
+from pvtrace_amd.data import fluro_red, lumogen_f_red_305
+from pvtrace_amd.geometry import Transformable
+from pvtrace_amd.material import (
+    Distribution, fresnel_reflectivity, fresnel_refraction, specular_reflection,
+)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def test_spectra_bit_exact():
+    g = load("spectra.npz")
+    assert np.array_equal(lumogen_f_red_305.absorption(g["x"]), g["lumogen_abs"])
+    assert np.array_equal(lumogen_f_red_305.emission(g["x"]), g["lumogen_ems"])
+    assert np.array_equal(lumogen_f_red_305.absorption(g["xw"]), g["lumogen_abs_w"])
+    assert np.array_equal(lumogen_f_red_305.emission(g["xw"]), g["lumogen_ems_w"])
+    assert np.array_equal(fluro_red.absorption(g["xw"]), g["fluro_abs_w"])
+    assert np.array_equal(fluro_red.emission(g["xw"]), g["fluro_ems_w"])
+
+
+def test_distribution_cdf_sample_lookup():
+    g = load("spectra.npz")
+    d = Distribution(g["x"], g["lumogen_ems"])
+    assert np.array_equal(d._cdf, g["lumogen_ems_cdf"])
+    assert np.array_equal(d.sample(g["sample_p"]), g["sample_x"])
+    assert np.array_equal(d.lookup(g["lookup_x"]), g["lookup_p"])
+    assert np.array_equal(d(g["lookup_x"]), g["call_y"])
+    # the kernel's clamped interpolation reproduces np.interp on the same tables
+    xs = g["x"].astype(float)
+    for p, want in zip(g["sample_p"], g["sample_x"]):
+        assert O.interp(p, d._cdf, xs) == pytest.approx(want, rel=1e-15, abs=1e-12)
+    for x, want in zip(g["lookup_x"], g["lookup_p"]):
+        assert O.interp(x, xs, d._cdf) == pytest.approx(want, rel=1e-14, abs=1e-16)
+
+
+def test_distribution_reference_endpoint_cases():
+    """reference tests/test_distibution.py:9-21 (sample(0)/sample(1) hit the range ends)."""
+    x = np.linspace(400, 1010, 2000)
+    y = np.exp(-((x - 700.0) / 60.0) ** 2)
+    d = Distribution(x, y)
+    assert np.isclose(d.sample(0), x.min()) and np.isclose(d.sample(1), x.max())
+    assert np.isclose(d.lookup(x.min()), 0.0) and np.isclose(d.lookup(x.max()), 1.0)
+    with pytest.raises(ValueError):
+        d.sample(1.5)
+    with pytest.raises(ValueError):
+        d.lookup(1200.0)
+
+
+def test_fresnel_reflectivity_golden():
+    g = load("optics.npz")
+    for (n1, n2), row in zip(g["pairs"], g["reflectivity"]):
+        mine = np.array([fresnel_reflectivity(a, n1, n2) for a in g["angles"]])
+        assert np.allclose(mine, row, rtol=1e-13, atol=1e-16)
+        for mode in (O.MATH_LIBM, O.MATH_PORTABLE):
+            orc = np.array([O.fresnel_reflectivity(a, n1, n2, mode) for a in g["angles"]])
+            assert np.allclose(orc, row, rtol=1e-12, atol=1e-15)
+    # reference tests/test_frensel_reflection.py:8-10
+    assert np.isclose(O.fresnel_reflectivity(0.0, 1.0, 1.5), 0.04)
+    assert O.fresnel_reflectivity(1.0, 1.5, 1.0) == 1.0  # beyond the critical angle
+
+
+def test_reflection_refraction_vectors_golden():
+    g = load("optics.npz")
+    for d, n, want in zip(g["d"], g["n"], g["specular"]):
+        assert np.allclose(specular_reflection(d, n), want, rtol=0, atol=1e-15)
+        assert np.allclose(O.specular_reflect(d, n), want, rtol=0, atol=1e-15)
+    for d, nf, want in zip(g["d"], g["nf"], g["refract_up"]):
+        assert np.allclose(fresnel_refraction(d, nf, 1.0, 1.5), want, rtol=0, atol=1e-15)
+        assert np.allclose(O.fresnel_refract(d, nf, 1.0, 1.5), want, rtol=0, atol=1e-15)
+    ok = g["down_mask"]
+    for d, nf, want in zip(g["d"][ok], g["nf"][ok], g["refract_down"]):
+        assert np.allclose(O.fresnel_refract(d, nf, 1.5, 1.0), want, rtol=0, atol=2e-15)
+    # reference tests/test_frensel_refraction.py: normal incidence is not bent
+    assert np.allclose(O.fresnel_refract((0, 0, -1.0), (0, 0, -1.0), 1.0, 1.5), (0, 0, -1.0))
+    # reference tests/test_frensel_reflection.py: the normal's sign does not matter
+    assert np.allclose(O.specular_reflect((0, 0, -1.0), (0, 0, 1.0)), (0, 0, 1.0))
+    assert np.allclose(O.specular_reflect((0, 0, -1.0), (0, 0, -1.0)), (0, 0, 1.0))
+
+
+@pytest.mark.parametrize("shape", ["sphere", "cyl"])
+def test_intersections_and_normals_golden(shape):
+    g = load("geometry.npz")
+    if shape == "sphere":
+        geom, gtype, prm = Sphere(float(g["sphere_radius"])), 1, [float(g["sphere_radius"])]
+    else:
+        geom = Cylinder(float(g["cyl_length"]), float(g["cyl_radius"]))
+        gtype, prm = 2, [float(g["cyl_length"]), float(g["cyl_radius"])]
+    counts, points = g[f"{shape}_count"], g[f"{shape}_points"]
+    k = 0
+    for i, (o, d) in enumerate(zip(g["origin"], g["direction"])):
+        ts = np.sort(O.intersect(gtype, prm, o, d))
+        assert len(ts) == counts[i], i
+        host = geom.intersections(o, d)
+        assert len(host) == counts[i]
+        for j, t in enumerate(ts):
+            assert np.allclose(o + t * d, points[i, j], rtol=0, atol=1e-9)
+            assert np.allclose(host[j], points[i, j], rtol=0, atol=1e-9)
+        if counts[i] > 0:
+            want = g[f"{shape}_normals"][k]
+            k += 1
+            assert np.allclose(O.normal(gtype, prm, points[i, 0]), want, atol=1e-9)
+            assert np.allclose(geom.normal(points[i, 0]), want, atol=1e-9)
+
+
+def test_reference_geometry_known_answers():
+    """Numbers from the reference's tests/test_sphere.py, test_box.py, test_geometry_utils.py."""
+    assert Sphere(1).intersections((-2.0, 0.0, 0.0), (1.0, 0.0, 0.0)) == ((-1.0, 0.0, 0.0), (1.0, 0.0, 0.0))
+    assert Box((1, 1, 1)).intersections((-2.0, 0.0, 0.0), (1.0, 0.0, 0.0)) == ((-0.5, 0.0, 0.0), (0.5, 0.0, 0.0))
+    for p, n in [((0.5, 0, 0), (1, 0, 0)), ((0, 0.5, 0), (0, 1, 0)), ((0, 0, 0.5), (0, 0, 1)),
+                 ((-0.5, 0, 0), (-1, 0, 0)), ((0, -0.5, 0), (0, -1, 0)), ((0, 0, -0.5), (0, 0, -1))]:
+        assert np.allclose(Box((1, 1, 1)).normal(p), n)
+        assert np.allclose(O.normal(0, [1, 1, 1], p), n)
+    assert Sphere(1).contains((0, 0, 0)) and not Sphere(1).contains((0, 0, 1.0))
+    assert Box((1, 1, 1)).contains((0, 0, 0)) and not Box((1, 1, 1)).contains((0, 0, 0.5))
+    assert Box((1, 1, 1)).is_on_surface((0.5, 0, 0)) and not Box((1, 1, 1)).is_on_surface((0.501, 0, 0))
+    # ray / z-cylinder cases (tests/test_geometry_utils.py:63-101), length 1 radius 1
+    cyl = Cylinder(1.0, 1.0)
+    unit = lambda v: np.asarray(v, float) / np.linalg.norm(v)
+    got = cyl.intersections((0.2, 0.2, -1), unit((0, 0, 1.0)))
+    assert np.allclose(got, ((0.2, 0.2, -0.5), (0.2, 0.2, 0.5)))
+    got = cyl.intersections((-2, 0.2, 0.0), unit((1.0, 0.2, -0.2)))
+    assert np.allclose(got, ((-0.9082895433880116, 0.41834209132239775, -0.2183420913223977), (0.5, 0.7, -0.5)))
+    got = cyl.intersections((-2, 0.2, 0.0), unit((1.0, 0.2, 0.2)))
+    assert np.allclose(got, ((-0.9082895433880116, 0.41834209132239775, 0.2183420913223977), (0.5, 0.7, 0.5)))
+    ts = O.intersect(2, [1.0, 1.0], (-2, 0.2, 0.0), unit((1.0, 0.2, 0.2)))
+    assert np.allclose(np.sort(ts), [np.linalg.norm(np.subtract(p, (-2, 0.2, 0.0))) for p in got])
+
+
+def test_transformable_and_node_poses_golden():
+    g = load("transforms.npz")
+    a = Node(name="A"); a.translate((0, 0, 2)); a.rotate(np.pi * 0.2, (0, 1, 0))
+    b = Node(name="B", parent=a); b.rotate(np.pi / 2, (1, 0, 0))
+    world = Node(name="W"); a.parent = world
+    assert np.array_equal(a.pose, g["A"]) and np.array_equal(b.pose, g["B"])
+    assert np.allclose(b.transformation_to(world), g["B_in_world"], rtol=0, atol=1e-15)
+    light = Transformable(); light.location = (0.0, 0.0, 5.0); light.rotate(np.radians(180), (1, 0, 0))
+    assert np.array_equal(light.pose, g["light"])
+    slab = Transformable(); slab.translate((0.5, -0.3, 1.0)); slab.rotate(0.35, (1.0, 0.4, 0.2))
+    assert np.array_equal(slab.pose, g["slab"])
+    loc = Transformable(location=(1.0, 2.0, 3.0)); loc.rotate(1.1, (0.0, 1.0, 0.3)); loc.translate((0.5, 0.5, -2.0))
+    assert np.array_equal(loc.pose, g["located"])
+    # round trips (reference tests/test_node.py:38-63 style)
+    p = (0.3, -0.2, 0.9)
+    assert np.allclose(world.point_to_node(b.point_to_node(p, world), b), p)
+    assert np.allclose(np.linalg.norm(b.vector_to_node((0, 0, 1), world)), 1.0)

@@ -1,0 +1,164 @@
+"""engine.simulate() on the GPU (device-resident entry + torch plumbing): the
+behaviours the reference's own tests/test_engine.py pins for its engine."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pvtrace_amd import LSC, engine
+from pvtrace_amd.engine import Heatmap, Histogram, Recorder, compile_scene, tally_histories
+from pvtrace_amd.engine.emit import EmitterTables, emit_bundle
+from pvtrace_amd.light import Event
+from tests import scenes
+from tests.util import assert_bundles_identical
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_is_available_and_native_library_is_loaded():
+    import os
+    assert engine.is_available()
+    maps = open(f"/proc/{os.getpid()}/maps").read()
+    engine.simulate(scenes.fresnel_box(), 100, seed=1, record_every=0)
+    maps = open(f"/proc/{os.getpid()}/maps").read()
+    assert "libpvtrace_hip.so" in maps
+
+
+def test_simulate_equals_oracle_on_the_same_emitted_rays():
+    scene = scenes.bench_slab(recorders=True)
+    result = engine.simulate(scene, 4000, seed=11, emit_seed=3, max_events=96)
+    pos, dirs, wl, src = emit_bundle(scene, 4000, seed=3)
+    cpu = O.trace_bundle(result.compiled, pos, dirs, wl, 11, 1000, 96, 0, 1, 1, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(result.data, cpu, sums_rtol=1e-12)
+    assert result.sources == src and result.num_rays == 4000 and result.num_recorded == 4000
+    assert result.elapsed > 0 and result.kernel_ms > 0
+
+
+def test_engine_is_deterministic_for_seed_and_ignores_workers():
+    scene = scenes.bench_slab()
+    a = engine.simulate(scene, 500, seed=123, workers=4, emit_seed=1)
+    b = engine.simulate(scene, 500, seed=123, workers=2, emit_seed=1)
+    for key in a.data:
+        assert np.array_equal(a.data[key], b.data[key]), key
+
+
+def test_histories_look_like_python_histories():
+    result = engine.simulate(scenes.fresnel_box(), 10, seed=5)
+    histories = list(result.histories())
+    assert len(histories) == 10
+    for history in histories:
+        ray, event, meta = history[0]
+        assert event == Event.GENERATE and ray.travelled == 0.0 and ray.source == "Light"
+        ray, event, meta = history[-1]
+        assert event in (Event.EXIT, Event.NONRADIATIVE, Event.KILL, Event.REACT)
+        if event == Event.EXIT:
+            assert meta["hit"] == "world"
+    assert result.event_counts()[Event.EXIT] == 10
+
+
+def test_recorders_match_event_log_and_python_tally():
+    scene = scenes.bench_slab(recorders=True)
+    result = engine.simulate(scene, 4000, seed=21, max_events=256, emit_seed=2)
+    recs = result.recorders
+    n_enter = n_top = n_lost = n_exit = 0
+    for history in result.histories():
+        entered = top = lost = exited = False
+        for ray, event, meta in history:
+            if event == Event.TRANSMIT and meta["hit"] == "slab":
+                if meta["adjacent"] == "slab":
+                    entered = True
+                elif meta["container"] == "slab":
+                    nx, ny, nz = meta["normal"]
+                    top |= abs(nx) <= 1e-6 and abs(ny) <= 1e-6 and abs(nz - 1.0) <= 1e-6
+            elif event == Event.NONRADIATIVE and meta["container"] == "slab":
+                lost = True
+            elif event == Event.EXIT:
+                exited = True
+        n_enter += entered; n_top += top; n_lost += lost; n_exit += exited
+    assert recs["entering"].rays == n_enter > 0 and recs["top"].rays == n_top > 0
+    assert recs["lost"].rays == n_lost > 0 and recs["exit"].rays == n_exit > 0
+    assert recs["entering"].mean("wavelength") == pytest.approx(555.0)
+    assert recs["entering"].crossings >= recs["entering"].rays
+    python_side = tally_histories(scene, result.histories())
+    for name, rec in recs.items():
+        assert python_side[name].rays == rec.rays and python_side[name].crossings == rec.crossings
+        for i in range(len(rec.spec.histograms)):
+            assert np.array_equal(python_side[name]._bins[i], rec._bins[i]), (name, i)
+        assert np.allclose(python_side[name]._moments, rec._moments, rtol=1e-9)
+
+
+def test_recorders_independent_of_history_sampling():
+    scene = scenes.bench_slab(recorders=True)
+    full = engine.simulate(scene, 3000, seed=9, record_every=1, max_events=256, emit_seed=4)
+    sampled = engine.simulate(scene, 3000, seed=9, record_every=100, emit_seed=4)
+    none = engine.simulate(scene, 3000, seed=9, record_every=0, emit_seed=4)
+    assert full.recorders["entering"].rays == sampled.recorders["entering"].rays == none.recorders["entering"].rays
+    assert full.recorders["entering"].crossings == none.recorders["entering"].crossings
+    assert (full.num_recorded, sampled.num_recorded, none.num_recorded) == (3000, 30, 0)
+    assert len(list(sampled.histories())) == 30 and len(list(none.histories())) == 0
+    assert np.array_equal(sampled.recorded_indices, np.arange(0, 3000, 100))
+    # the sampled histories are exactly those rays' histories in the full log
+    m = 256
+    for j, i in enumerate(sampled.recorded_indices):
+        k = int(sampled.data["counts"][j])
+        assert k == full.data["counts"][i]
+        assert np.array_equal(sampled.data["kind"][j * 128:j * 128 + k], full.data["kind"][i * m:i * m + k])
+
+
+def test_simulate_stream_accumulates_to_a_single_call():
+    scene = scenes.lsc_equivalent()
+    total = None
+    for result, traced in engine.simulate_stream(scene, 30000, bundle=8000, seed=77, record_every=0,
+                                                 emission="device", emit_seed=5):
+        part = {k: result.data[k].copy() for k in ("rec_distinct", "rec_crossings", "rec_bins")}
+        total = part if total is None else {k: total[k] + part[k] for k in part}
+    assert traced == 30000
+    whole = engine.simulate(scene, 30000, seed=77, record_every=0, emission="device", emit_seed=5)
+    for key in total:
+        assert np.array_equal(total[key], whole.data[key]), key
+
+
+def test_device_emission_mode_equals_oracle():
+    scene = scenes.kitchen_sink()
+    result = engine.simulate(scene, 6000, seed=3, emission="device", emit_seed=12, max_events=64)
+    pos, dirs, wl = O.emit(EmitterTables(scene), 6000, emit_seed=12)
+    cpu = O.trace_bundle(result.compiled, pos, dirs, wl, 3, 1000, 64, 0, 1, 1, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(result.data, cpu, sums_rtol=1e-12)
+    assert result.sources[:4] == ["lamp", "glow", "lamp", "glow"]
+
+
+def test_lsc_high_level_api_runs_on_the_engine():
+    lsc = LSC((5.0, 5.0, 1.0))
+    lsc.simulate(200000, seed=4, emit_seed=6)
+    s = lsc.summary()
+    assert abs(s["escaping-top"] - 0.207) < 0.006 and abs(s["lost"] - 0.340) < 0.006
+    assert abs(s["entered"] - 0.960) < 0.003
+    cells = LSC((5.0, 5.0, 1.0)); cells.add_solar_cell({"left", "right", "near", "far"}); cells.add_back_surface_mirror()
+    cells.simulate(200000, seed=4, emit_seed=6)
+    t = cells.summary()
+    assert t["escaping-bottom"] == 0.0                       # perfect back mirror
+    assert t["optical-efficiency"] > s["optical-efficiency"]  # index-matched cells collect more
+    mirror = LSC((5.0, 5.0, 1.0)); mirror.add_air_gap_mirror(lambertian=True)
+    r = mirror.simulate(50000, seed=4, emit_seed=6)
+    assert r.compiled.node_names == ["World", "LSC", "Air Gap Mirror"]
+
+
+def test_unsupported_scene_and_bad_arguments_raise():
+    from pvtrace_amd import Box, Light, Material, Node, Scene, Sphere, Surface, SurfaceDelegate
+
+    class Custom(SurfaceDelegate):
+        def reflectivity(self, *a): return 0.5
+        def reflected_direction(self, *a): return (0, 0, 1)
+        def transmitted_direction(self, *a): return (0, 0, 1)
+    w = Node(name="w", geometry=Sphere(10.0, material=Material(1.0)))
+    Node(name="n", parent=w, geometry=Box((1, 1, 1), material=Material(1.5, surface=Surface(delegate=Custom()))))
+    Node(name="l", parent=w, light=Light())
+    with pytest.raises(engine.UnsupportedSceneError):
+        engine.simulate(Scene(w), 10)
+    with pytest.raises(ValueError):
+        engine.simulate(scenes.fresnel_box(), 10, emit_method="nope")
+    w2 = Node(name="w", geometry=Sphere(5.0, material=Material(1.0)))
+    Node(name="l", parent=w2, light=Light(direction=lambda: (0.0, 1.0, 0.0)))
+    with pytest.raises(engine.UnsupportedSceneError):
+        engine.simulate(Scene(w2), 10, emission="device")
+    r = engine.simulate(Scene(w2), 10, seed=1)    # host fallback emitter still works
+    assert r.event_counts()[Event.EXIT] == 10

@@ -1,0 +1,101 @@
+"""The oracle pinned to the reference: committed fixtures hold what the REFERENCE's
+native kernel returned for our tables + seeded rays (tests/golden/make_golden.py).
+math_mode 0 must reproduce every array bit for bit; math_mode 1 (the arithmetic the
+GPU uses) must tell the same story up to last-ulp drift."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pvtrace_amd.engine import compile_scene
+from pvtrace_amd.engine.emit import emit_bundle
+from tests import scenes
+from tests.util import assert_bundles_identical, assert_same_tables, load_golden, three_sigma
+
+
+def run_fixture(name, math_mode, threads=1):
+    g = load_golden(f"trace_{name}.npz")
+    compiled = compile_scene(scenes.REFERENCE_SCENES[name]())
+    assert_same_tables(compiled, g)
+    out = O.trace_bundle(compiled, g["in_pos"], g["in_dir"], g["in_wl"], int(g["par_seed"]),
+                         int(g["par_maxsteps"]), int(g["par_max_events"]), int(g["par_emit_method"]),
+                         threads, int(g["par_record_every"]), math_mode=math_mode)
+    ref = {k[4:]: g[k] for k in g.files if k.startswith("ref_")}
+    return out, ref, g
+
+
+@pytest.mark.parametrize("name", sorted(scenes.REFERENCE_SCENES))
+def test_oracle_libm_is_bit_identical_to_reference_kernel(name):
+    out, ref, _ = run_fixture(name, O.MATH_LIBM)
+    assert_bundles_identical(out, ref, what=name)
+
+
+@pytest.mark.parametrize("name", sorted(scenes.REFERENCE_SCENES))
+def test_oracle_thread_count_does_not_change_histories(name):
+    out, ref, _ = run_fixture(name, O.MATH_LIBM, threads=4)
+    assert_bundles_identical(out, ref, sums_rtol=1e-12, what=name)
+
+
+@pytest.mark.parametrize("name", sorted(scenes.REFERENCE_SCENES))
+def test_portable_math_tells_the_same_story(name):
+    """Same event sequences for (nearly) every ray; numbers equal to ~1e-9."""
+    out, ref, g = run_fixture(name, O.MATH_PORTABLE)
+    m = int(g["par_max_events"])
+    n = ref["counts"].shape[0]
+    same = 0
+    for j in range(n):
+        a = ref["kind"][j * m:(j + 1) * m]
+        b = out["kind"][j * m:(j + 1) * m]
+        if ref["counts"][j] == out["counts"][j] and np.array_equal(a, b):
+            same += 1
+            rows = slice(j * m, j * m + int(ref["counts"][j]))
+            assert np.allclose(out["position"][rows], ref["position"][rows], rtol=0, atol=1e-8)
+            assert np.allclose(out["wavelength"][rows], ref["wavelength"][rows], rtol=1e-10)
+    assert same >= n - 2, (name, same, n)
+
+
+def test_snell_directions_bit_identical_before_first_absorption():
+    """north_star: 'Snell angles bit-identical for fixed seeds'.  Refraction uses only
+    + - * / sqrt, so every TRANSMIT row that precedes a ray's first ABSORB must carry
+    exactly the reference's direction even in portable-math mode."""
+    checked = 0
+    for name in ("lsc_equivalent", "hello_world", "nested_cylinders", "fresnel_box", "touching_boxes"):
+        out, ref, g = run_fixture(name, O.MATH_PORTABLE)
+        m = int(g["par_max_events"])
+        for j in range(ref["counts"].shape[0]):
+            for row in range(j * m, j * m + int(ref["counts"][j])):
+                if ref["kind"][row] == 3:  # ABSORB
+                    break
+                if ref["kind"][row] == 2:  # TRANSMIT
+                    assert out["kind"][row] == 2
+                    assert np.array_equal(out["direction"][row], ref["direction"][row]), (name, j, row)
+                    checked += 1
+    assert checked > 1000
+
+
+def test_headline_tallies_one_million_photons():
+    """BASELINE configs[1]: 10^6 photons.  libm mode reproduces the reference's integer
+    tallies EXACTLY; portable mode within 3 sigma (north_star) — in fact within a few counts."""
+    g = load_golden("tallies_lsc_1e6.npz")
+    scene = scenes.lsc_equivalent()
+    compiled = compile_scene(scene)
+    assert_same_tables(compiled, g)
+    n = int(g["n"])
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=int(g["emit_seed"]))
+    checksum = np.array([pos.sum(), dirs.sum(), wl.sum(), np.abs(dirs).sum()])
+    same_inputs = np.array_equal(checksum, g["input_checksum"])
+    libm = O.trace_bundle(compiled, pos, dirs, wl, int(g["seed"]), 1000, 128, 0, 8, 0, math_mode=O.MATH_LIBM)
+    port = O.trace_bundle(compiled, pos, dirs, wl, int(g["seed"]), 1000, 128, 0, 8, 0, math_mode=O.MATH_PORTABLE)
+    if same_inputs:
+        for key in ("rec_distinct", "rec_crossings", "rec_bins"):
+            assert np.array_equal(libm[key], g[key]), key
+        assert np.allclose(libm["rec_sums"], g["rec_sums"], rtol=1e-10)
+    for r, name in enumerate(g["recorder_names"]):
+        pa, pb = port["rec_distinct"][r] / n, g["rec_distinct"][r] / n
+        assert abs(pa - pb) <= three_sigma(pa, pb, n, n) + 1e-12, (name, pa, pb)
+    # published-in-survey reference fractions (1 sigma ~ 3-5e-4)
+    frac = {str(k): v / n for k, v in zip(g["recorder_names"], g["rec_distinct"])}
+    assert abs(frac["top"] - 0.20723) < 0.002 and abs(frac["lost"] - 0.33984) < 0.002
+    assert abs(frac["entering"] - 0.96000) < 0.001 and frac["killed"] == 0.0
+    # conservation: every photon that entered either escapes a face or is lost
+    esc = sum(port["rec_distinct"][:6])
+    assert port["rec_distinct"][7] <= esc + port["rec_distinct"][6] + port["rec_distinct"][9]

@@ -1,0 +1,46 @@
+"""Live referee-of-the-referee: when /root/reference is present (build container
+only) drive the reference's compiled kernel and the oracle with fresh random inputs
+and require identical outputs.  Skipped on the GPU box, where the committed golden
+fixtures (tests/test_oracle_golden.py) carry the same guarantee."""
+import numpy as np
+import pytest
+
+from oracle import build_ref
+from oracle import oracle as O
+from pvtrace_amd.engine import compile_scene
+from pvtrace_amd.engine.emit import emit_bundle
+from tests import scenes
+from tests.util import assert_bundles_identical
+
+pytestmark = pytest.mark.skipif(not build_ref.ref_available(),
+                                reason="reference tree not present on this machine")
+
+
+@pytest.mark.parametrize("name", sorted(scenes.REFERENCE_SCENES))
+@pytest.mark.parametrize("mode", [(1, 40, 1000, 0), (0, 128, 30, 1), (5, 12, 1000, 2)])
+def test_oracle_equals_reference_kernel(name, mode):
+    record_every, max_events, maxsteps, emit_method = mode
+    scene = scenes.REFERENCE_SCENES[name]()
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, 1500, seed=hash(name) % 1000)
+    ref = O.reference_trace_bundle(compiled, pos, dirs, wl, 31337, maxsteps, max_events,
+                                   emit_method, 1, record_every)
+    mine = O.trace_bundle(compiled, pos, dirs, wl, 31337, maxsteps, max_events, emit_method, 1,
+                          record_every, math_mode=O.MATH_LIBM)
+    assert_bundles_identical(mine, ref, what=name)
+
+
+def test_reference_rejects_more_than_128_nodes_like_we_do():
+    from pvtrace_amd import Box, Light, Material, Node, Scene
+
+    world = Node(name="w", geometry=Box((1000.0, 10.0, 10.0), material=Material(1.0)))
+    for i in range(128):
+        Node(name=f"b{i}", parent=world, location=(-400.0 + 6.0 * i, 0.0, 0.0),
+             geometry=Box((1.0, 1.0, 1.0), material=Material(1.5)))
+    Node(name="l", parent=world, light=Light())
+    compiled = compile_scene(Scene(world))
+    pos, dirs, wl = np.zeros((4, 3)), np.tile((0.0, 0.0, 1.0), (4, 1)), np.full(4, 555.0)
+    with pytest.raises(ValueError):
+        O.reference_trace_bundle(compiled, pos, dirs, wl, 1, 10, 8, 0, 1, 0)
+    with pytest.raises(ValueError):
+        O.trace_bundle(compiled, pos, dirs, wl, 1, 10, 8, 0, 1, 0)

@@ -1,0 +1,232 @@
+"""Host side: scene graph, flattener, recorders, emitters, LSC builder, and the
+pure-Python tally — the parts of the reference API the hot path sits behind
+(constructor surface of SURVEY.md §8(b))."""
+import functools
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pvtrace_amd import (
+    LSC, Absorber, Box, Coating, CoatedSurfaceDelegate, Cylinder, Light, Luminophore, Material,
+    Node, Reactor, Scatterer, Scene, Sphere, Surface, SurfaceDelegate, cone, engine, isotropic,
+)
+from pvtrace_amd.engine import (
+    Heatmap, Histogram, Recorder, UnsupportedSceneError, compile_scene, tally_histories,
+)
+from pvtrace_amd.engine import compiler as C
+from pvtrace_amd.engine.api import EngineResult
+from pvtrace_amd.engine.emit import EmitterTables, emit_bundle, sources_for
+from pvtrace_amd.light import Event
+from tests import scenes
+
+
+def test_node_tree_and_preorder():
+    w = Node(name="w"); a = Node(name="a", parent=w); b = Node(name="b", parent=w)
+    c = Node(name="c", parent=a)
+    assert [n.name for n in w.preorder()] == ["w", "a", "c", "b"]
+    assert [n.name for n in w.levelorder()] == ["w", "a", "b", "c"]
+    assert c.root is w and c.path == (w, a, c) and w.leaves == (c, b)
+    c.parent = b
+    assert [n.name for n in w.preorder()] == ["w", "a", "b", "c"]
+    with pytest.raises(Exception):
+        w.parent = c
+
+
+def test_compile_headline_scene_tables():
+    c = compile_scene(scenes.lsc_equivalent())
+    assert c.node_names == ["World", "LSC"] and c.root_id == 0
+    assert c.geom_type.tolist() == [C.GEOM_BOX, C.GEOM_BOX]
+    assert c.geom_params[:, :3].tolist() == [[500.0, 500.0, 100.0], [5.0, 5.0, 1.0]]
+    assert c.refractive_index.tolist() == [1.0, 1.5]
+    assert c.comp_start.tolist() == [0, 0] and c.comp_count.tolist() == [0, 2]
+    assert c.comp_type.tolist() == [C.COMP_LUMINOPHORE, C.COMP_ABSORBER]
+    assert c.comp_abs_n.tolist() == [400, 1] and c.comp_ems_n.tolist() == [400, 0]
+    assert c.abs_x.shape == (401,) and c.abs_x[-1] == 0.0 and c.abs_y[-1] == 0.1  # constant -> (0, c)
+    assert c.ems_cdf[0] == 0.0 and c.ems_cdf[399] == 1.0
+    assert c.component_names == ["Lumogen F Red 305", "Background"]
+    assert len(c.recorder_names) == 10 and c.total_bins == 6 * 80
+    assert np.array_equal(c.local_to_world[1], np.eye(4))
+    assert c.rec_event.tolist() == [1] * 6 + [3, 0, 2, 5]
+    for dtype_i in ("geom_type", "surface_type", "comp_type", "rec_node", "hist_offset"):
+        assert getattr(c, dtype_i).dtype == np.int32
+
+
+def test_compile_rejects_what_the_reference_rejects():
+    class Custom(SurfaceDelegate):
+        def reflectivity(self, *a): return 0.5
+        def reflected_direction(self, *a): return (0, 0, 1)
+        def transmitted_direction(self, *a): return (0, 0, 1)
+
+    def scene_with(material=None, geometry=None, recorders=None, light=True):
+        w = Node(name="w", geometry=Sphere(10.0, material=Material(1.0)))
+        g = geometry if geometry is not None else Box((1, 1, 1), material=material)
+        Node(name="n", parent=w, geometry=g, recorders=recorders)
+        if light:
+            Node(name="l", parent=w, light=Light())
+        return Scene(w)
+
+    with pytest.raises(UnsupportedSceneError):   # custom Python surface delegate
+        compile_scene(scene_with(Material(1.5, surface=Surface(delegate=Custom()))))
+    with pytest.raises(UnsupportedSceneError):   # custom phase function
+        compile_scene(scene_with(Material(1.5, components=[Scatterer(1.0, phase_function=lambda: (0, 0, 1))])))
+    with pytest.raises(UnsupportedSceneError):   # histogram-sampled spectrum
+        x = np.linspace(400, 800, 10)
+        compile_scene(scene_with(Material(1.5, components=[Absorber(np.column_stack((x, x * 0 + 1)), hist=True)])))
+    with pytest.raises(UnsupportedSceneError):   # geometry without material
+        compile_scene(scene_with(None))
+    with pytest.raises(UnsupportedSceneError):   # facet on a volume event
+        compile_scene(scene_with(Material(1.5), recorders=[Recorder("x", event="lost", facet=(0, 0, 1))]))
+    with pytest.raises(UnsupportedSceneError):   # duplicate names
+        compile_scene(scene_with(Material(1.5), recorders=[Recorder("x"), Recorder("x")]))
+    with pytest.raises(UnsupportedSceneError):   # non-rigid pose
+        s = scene_with(Material(1.5)); n = s.root.children[0]
+        pose = np.eye(4); pose[0, 0] = 2.0; n.pose = pose
+        compile_scene(s)
+    with pytest.raises(UnsupportedSceneError):   # root without geometry
+        compile_scene(Scene(Node(name="empty")))
+
+    class Blob:  # unsupported geometry type (the reference rejects meshes, tests/test_engine.py:418-436)
+        material = Material(1.5)
+    with pytest.raises(UnsupportedSceneError):
+        compile_scene(scene_with(geometry=Blob()))
+    with pytest.raises(ValueError):
+        Recorder("r", event="nonsense")
+    with pytest.raises(ValueError):
+        Histogram("wavelength", 5, 5, 10)
+    with pytest.raises(ValueError):
+        Histogram("colour", 0, 1, 10)
+
+
+def test_simulate_validates_before_touching_the_gpu():
+    with pytest.raises(ValueError):
+        engine.simulate(scenes.fresnel_box(), 10, emit_method="planck")
+    class Custom(SurfaceDelegate):
+        def reflectivity(self, *a): return 0.5
+        def reflected_direction(self, *a): return (0, 0, 1)
+        def transmitted_direction(self, *a): return (0, 0, 1)
+    w = Node(name="w", geometry=Sphere(10.0, material=Material(1.0)))
+    Node(name="n", parent=w, geometry=Box((1, 1, 1), material=Material(1.5, surface=Surface(delegate=Custom()))))
+    Node(name="l", parent=w, light=Light())
+    with pytest.raises(UnsupportedSceneError):
+        engine.simulate(Scene(w), 10)
+
+
+def test_phase_functions_lowered_in_every_spelling():
+    from pvtrace_amd.material import Cone, HenyeyGreenstein, henyey_greenstein
+    for phase, want in [(None, (0, 0.0)), (isotropic, (0, 0.0)), (HenyeyGreenstein(0.3), (1, 0.3)),
+                        (Cone(0.2), (2, 0.2)), (functools.partial(cone, 0.25), (2, 0.25)),
+                        (functools.partial(henyey_greenstein, -0.4), (1, -0.4))]:
+        w = Node(name="w", geometry=Sphere(5.0, material=Material(1.0, components=[Scatterer(0.5, phase_function=phase)])))
+        Node(name="l", parent=w, light=Light())
+        c = compile_scene(Scene(w))
+        assert (int(c.comp_phase_type[0]), float(c.comp_phase_param[0])) == want
+
+
+def test_emit_bundle_matches_reference_distributions():
+    scene = scenes.lsc_equivalent()
+    pos, dirs, wl, src = emit_bundle(scene, 20000, seed=4)
+    assert pos.shape == (20000, 3) and np.all(pos == (0.0, 0.0, 5.0)) and np.all(wl == 555.0)
+    assert set(src) == {"Light"}
+    assert np.allclose(np.linalg.norm(dirs, axis=1), 1.0)
+    # flipped about x: the cone points down; polar angle <= 20 degrees
+    cosang = -dirs[:, 2]
+    assert cosang.min() >= np.cos(np.radians(20)) - 1e-12
+    # pdf ~ cos(theta) sin(theta): E[sin^2 theta] = sin^2(theta_max)/2
+    assert abs(np.mean(1 - cosang ** 2) - np.sin(np.radians(20)) ** 2 / 2) < 2e-3
+    # round-robin over two lights, level order
+    ks = scenes.kitchen_sink()
+    _, _, wl2, src2 = emit_bundle(ks, 10, seed=1)
+    assert src2 == ["lamp", "glow"] * 5 and sources_for(ks, 10) == src2
+    assert np.all(wl2[1::2] == 480.0)
+    # global numpy state like the reference when seed is None
+    np.random.seed(3); a = emit_bundle(ks, 50)[0]
+    np.random.seed(3); b = emit_bundle(ks, 50)[0]
+    assert np.array_equal(a, b)
+
+
+def test_emit_falls_back_for_custom_delegates_and_device_mode_refuses():
+    w = Node(name="w", geometry=Sphere(5.0, material=Material(1.0)))
+    Node(name="l", parent=w, light=Light(direction=lambda: (0.0, 1.0, 0.0), name="odd"))
+    scene = Scene(w)
+    pos, dirs, wl, src = emit_bundle(scene, 7, seed=1)
+    assert np.all(dirs == (0.0, 1.0, 0.0)) and src == ["odd"] * 7
+    with pytest.raises(UnsupportedSceneError):
+        EmitterTables(scene, strict=True)
+
+
+def test_oracle_emitter_statistics_and_reproducibility():
+    ks = scenes.kitchen_sink()
+    tab = EmitterTables(ks)
+    p1, d1, w1 = O.emit(tab, 4000, emit_seed=9)
+    p2, d2, w2 = O.emit(tab, 1000, emit_seed=9, ray_offset=3000)
+    assert np.array_equal(p1[3000:], p2) and np.array_equal(d1[3000:], d2) and np.array_equal(w1[3000:], w2)
+    assert np.allclose(np.linalg.norm(d1, axis=1), 1.0)
+    lamp = slice(0, None, 2)
+    assert np.all(np.hypot(p1[lamp, 0], p1[lamp, 1]) <= 1.5 + 1e-12) and np.all(p1[lamp, 2] == 8.0)
+    assert 350 <= w1[lamp].min() and w1[lamp].max() <= 900 and abs(w1[lamp].mean() - 500) < 5
+    assert np.all(w1[1::2] == 480.0)
+
+
+def test_lsc_builder_lowers_its_delegates_to_coatings():
+    lsc = LSC((5.0, 5.0, 1.0))
+    c = compile_scene(lsc.scene)
+    assert c.node_names == ["World", "LSC"] and c.n_coatings == 0      # plain Fresnel
+    ref = compile_scene(scenes.lsc_equivalent(recorders=False))
+    for key in ("geom_params", "local_to_world", "refractive_index", "abs_x", "abs_y", "ems_x", "ems_cdf",
+                "comp_type", "comp_qy"):
+        assert np.array_equal(getattr(c, key), getattr(ref, key)), key
+    lsc2 = LSC((5.0, 5.0, 1.0))
+    lsc2.add_solar_cell({"left", "right"}); lsc2.add_back_surface_mirror(); lsc2.add_air_gap_mirror(lambertian=True)
+    c2 = compile_scene(lsc2.scene)
+    assert c2.node_names == ["World", "LSC", "Air Gap Mirror"]
+    assert c2.coat_count.tolist() == [0, 3, 6]
+    assert c2.coat_reflectivity[:3].tolist() == [1.0, 0.0, 0.0] and c2.coat_transmit_mode[:3].tolist() == [0, 1, 1]
+    assert set(c2.coat_reflect_mode[3:].tolist()) == {1} and np.all(c2.coat_reflectivity[3:] == 1.0)
+    with pytest.raises(ValueError):
+        lsc2.add_solar_cell({"top"})
+
+
+def test_python_tally_reproduces_oracle_tallies_exactly():
+    """reference tests/test_engine.py:286-318, with the oracle standing in for the engine."""
+    scene = scenes.bench_slab(recorders=True)
+    compiled = compile_scene(scene)
+    pos, dirs, wl, src = emit_bundle(scene, 1500, seed=17)
+    data = O.trace_bundle(compiled, pos, dirs, wl, 17, 1000, 256, 0, 1, 1)
+    result = EngineResult(compiled, data, src, 256, 1, 0.0)
+    python_side = tally_histories(scene, result.histories())
+    for name, rec in result.recorders.items():
+        assert python_side[name].rays == rec.rays and python_side[name].crossings == rec.crossings, name
+        for i in range(len(rec.spec.histograms)):
+            assert np.array_equal(python_side[name]._bins[i], rec._bins[i]), (name, i)
+        assert np.allclose(python_side[name]._moments, rec._moments, rtol=1e-9), name
+    assert result.recorders["entering"].mean("wavelength") == pytest.approx(555.0)
+    counts = result.event_counts()
+    assert counts[Event.GENERATE] == 1500 and counts[Event.EXIT] + counts[Event.NONRADIATIVE] + counts[Event.KILL] == 1500
+    edges, values = result.recorders["entering"].histogram(0)
+    assert edges.size == 51 and values.sum() == result.recorders["entering"].rays
+    xe, ye, heat = result.recorders["top"].histogram(0)
+    assert heat.shape == (20, 20) and heat.sum() == result.recorders["top"].rays
+
+
+def test_coating_semantics_on_the_oracle():
+    """Extension (no reference-engine counterpart): mirror quadrant reflects with p=1,
+    everything else is Fresnel; index-matched cell faces transmit undeviated."""
+    scene = scenes.coated_slab(scatter=0.0)
+    compiled = compile_scene(scene)
+    n = 4000
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=8)
+    data = O.trace_bundle(compiled, pos, dirs, wl, 5, 1000, 32, 0, 1, 1)
+    first = np.arange(n) * 32 + 1          # the event after GENERATE: hits the slab's top face
+    on_mirror = (pos[:, 0] > 0) & (pos[:, 1] > 0)
+    assert np.all(data["kind"][first][on_mirror] == 1)                    # REFLECT, always
+    frac_reflected = np.mean(data["kind"][first][~on_mirror] == 1)
+    assert abs(frac_reflected - 0.04) < 0.012                             # Fresnel at normal incidence
+    lsc = LSC((5.0, 5.0, 1.0)); lsc.add_solar_cell({"left", "right", "near", "far"})
+    c = compile_scene(lsc.scene)
+    p, d, w, _ = emit_bundle(lsc.scene, 3000, seed=2)
+    out = O.trace_bundle(c, p, d, w, 3, 1000, 64, 0, 1, 1)
+    rows = (out["kind"] == 2) & (out["hit"] == 1) & (np.abs(out["normal"][:, 2]) < 0.5) & (out["container"] == 1)
+    idx = np.flatnonzero(rows)
+    assert idx.size > 100
+    assert np.array_equal(out["direction"][idx], out["direction"][idx - 1])   # straight through the cell faces

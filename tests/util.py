@@ -1,0 +1,43 @@
+"""Helpers shared by the test modules."""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+INT_KEYS = ("counts", "rec_distinct", "rec_crossings", "rec_bins", "kind", "hit", "container",
+            "adjacent", "component", "source")
+F64_KEYS = ("position", "direction", "normal", "wavelength", "travelled", "duration")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def assert_same_tables(compiled, gold):
+    """The fixture was made with these exact tables; any drift invalidates it."""
+    for key, value in compiled.tables().items():
+        want = gold[f"tab_{key}"]
+        assert np.array_equal(np.asarray(value), want), f"flattener table {key} drifted from fixture"
+
+
+def assert_bundles_identical(got, want, sums_rtol=None, what=""):
+    """Every key equal bit for bit; rec_sums optionally to a tolerance (its
+    summation order is not defined on a parallel machine)."""
+    for key in want:
+        a, b = np.asarray(got[key]), np.asarray(want[key])
+        assert a.shape == b.shape, (what, key, a.shape, b.shape)
+        if key == "rec_sums" and sums_rtol is not None:
+            assert np.allclose(a, b, rtol=sums_rtol, atol=0.0), (what, key)
+        else:
+            assert np.array_equal(a, b), (what, key, int(np.sum(a != b)))
+
+
+def rows_of_ray(data, j, max_events):
+    n = int(data["counts"][j])
+    return slice(j * max_events, j * max_events + n)
+
+
+def three_sigma(p_hat_a, p_hat_b, n_a, n_b):
+    """|pa - pb| <= 3 sqrt(p(1-p)(1/na + 1/nb)) with the pooled p."""
+    p = (p_hat_a * n_a + p_hat_b * n_b) / (n_a + n_b)
+    return 3.0 * np.sqrt(max(p * (1 - p), 1e-12) * (1.0 / n_a + 1.0 / n_b))
