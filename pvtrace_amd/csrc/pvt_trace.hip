@@ -29,12 +29,19 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/pvtrace_hip.h"
 #include "pvt_math.h"
+
+// Developer-only ablation switches (timing experiments; results are WRONG when set).
+#ifndef PVT_ABLATE
+#define PVT_ABLATE 0
+#endif
+#define ABL(bit) ((PVT_ABLATE >> (bit)) & 1)   // 0 tally, 1 fresnel, 2 emission wl, 3 phase, 4 interp, 5 refill rng
 
 namespace {
 
@@ -46,16 +53,26 @@ constexpr double kCcm = 2.99792458e10;               // :33
 constexpr double kPi = 3.14159265358979323846;
 constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 
-// Offsets (in elements) of every table inside the double / int32 blobs.
-struct Off {
-    // doubles
-    int geom_params, w2l, l2w, nidx, comp_qy, comp_tau_rad, comp_tau_nr, comp_phase_param;
-    int abs_x, abs_y, ems_x, ems_cdf, rec_facet, rec_atol, h_lo_a, h_hi_a, h_lo_b, h_hi_b;
-    int coat_facet, coat_lo, coat_hi, coat_refl;
-    // int32
-    int geom_type, surf_type, comp_start, comp_count, coat_start, coat_count, comp_type;
-    int comp_phase_type, abs_start, abs_n, ems_start, ems_n, rec_node, rec_event, rec_has_facet;
-    int rec_hist_start, rec_hist_n, h_prop_a, h_prop_b, h_na, h_nb, h_offset, coat_rmode, coat_tmode;
+// Scene blobs are arrays of fixed-stride RECORDS (one double blob, one int32 blob), so a
+// table element is addressed as base + index*stride + field with compile-time strides
+// and fields; only the eight record bases below live in SGPRs (node records start at 0).
+enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND = 26 };           // node doubles
+enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI };  // node ints
+enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD };                         // component doubles
+enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N, CI };
+enum { RD_FACET = 0, RD_ATOL = 3, RD = 4 };                                     // recorder
+enum { RI_NODE = 0, RI_EVENT, RI_HAS_FACET, RI_HSTART, RI_HN, RI };
+enum { HD_LO_A = 0, HD_HI_A, HD_LO_B, HD_HI_B, HD };                             // histogram
+enum { HI_PA = 0, HI_PB, HI_NA, HI_NB, HI_OFF, HI };
+enum { KD_FACET = 0, KD_LO = 3, KD_HI = 6, KD_REFL = 9, KD = 10 };              // coating
+enum { KI_RMODE = 0, KI_TMODE, KI };
+
+struct Lay {  // record bases (elements) inside the blobs; spectra follow the records and are
+              // addressed by absolute offsets stored in the component records
+    int comp_d, rec_d, hist_d, coat_d;
+    int comp_i, rec_i, hist_i, coat_i;
+    int cand_i;     // (n_nodes*7) x {start, count}: recorders that can fire for (node, selector)
+    int cand_list;  // recorder ids, ascending within each (node, selector)
 };
 
 struct EmitOff {  // emitter blobs (global only; read once per photon)
@@ -68,7 +85,7 @@ struct KArgs {
     const int* gi;      // scene int blob
     const double* ed;   // emitter blobs (may be null)
     const int* ei;
-    Off off;
+    Lay lay;
     EmitOff eoff;
     int nd, ni;         // blob lengths
     int n_nodes, root, n_rec, total_bins, n_coat, n_lights;
@@ -125,16 +142,25 @@ __device__ __forceinline__ double rng_uniform(Rng& r) {
 // ------------------------------------------------------------ table access
 // TAB_LDS: divergent reads come from the LDS copy; uniform reads always come
 // from the global blob so the compiler can use scalar loads.
+// Read-only scene blobs viewed through the CONSTANT address space: a load whose
+// address is wave-uniform then becomes an s_load through the scalar cache (SGPR result,
+// no VGPR address arithmetic) instead of a 64-lane global_load of one address.  The
+// blobs are never written while a trace kernel runs, which is what makes this legal.
+typedef const __attribute__((address_space(4))) double* CDoubles;
+typedef const __attribute__((address_space(4))) int* CInts;
+
 template <bool TAB_LDS>
 struct Tables {
-    const double* __restrict__ gd;
-    const int* __restrict__ gi;
-    const double* ld;  // LDS copies (== gd/gi when !TAB_LDS)
+    CDoubles gd;
+    CInts gi;
+    const double* ld;  // LDS copies (== global blobs when !TAB_LDS)
     const int* li;
+    const double* __restrict__ hd;
+    const int* __restrict__ hi;
     __device__ __forceinline__ double du(int i) const { return gd[i]; }  // uniform index
     __device__ __forceinline__ int iu(int i) const { return gi[i]; }
-    __device__ __forceinline__ double dv(int i) const { return TAB_LDS ? ld[i] : gd[i]; }  // per-lane index
-    __device__ __forceinline__ int iv(int i) const { return TAB_LDS ? li[i] : gi[i]; }
+    __device__ __forceinline__ double dv(int i) const { return TAB_LDS ? ld[i] : hd[i]; }  // per-lane index
+    __device__ __forceinline__ int iv(int i) const { return TAB_LDS ? li[i] : hi[i]; }
 };
 
 struct V3 {
@@ -345,10 +371,11 @@ struct Seen {
 };
 
 // --------------------------------------------------------------- kernel
-template <bool RECORD, bool TAB_LDS, int SEENW, bool COATED>
+template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
 __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     extern __shared__ double smem[];
-    const Off& O = A.off;
+    const Lay L = A.lay;
+    const bool coated = A.n_coat > 0;  // wave-uniform
 
     // ---- stage tables + zero accumulators --------------------------------
     double* lds_d = smem;
@@ -369,7 +396,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         for (int i = threadIdx.x; i < A.total_bins; i += kBlock) acc_bins[i] = 0u;
     __syncthreads();
 
-    Tables<TAB_LDS> T{A.gd, A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi};
+    Tables<TAB_LDS> T{(CDoubles)A.gd, (CInts)A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi, A.gd, A.gi};
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -408,12 +435,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             unsigned int want = __popcll(need);
             if (!alive && rank < avail) {
                 unsigned int i = w_next + rank;
-                if (A.pos != nullptr) {
+                if constexpr (EMIT) {
+                    emit_one(A, A.ray_offset + i, pos, dir, wl);
+                } else {
                     pos = V3{A.pos[i * 3ull], A.pos[i * 3ull + 1], A.pos[i * 3ull + 2]};
                     dir = V3{A.dir[i * 3ull], A.dir[i * 3ull + 1], A.dir[i * 3ull + 2]};
                     wl = A.wl[i];
-                } else {
-                    emit_one(A, A.ray_offset + i, pos, dir, wl);
                 }
                 rng_seed(rng, A.seed + (unsigned long long)i);
                 travelled = 0.0;
@@ -461,7 +488,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 int nhits = 0, n1 = -1, n2 = -1, cnode = -1;
                 double t1 = INFINITY, t2 = INFINITY, cbest = INFINITY;
                 for (int node = 0; node < A.n_nodes; node++) {
-                    const int m = O.w2l + node * 12;
+                    const int m = node * ND + ND_W2L;
                     V3 o, d;
                     o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + T.du(m + 3);
                     o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + T.du(m + 7);
@@ -469,8 +496,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
                     d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
                     d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
-                    const int gp = O.geom_params + node * 4;
-                    const int gt = T.iu(O.geom_type + node);
+                    const int gp = node * ND + ND_PARAMS;
+                    const int gt = T.iu(node * NI + NI_GEOM);
                     // Hits are folded as they are found, in the reference's (node, k)
                     // order, so no per-ray hit list exists; the tie-breaks equal the
                     // reference's argmin scans over its hit arrays (:684-714).
@@ -565,7 +592,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         terminal = true;
                         t_sel = PVT_REC_KILLED; t_node = container;
                     } else {
-                        const double n_container = T.dv(O.nidx + container);
+                        const double n_container = T.dv(container * ND + ND_N);
                         if (hit == A.root) {  // leaves the scene (:728-744)
                             pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
                             travelled += t0;
@@ -575,13 +602,17 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                             t_sel = PVT_REC_EXIT; t_node = hit; t_normal = true;
                         } else {
                             // ---- volume absorption (:746-760) ----------------
-                            const int cbase = T.iv(O.comp_start + container);
-                            const int ccount = T.iv(O.comp_count + container);
-                            double alpha = 0.0;
+                            const int cbase = T.iv(container * NI + NI_CSTART);
+                            const int ccount = T.iv(container * NI + NI_CCOUNT);
+                            // alpha = sum of the components' coefficients; the running partial
+                            // sums ARE the cumulative thresholds the reference recomputes when it
+                            // picks the absorbing component (:768-781), so keep the first four
+                            double alpha = 0.0, pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0;
                             for (int k = 0; k < ccount; k++) {
-                                int c = cbase + k;
-                                int s = T.iv(O.abs_start + c);
-                                alpha += interp_clamped(T, wl, O.abs_x + s, O.abs_y + s, T.iv(O.abs_n + c));
+                                const int ci = L.comp_i + (cbase + k) * CI;
+                                alpha += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N));
+                                if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
+                                else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
                             }
                             double depth = INFINITY;
                             if (alpha > kAlphaZero) depth = -pvt_log(1.0 - rng_uniform(rng)) / alpha;
@@ -590,26 +621,35 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                 pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
                                 travelled += depth;
                                 duration += depth * n_container / kCcm;
-                                double target = rng_uniform(rng) * alpha, running = 0.0;
+                                const double target = rng_uniform(rng) * alpha;
                                 int comp = cbase;
-                                for (int k = 0; k < ccount; k++) {
-                                    int c = cbase + k;
-                                    int s = T.iv(O.abs_start + c);
-                                    running += interp_clamped(T, wl, O.abs_x + s, O.abs_y + s, T.iv(O.abs_n + c));
-                                    if (target <= running) { comp = c; break; }
+                                if (ccount <= 4) {
+                                    if (target <= pre0) comp = cbase;
+                                    else if (ccount > 1 && target <= pre1) comp = cbase + 1;
+                                    else if (ccount > 2 && target <= pre2) comp = cbase + 2;
+                                    else if (ccount > 3 && target <= pre3) comp = cbase + 3;
+                                } else {
+                                    double running = 0.0;
+                                    for (int k = 0; k < ccount; k++) {
+                                        const int ci = L.comp_i + (cbase + k) * CI;
+                                        running += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N));
+                                        if (target <= running) { comp = cbase + k; break; }
+                                    }
                                 }
                                 log_row<RECORD>(A, base, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
                                                 dir, false, pos, wl, travelled, duration);
-                                const int ctype = T.iv(O.comp_type + comp);
+                                const int ctype = T.iv(L.comp_i + comp * CI + CI_TYPE);
                                 ev_component = comp;
                                 bool radiative = false;
                                 if (ctype == PVT_COMP_SCATTERER || ctype == PVT_COMP_LUMINOPHORE)
-                                    radiative = rng_uniform(rng) < T.dv(O.comp_qy + comp);
+                                    radiative = rng_uniform(rng) < T.dv(L.comp_d + comp * CD + CD_QY);
                                 if (radiative) {
-                                    dir = sample_phase(T.iv(O.comp_phase_type + comp), T.dv(O.comp_phase_param + comp), rng);
+                                    if (ABL(3)) { double a_ = rng_uniform(rng), b_ = rng_uniform(rng); double c_ = 2.0 * a_ - 1.0; double s_ = pvt_sqrt(1.0 - c_ * c_); dir = V3{s_ * (2.0 * b_ - 1.0), s_ * pvt_sqrt(1.0 - (2.0 * b_ - 1.0) * (2.0 * b_ - 1.0)), c_}; }
+                                    else dir = sample_phase(T.iv(L.comp_i + comp * CI + CI_PHASE), T.dv(L.comp_d + comp * CD + CD_PHASE), rng);
                                     source = comp;
                                     if (ctype == PVT_COMP_LUMINOPHORE) {
-                                        const int es = T.iv(O.ems_start + comp), en = T.iv(O.ems_n + comp);
+                                        const int ci = L.comp_i + comp * CI;
+                                        const int ex = T.iv(ci + CI_EMS_X), ec = T.iv(ci + CI_EMS_CDF), en = T.iv(ci + CI_EMS_N);
                                         double p1;
                                         if (A.emit_method == PVT_EMIT_FULL) {
                                             p1 = 0.0;
@@ -620,18 +660,18 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                                 double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
                                                 e_nm = 1240.0 / e_ev;
                                             }
-                                            p1 = interp_clamped(T, e_nm, O.ems_x + es, O.ems_cdf + es, en);
+                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en);
                                         }
                                         double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
-                                        wl = interp_clamped(T, gamma, O.ems_cdf + es, O.ems_x + es, en);
-                                        double tau = T.dv(O.comp_tau_rad + comp);
+                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en);
+                                        double tau = T.dv(L.comp_d + comp * CD + CD_TAU_RAD);
                                         if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
                                         ev_kind = PVT_EV_EMIT;
                                     } else {
                                         ev_kind = PVT_EV_SCATTER;
                                     }
                                 } else {
-                                    double tau = T.dv(O.comp_tau_nr + comp);
+                                    double tau = T.dv(L.comp_d + comp * CD + CD_TAU_NR);
                                     if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
                                     if (ctype == PVT_COMP_REACTOR) { ev_kind = PVT_EV_REACT; t_sel = PVT_REC_REACTED; }
                                     else { ev_kind = PVT_EV_NONRADIATIVE; t_sel = PVT_REC_LOST; }
@@ -663,13 +703,13 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         const bool need_frame = alive && (t_normal || (t_sel >= 0 && t_node >= 0));
         V3 nloc{0, 0, 0};
         if (need_frame) {
-            const int m = O.w2l + t_node * 12;
+            const int m = t_node * ND + ND_W2L;
             lpos.x = T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(m + 3);
             lpos.y = T.dv(m + 4) * pos.x + T.dv(m + 5) * pos.y + T.dv(m + 6) * pos.z + T.dv(m + 7);
             lpos.z = T.dv(m + 8) * pos.x + T.dv(m + 9) * pos.y + T.dv(m + 10) * pos.z + T.dv(m + 11);
             if (t_normal) {  // outward normal (_kernel.pyx:359-400)
-                const int gp = O.geom_params + t_node * 4;
-                const int gt = T.iv(O.geom_type + t_node);
+                const int gp = t_node * ND + ND_PARAMS;
+                const int gt = T.iv(t_node * NI + NI_GEOM);
                 if (gt == PVT_GEOM_BOX) {
                     double best = INFINITY;
                     int baxis = 0;
@@ -699,7 +739,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         nloc = V3{lpos.x / r, lpos.y / r, 0.0};
                     }
                 }
-                const int q = O.l2w + t_node * 9;
+                const int q = t_node * ND + ND_L2W;
                 nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
                 nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
                 nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
@@ -720,30 +760,30 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
                 const double angle = pvt_acos(ddot);
                 t_angle = angle;
-                const bool fres = T.iv(O.surf_type + hit) == PVT_SURF_FRESNEL;
+                const bool fres = T.iv(hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
                 double r = 0.0, n1 = 0.0, n2 = 0.0;
                 if (fres) {
-                    n1 = T.dv(O.nidx + container);
-                    n2 = T.dv(O.nidx + adjacent);
-                    r = fresnel_reflectivity(angle, n1, n2);
+                    n1 = T.dv(container * ND + ND_N);
+                    n2 = T.dv(adjacent * ND + ND_N);
+                    r = ABL(1) ? (n2 < n1 && angle > 0.7297 ? 1.0 : 0.04) : fresnel_reflectivity(angle, n1, n2);
                 }
                 int coat = -1;
-                if constexpr (COATED) {
+                if (coated) {
                     if (fres) {
-                        const int cs = T.iv(O.coat_start + hit), ce = cs + T.iv(O.coat_count + hit);
+                        const int cs = T.iv(hit * NI + NI_KSTART), ce = cs + T.iv(hit * NI + NI_KCOUNT);
                         const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
                         for (int c = cs; c < ce && coat < 0; c++) {
                             bool ok = true;
 #pragma unroll
                             for (int a = 0; a < 3; a++) {
-                                double f = T.dv(O.coat_facet + c * 3 + a);
+                                double f = T.dv(L.coat_d + c * KD + KD_FACET + a);
                                 if (pvt_fabs(nl3[a] - f) > 1e-8 + 1e-5 * pvt_fabs(f)) ok = false;
-                                if (!(pl3[a] > T.dv(O.coat_lo + c * 3 + a) && pl3[a] < T.dv(O.coat_hi + c * 3 + a))) ok = false;
+                                if (!(pl3[a] > T.dv(L.coat_d + c * KD + KD_LO + a) && pl3[a] < T.dv(L.coat_d + c * KD + KD_HI + a))) ok = false;
                             }
                             if (ok) coat = c;
                         }
                         if (coat >= 0) {
-                            double cr = T.dv(O.coat_refl + coat);
+                            double cr = T.dv(L.coat_d + coat * KD + KD_REFL);
                             if (cr >= 0.0) r = cr;
                         }
                     }
@@ -752,7 +792,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 if (r > 0.0) u = rng_uniform(rng);
                 if (u < r) {
                     bool lamb = false;
-                    if constexpr (COATED) lamb = (coat >= 0 && T.iv(O.coat_rmode + coat) == 1);
+                    if (coat >= 0) lamb = T.iv(L.coat_i + coat * KI + KI_RMODE) == 1;
                     if (lamb) {
                         // cosine-weighted about the incoming side's normal, in the node frame
                         double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
@@ -766,7 +806,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         V3 t2v{b, sign + mm.y * mm.y * a, -mm.y};
                         V3 dl{s.x * t1v.x + s.y * t2v.x + s.z * mm.x, s.x * t1v.y + s.y * t2v.y + s.z * mm.y,
                               s.x * t1v.z + s.y * t2v.z + s.z * mm.z};
-                        const int q = O.l2w + hit * 9;
+                        const int q = hit * ND + ND_L2W;
                         dir.x = T.dv(q + 0) * dl.x + T.dv(q + 1) * dl.y + T.dv(q + 2) * dl.z;
                         dir.y = T.dv(q + 3) * dl.x + T.dv(q + 4) * dl.y + T.dv(q + 5) * dl.z;
                         dir.z = T.dv(q + 6) * dl.x + T.dv(q + 7) * dl.y + T.dv(q + 8) * dl.z;
@@ -778,7 +818,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     t_sel = (container != hit) ? PVT_REC_REFLECTED : -1;
                 } else {
                     bool matched = false;
-                    if constexpr (COATED) matched = (coat >= 0 && T.iv(O.coat_tmode + coat) == 1);
+                    if (coat >= 0) matched = T.iv(L.coat_i + coat * KI + KI_TMODE) == 1;
                     if (fres && !matched) {  // Snell, vector form (:436-446)
                         double n = n1 / n2;
                         double dd = dot3(dir, nf);
@@ -798,57 +838,72 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             log_row<RECORD>(A, base, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
                             dir, ev_normal, nrm, wl, travelled, duration);
 
-        if (A.n_rec > 0 && __ballot(alive && t_sel >= 0) != 0ull) {
-            const bool want = alive && t_sel >= 0;
-#pragma unroll
-            for (int w = 0; w < SEENW; w++) {
-                const int rlo = w * 64;
-                const int rhi = (A.n_rec - rlo) < 64 ? (A.n_rec - rlo) : 64;
-                for (int b = 0; b < rhi; b++) {
-                    const int r = rlo + b;
-                    bool match = want && T.iu(O.rec_node + r) == t_node && T.iu(O.rec_event + r) == t_sel;
-                    if (match && T.iu(O.rec_has_facet + r) != 0) {
-                        const double atol = T.du(O.rec_atol + r);
+        // Lane-parallel tally.  Each lane walks the (host-precomputed) list of recorders that
+        // can fire for ITS (node, selector) — different lanes handle different recorders in
+        // the same trip — reading the recorder rows from LDS with per-lane addresses and
+        // adding into the workgroup accumulators with per-lane LDS atomics (hardware
+        // serialises same-address lanes; no wave-uniform recorder loop, no scalar-load
+        // chains, no software scan).  Recorder order per lane is ascending, as in the
+        // reference's loop (_kernel.pyx:517-556).
+        if (!ABL(0) && A.n_rec > 0) {
+            int cs = 0, cn = 0;
+            if (alive && t_sel >= 0) {
+                const int key = L.cand_i + (t_node * 7 + t_sel) * 2;
+                cs = T.iv(key);
+                cn = T.iv(key + 1);
+            }
+            for (int j = 0; __ballot(j < cn) != 0ull; j++) {
+                if (j < cn) {
+                    const int r = T.iv(L.cand_list + cs + j);
+                    const int ri = L.rec_i + r * RI;
+                    bool match = true;
+                    if (T.iv(ri + RI_HAS_FACET) != 0) {
+                        const int rd = L.rec_d + r * RD;
+                        const double atol = T.dv(rd + RD_ATOL);
                         if (!t_normal) match = false;
-                        else if (pvt_fabs(T.du(O.rec_facet + r * 3) - nrm.x) > atol) match = false;
-                        else if (pvt_fabs(T.du(O.rec_facet + r * 3 + 1) - nrm.y) > atol) match = false;
-                        else if (pvt_fabs(T.du(O.rec_facet + r * 3 + 2) - nrm.z) > atol) match = false;
+                        else if (pvt_fabs(T.dv(rd + RD_FACET) - nrm.x) > atol) match = false;
+                        else if (pvt_fabs(T.dv(rd + RD_FACET + 1) - nrm.y) > atol) match = false;
+                        else if (pvt_fabs(T.dv(rd + RD_FACET + 2) - nrm.z) > atol) match = false;
                     }
                     if (match) {
                         atomicAdd(&acc_cross[r], 1u);
-                        const unsigned long long bit = 1ull << b;
-                        if (!(seen.w[w] & bit)) {
-                            seen.w[w] |= bit;
+                        const unsigned long long bit = 1ull << (r & 63);
+                        bool first;
+                        if constexpr (SEENW == 1) {
+                            first = !(seen.w[0] & bit);
+                            seen.w[0] |= bit;
+                        } else {
+                            const int w = r >> 6;
+                            const unsigned long long cur = w == 0 ? seen.w[0] : w == 1 ? seen.w[1] : w == 2 ? seen.w[2] : seen.w[3];
+                            first = !(cur & bit);
+                            if (w == 0) seen.w[0] |= bit; else if (w == 1) seen.w[1] |= bit;
+                            else if (w == 2) seen.w[2] |= bit; else seen.w[3] |= bit;
+                        }
+                        if (first) {
                             atomicAdd(&acc_distinct[r], 1u);
-                            double* s = acc_sums + r * 8;
-                            atomicAdd(&s[0], wl); atomicAdd(&s[1], wl * wl);
-                            atomicAdd(&s[2], t_angle); atomicAdd(&s[3], t_angle * t_angle);
-                            atomicAdd(&s[4], duration); atomicAdd(&s[5], duration * duration);
-                            atomicAdd(&s[6], travelled); atomicAdd(&s[7], travelled * travelled);
-                            const int h0 = T.iu(O.rec_hist_start + r), h1 = h0 + T.iu(O.rec_hist_n + r);
+                            double* sp = acc_sums + r * 8;
+                            atomicAdd(&sp[0], wl); atomicAdd(&sp[1], wl * wl);
+                            atomicAdd(&sp[2], t_angle); atomicAdd(&sp[3], t_angle * t_angle);
+                            atomicAdd(&sp[4], duration); atomicAdd(&sp[5], duration * duration);
+                            atomicAdd(&sp[6], travelled); atomicAdd(&sp[7], travelled * travelled);
+                            const int h0 = T.iv(ri + RI_HSTART), h1 = h0 + T.iv(ri + RI_HN);
                             for (int h = h0; h < h1; h++) {
-                                const int pa = T.iu(O.h_prop_a + h), pb = T.iu(O.h_prop_b + h);
-                                const int na = T.iu(O.h_na + h), nb = T.iu(O.h_nb + h);
-                                auto prop = [&](int p) -> double {
-                                    switch (p) {
-                                        case 0: return wl;
-                                        case 1: return t_angle;
-                                        case 2: return duration;
-                                        case 3: return travelled;
-                                        case 4: return lpos.x;
-                                        case 5: return lpos.y;
-                                        default: return lpos.z;
-                                    }
+                                const int hi_ = L.hist_i + h * HI, hd_ = L.hist_d + h * HD;
+                                const int pa = T.iv(hi_ + HI_PA), pb = T.iv(hi_ + HI_PB);
+                                const int na = T.iv(hi_ + HI_NA), nb = T.iv(hi_ + HI_NB);
+                                auto prop = [&](int pr) -> double {
+                                    return pr == 0 ? wl : pr == 1 ? t_angle : pr == 2 ? duration : pr == 3 ? travelled
+                                         : pr == 4 ? lpos.x : pr == 5 ? lpos.y : lpos.z;
                                 };
-                                double la = T.du(O.h_lo_a + h), ha = T.du(O.h_hi_a + h);
-                                int ia = (int)((prop(pa) - la) / (ha - la) * na);
+                                const double la = T.dv(hd_ + HD_LO_A), ha = T.dv(hd_ + HD_HI_A);
+                                const int ia = (int)((prop(pa) - la) / (ha - la) * na);
                                 if (ia < 0 || ia >= na) continue;
-                                int slot = T.iu(O.h_offset + h) + ia;
+                                int slot = T.iv(hi_ + HI_OFF) + ia;
                                 if (pb >= 0) {
-                                    double lb = T.du(O.h_lo_b + h), hb = T.du(O.h_hi_b + h);
-                                    int ib = (int)((prop(pb) - lb) / (hb - lb) * nb);
+                                    const double lb = T.dv(hd_ + HD_LO_B), hb = T.dv(hd_ + HD_HI_B);
+                                    const int ib = (int)((prop(pb) - lb) / (hb - lb) * nb);
                                     if (ib < 0 || ib >= nb) continue;
-                                    slot = T.iu(O.h_offset + h) + ia * nb + ib;
+                                    slot = T.iv(hi_ + HI_OFF) + ia * nb + ib;
                                 }
                                 if (A.bins_in_lds) atomicAdd(&acc_bins[slot], 1u);
                                 else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + slot, 1ull);
@@ -910,7 +965,7 @@ int push(std::vector<T>& blob, const T* src, size_t n) {
 
 struct PvtScene {
     int device = 0;
-    Off off{};
+    Lay lay{};
     EmitOff eoff{};
     int nd = 0, ni = 0;
     int n_nodes = 0, root = 0, n_rec = 0, total_bins = 0, n_coat = 0, n_lights = 0;
@@ -944,71 +999,100 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipSetDevice(device));
 
     const int N = t->n_nodes, C = t->n_components, R = t->n_recorders, H = t->n_hists, K = t->n_coatings;
-    std::vector<double> gd;
-    std::vector<int> gi;
-    Off o{};
-    o.geom_params = push(gd, t->geom_params, (size_t)N * 4);
-    // rigid transforms: keep the 3x4 of world_to_local and the 3x3 of local_to_world
-    o.w2l = (int)gd.size();
-    for (int n = 0; n < N; n++)
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 4; c++) gd.push_back(t->world_to_local[n * 16 + r * 4 + c]);
-    o.l2w = (int)gd.size();
-    for (int n = 0; n < N; n++)
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) gd.push_back(t->local_to_world[n * 16 + r * 4 + c]);
-    o.nidx = push(gd, t->refractive_index, N);
-    o.comp_qy = push(gd, t->comp_qy, C);
-    o.comp_tau_rad = push(gd, t->comp_tau_rad, C);
-    o.comp_tau_nr = push(gd, t->comp_tau_nr, C);
-    o.comp_phase_param = push(gd, t->comp_phase_param, C);
-    o.abs_x = push(gd, t->abs_x, t->n_abs);
-    o.abs_y = push(gd, t->abs_y, t->n_abs);
-    o.ems_x = push(gd, t->ems_x, t->n_ems);
-    o.ems_cdf = push(gd, t->ems_cdf, t->n_ems);
-    o.rec_facet = push(gd, t->rec_facet, (size_t)R * 3);
-    o.rec_atol = push(gd, t->rec_atol, R);
-    o.h_lo_a = push(gd, t->hist_lo_a, H);
-    o.h_hi_a = push(gd, t->hist_hi_a, H);
-    o.h_lo_b = push(gd, t->hist_lo_b, H);
-    o.h_hi_b = push(gd, t->hist_hi_b, H);
-    o.coat_facet = push(gd, t->coat_facet, (size_t)K * 3);
-    o.coat_lo = push(gd, t->coat_lo, (size_t)K * 3);
-    o.coat_hi = push(gd, t->coat_hi, (size_t)K * 3);
-    o.coat_refl = push(gd, t->coat_reflectivity, K);
-
-    o.geom_type = push(gi, t->geom_type, N);
-    o.surf_type = push(gi, t->surface_type, N);
-    o.comp_start = push(gi, t->comp_start, N);
-    o.comp_count = push(gi, t->comp_count, N);
-    if (K > 0) {
-        o.coat_start = push(gi, t->coat_start, N);
-        o.coat_count = push(gi, t->coat_count, N);
+    // fixed-stride records, then the pooled spectra (see the enums next to struct Lay)
+    Lay lay{};
+    lay.comp_d = N * ND;
+    lay.rec_d = lay.comp_d + C * CD;
+    lay.hist_d = lay.rec_d + R * RD;
+    lay.coat_d = lay.hist_d + H * HD;
+    const int spec_d = lay.coat_d + K * KD;
+    const int abs_x0 = spec_d, abs_y0 = abs_x0 + t->n_abs, ems_x0 = abs_y0 + t->n_abs, ems_c0 = ems_x0 + t->n_ems;
+    std::vector<double> gd((size_t)ems_c0 + t->n_ems + 1, 0.0);
+    lay.comp_i = N * NI;
+    lay.rec_i = lay.comp_i + C * CI;
+    lay.hist_i = lay.rec_i + R * RI;
+    lay.coat_i = lay.hist_i + H * HI;
+    lay.cand_i = lay.coat_i + K * KI;
+    lay.cand_list = lay.cand_i + N * 7 * 2;
+    std::vector<int> gi((size_t)lay.cand_list + R + 1, 0);
+    {   // recorders grouped by the (node, selector) they listen to, ascending id within a group
+        int at = 0;
+        for (int key = 0; key < N * 7; key++) {
+            gi[lay.cand_i + key * 2] = at;
+            for (int r = 0; r < R; r++)
+                if (t->rec_node[r] * 7 + t->rec_event[r] == key) gi[lay.cand_list + at++] = r;
+            gi[lay.cand_i + key * 2 + 1] = at - gi[lay.cand_i + key * 2];
+        }
     }
-    o.comp_type = push(gi, t->comp_type, C);
-    o.comp_phase_type = push(gi, t->comp_phase_type, C);
-    o.abs_start = push(gi, t->comp_abs_start, C);
-    o.abs_n = push(gi, t->comp_abs_n, C);
-    o.ems_start = push(gi, t->comp_ems_start, C);
-    o.ems_n = push(gi, t->comp_ems_n, C);
-    o.rec_node = push(gi, t->rec_node, R);
-    o.rec_event = push(gi, t->rec_event, R);
-    o.rec_has_facet = push(gi, t->rec_has_facet, R);
-    o.rec_hist_start = push(gi, t->rec_hist_start, R);
-    o.rec_hist_n = push(gi, t->rec_hist_n, R);
-    o.h_prop_a = push(gi, t->hist_prop_a, H);
-    o.h_prop_b = push(gi, t->hist_prop_b, H);
-    o.h_na = push(gi, t->hist_na, H);
-    o.h_nb = push(gi, t->hist_nb, H);
-    o.h_offset = push(gi, t->hist_offset, H);
-    o.coat_rmode = push(gi, t->coat_reflect_mode, K);
-    o.coat_tmode = push(gi, t->coat_transmit_mode, K);
-    gd.push_back(0.0);  // never zero-sized
-    gi.push_back(0);
+    for (int n = 0; n < N; n++) {
+        double* d = gd.data() + n * ND;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) d[ND_W2L + r * 4 + c] = t->world_to_local[n * 16 + r * 4 + c];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) d[ND_L2W + r * 3 + c] = t->local_to_world[n * 16 + r * 4 + c];
+        for (int c = 0; c < 4; c++) d[ND_PARAMS + c] = t->geom_params[n * 4 + c];
+        d[ND_N] = t->refractive_index[n];
+        int* q = gi.data() + n * NI;
+        q[NI_GEOM] = t->geom_type[n];
+        q[NI_SURF] = t->surface_type[n];
+        q[NI_CSTART] = t->comp_start[n];
+        q[NI_CCOUNT] = t->comp_count[n];
+        q[NI_KSTART] = K > 0 ? t->coat_start[n] : 0;
+        q[NI_KCOUNT] = K > 0 ? t->coat_count[n] : 0;
+    }
+    for (int c = 0; c < C; c++) {
+        double* d = gd.data() + lay.comp_d + c * CD;
+        d[CD_QY] = t->comp_qy[c];
+        d[CD_TAU_RAD] = t->comp_tau_rad[c];
+        d[CD_TAU_NR] = t->comp_tau_nr[c];
+        d[CD_PHASE] = t->comp_phase_param[c];
+        int* q = gi.data() + lay.comp_i + c * CI;
+        q[CI_TYPE] = t->comp_type[c];
+        q[CI_PHASE] = t->comp_phase_type[c];
+        q[CI_ABS_X] = abs_x0 + t->comp_abs_start[c];   // absolute offsets into the double blob
+        q[CI_ABS_Y] = abs_y0 + t->comp_abs_start[c];
+        q[CI_ABS_N] = t->comp_abs_n[c];
+        q[CI_EMS_X] = ems_x0 + t->comp_ems_start[c];
+        q[CI_EMS_CDF] = ems_c0 + t->comp_ems_start[c];
+        q[CI_EMS_N] = t->comp_ems_n[c];
+    }
+    for (int r = 0; r < R; r++) {
+        double* d = gd.data() + lay.rec_d + r * RD;
+        for (int a = 0; a < 3; a++) d[RD_FACET + a] = t->rec_facet[r * 3 + a];
+        d[RD_ATOL] = t->rec_atol[r];
+        int* q = gi.data() + lay.rec_i + r * RI;
+        q[RI_NODE] = t->rec_node[r];
+        q[RI_EVENT] = t->rec_event[r];
+        q[RI_HAS_FACET] = t->rec_has_facet[r];
+        q[RI_HSTART] = t->rec_hist_start[r];
+        q[RI_HN] = t->rec_hist_n[r];
+    }
+    for (int h = 0; h < H; h++) {
+        double* d = gd.data() + lay.hist_d + h * HD;
+        d[HD_LO_A] = t->hist_lo_a[h]; d[HD_HI_A] = t->hist_hi_a[h];
+        d[HD_LO_B] = t->hist_lo_b[h]; d[HD_HI_B] = t->hist_hi_b[h];
+        int* q = gi.data() + lay.hist_i + h * HI;
+        q[HI_PA] = t->hist_prop_a[h]; q[HI_PB] = t->hist_prop_b[h];
+        q[HI_NA] = t->hist_na[h]; q[HI_NB] = t->hist_nb[h]; q[HI_OFF] = t->hist_offset[h];
+    }
+    for (int k = 0; k < K; k++) {
+        double* d = gd.data() + lay.coat_d + k * KD;
+        for (int a = 0; a < 3; a++) {
+            d[KD_FACET + a] = t->coat_facet[k * 3 + a];
+            d[KD_LO + a] = t->coat_lo[k * 3 + a];
+            d[KD_HI + a] = t->coat_hi[k * 3 + a];
+        }
+        d[KD_REFL] = t->coat_reflectivity[k];
+        int* q = gi.data() + lay.coat_i + k * KI;
+        q[KI_RMODE] = t->coat_reflect_mode[k];
+        q[KI_TMODE] = t->coat_transmit_mode[k];
+    }
+    for (int i = 0; i < t->n_abs; i++) { gd[abs_x0 + i] = t->abs_x[i]; gd[abs_y0 + i] = t->abs_y[i]; }
+    for (int i = 0; i < t->n_ems; i++) { gd[ems_x0 + i] = t->ems_x[i]; gd[ems_c0 + i] = t->ems_cdf[i]; }
 
     PvtScene* s = new PvtScene();
     s->device = device;
-    s->off = o;
+    s->lay = lay;
     s->nd = (int)gd.size();
     s->ni = (int)gi.size();
     s->n_nodes = N;
@@ -1078,7 +1162,7 @@ namespace {
 KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
     KArgs a{};
     a.gd = s->d_gd; a.gi = s->d_gi; a.ed = s->d_ed; a.ei = s->d_ei;
-    a.off = s->off; a.eoff = s->eoff;
+    a.lay = s->lay; a.eoff = s->eoff;
     a.nd = s->nd; a.ni = s->ni;
     a.n_nodes = s->n_nodes; a.root = s->root; a.n_rec = s->n_rec; a.total_bins = s->total_bins;
     a.n_coat = s->n_coat; a.n_lights = s->n_lights;
@@ -1093,16 +1177,16 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
 }
 
 template <bool RECORD, bool TAB_LDS, int SEENW>
-hipError_t launch_variant(bool coated, int grid, size_t lds, hipStream_t st, const KArgs& a) {
-    if (coated) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
+hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
+    if (emit) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
     else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
     return hipGetLastError();
 }
 
 template <bool RECORD, bool TAB_LDS>
-hipError_t launch_seen(int n_rec, bool coated, int grid, size_t lds, hipStream_t st, const KArgs& a) {
-    if (n_rec <= 64) return launch_variant<RECORD, TAB_LDS, 1>(coated, grid, lds, st, a);
-    return launch_variant<RECORD, TAB_LDS, 4>(coated, grid, lds, st, a);
+hipError_t launch_seen(int n_rec, bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
+    if (n_rec <= 64) return launch_variant<RECORD, TAB_LDS, 1>(emit, grid, lds, st, a);
+    return launch_variant<RECORD, TAB_LDS, 4>(emit, grid, lds, st, a);
 }
 
 }  // namespace
@@ -1163,20 +1247,22 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     // persistent grid: enough workgroups to fill every CU a few times over,
     // never more than the rays can feed
     long long blocks_for_rays = (p->n_rays + kBlock - 1) / kBlock;
-    long long grid = (long long)s->num_cu * 4;
+    double per_cu = 4.0;
+    if (const char* env = getenv("PVT_BLOCKS_PER_CU")) per_cu = atof(env) > 0 ? atof(env) : per_cu;
+    long long grid = (long long)((double)s->num_cu * per_cu);
     if (grid > blocks_for_rays) grid = blocks_for_rays;
     if (grid < 1) grid = 1;
     s->last_grid = (int)grid;
     s->last_lds = (int)lds;
 
-    const bool coated = s->n_coat > 0;
+    const bool emit = rays == nullptr;
     hipError_t e;
     if (record) {
-        e = tab_lds ? launch_seen<true, true>(s->n_rec, coated, (int)grid, lds, st, a)
-                    : launch_seen<true, false>(s->n_rec, coated, (int)grid, lds, st, a);
+        e = tab_lds ? launch_seen<true, true>(s->n_rec, emit, (int)grid, lds, st, a)
+                    : launch_seen<true, false>(s->n_rec, emit, (int)grid, lds, st, a);
     } else {
-        e = tab_lds ? launch_seen<false, true>(s->n_rec, coated, (int)grid, lds, st, a)
-                    : launch_seen<false, false>(s->n_rec, coated, (int)grid, lds, st, a);
+        e = tab_lds ? launch_seen<false, true>(s->n_rec, emit, (int)grid, lds, st, a)
+                    : launch_seen<false, false>(s->n_rec, emit, (int)grid, lds, st, a);
     }
     if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
     return PVT_OK;

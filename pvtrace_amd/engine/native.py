@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpvtrace_hip.so")
+LIB_PATH = os.environ.get(  # PVT_LIB: developer override (ablation builds); never a CPU path
+    "PVT_LIB", os.path.join(os.path.dirname(_HERE), "csrc", "libpvtrace_hip.so"))
 
 _p_i32 = C.POINTER(C.c_int32)
 _p_f64 = C.POINTER(C.c_double)
