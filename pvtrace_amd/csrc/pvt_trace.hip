@@ -41,12 +41,19 @@
 #ifndef PVT_ABLATE
 #define PVT_ABLATE 0
 #endif
+#ifndef PVT_STATS
+#define PVT_STATS 0
+#endif
 #define ABL(bit) ((PVT_ABLATE >> (bit)) & 1)   // 0 tally, 1 fresnel, 2 emission wl, 3 phase, 4 interp, 5 refill rng
 
 namespace {
 
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
+constexpr int kWaves = kBlock / 64;
+constexpr int kXSlots = 128;         // LDS photon-state slots used to repack a draining workgroup
+// workgroup control words in LDS
+enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_WORDS = 16 };
 constexpr double kEps = 2.220446049250313e-13;       // _kernel.pyx:29
 constexpr double kAlphaZero = 1e-8;                  // :32
 constexpr double kCcm = 2.99792458e10;               // :33
@@ -58,8 +65,9 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
 enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND = 26 };           // node doubles
 enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI };  // node ints
-enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD };                         // component doubles
-enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N, CI };
+enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C, CD };                         // component doubles
+enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N,
+       CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI };  // *_G*: guide tables (bucket -> bracketing index)
 enum { RD_FACET = 0, RD_ATOL = 3, RD = 4 };                                     // recorder
 enum { RI_NODE = 0, RI_EVENT, RI_HAS_FACET, RI_HSTART, RI_HN, RI };
 enum { HD_LO_A = 0, HD_HI_A, HD_LO_B, HD_HI_B, HD };                             // histogram
@@ -94,7 +102,7 @@ struct KArgs {
     const double* dir;
     const double* wl;
     unsigned int n_rays;
-    unsigned int* cursor;
+    unsigned int* cursor;   // [0] ray cursor; (PVT_STATS builds) [2..] u64 counters
     unsigned long long seed;       // + ray_offset folded in by the host
     unsigned long long emit_seed;  // + nothing; global index added per ray
     unsigned long long ray_offset;
@@ -107,6 +115,7 @@ struct KArgs {
     long long* rec_bins;
     PvtEventLog log;
     int bins_in_lds;
+    int xslots;   // photon-state slots in LDS for drain-phase consolidation (0 = off)
 };
 
 // ------------------------------------------------------------------ RNG
@@ -168,14 +177,26 @@ struct V3 {
 };
 __device__ __forceinline__ double dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// np.interp-like clamped interpolation, binary search `xs[mid] <= x` (_kernel.pyx:219-238)
+// np.interp-like clamped interpolation (_kernel.pyx:219-238).  The reference bisects the
+// whole table for `lo` = the largest index with xs[lo] <= x; that index is unique, so any
+// search that finds it gives identical results.  Here a host-built guide table (n buckets of
+// equal width over [xs[0], xs[n-1]], entry b = largest i with xs[i] <= left edge of bucket b)
+// brackets the answer to a bucket first, the bracket is VALIDATED against the table (falls
+// back to the full range if rounding put x in a neighbouring bucket), and the same bisection
+// runs inside the bracket: typically 0-1 steps instead of ~log2(n) dependent LDS reads.
 template <bool TAB_LDS>
-__device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n) {
+__device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n,
+                                                 int guide, double scale) {
     if (n == 1) return T.dv(ys);
-    double x0 = T.dv(xs), xl = T.dv(xs + n - 1);
+    const double x0 = T.dv(xs), xl = T.dv(xs + n - 1);
     if (x <= x0) return T.dv(ys);
     if (x >= xl) return T.dv(ys + n - 1);
-    int lo = 0, hi = n - 1;
+    int b = (int)((x - x0) * scale);
+    b = b < 0 ? 0 : (b > n - 2 ? n - 2 : b);
+    int lo = T.iv(guide + b), hi = T.iv(guide + b + 1) + 1;
+    if (hi > n - 1) hi = n - 1;
+    if (!(T.dv(xs + lo) <= x)) lo = 0;
+    if (!(x < T.dv(xs + hi))) hi = n - 1;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (T.dv(xs + mid) <= x) lo = mid; else hi = mid;
@@ -386,6 +407,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     unsigned int* acc_cross = reinterpret_cast<unsigned int*>(acc_sums + A.n_rec * 8);
     unsigned int* acc_distinct = acc_cross + A.n_rec;
     unsigned int* acc_bins = acc_distinct + A.n_rec;
+    constexpr int XW = 14 + SEENW + (RECORD ? 3 : 0);  // u64 words of one photon's state
+    int* ctl = reinterpret_cast<int*>(acc_bins + ((A.bins_in_lds ? A.total_bins : 0) + 1 & ~1));
+    unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [XW][xslots]
+    if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
     if constexpr (TAB_LDS) {
         for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
         for (int i = threadIdx.x; i < A.ni; i += kBlock) lds_i[i] = A.gi[i];
@@ -413,9 +438,16 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
 #pragma unroll
     for (int w = 0; w < SEENW; w++) seen.w[w] = 0ull;
 
+#if PVT_STATS
+    unsigned long long st_iters = 0, st_lane_steps = 0, st_drain_iters = 0, st_drain_lane_steps = 0;
+#endif
     // wave-uniform ray window claimed from the global cursor
     unsigned int w_next = 0, w_end = 0;
     bool exhausted = false;
+    // drain-phase consolidation state (all wave-uniform)
+    const int wave = threadIdx.x >> 6;
+    bool counted = false, in_regime = false, solo = false;
+    int members = 0, parity = 0;
 
     for (;;) {
         // ================= refill dead lanes ==============================
@@ -464,7 +496,106 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             w_next += (want < avail) ? want : avail;
             need = __ballot(!alive);
         }
-        if (__ballot(alive) == 0ull) break;  // wave drained and cursor exhausted
+        // ================= drain: repack the workgroup's survivors ==========
+        // Once the ray cursor is dry a wave can only lose lanes; with 4 waves per workgroup
+        // each at a handful of live lanes, most issue slots would be spent on idle lanes
+        // (measured: 55 % of all wave-iterations of a 10^6-photon launch ran at 11 live lanes).
+        // So when ALL waves of the workgroup are draining they rendezvous each iteration
+        // (s_barrier), publish their live counts, and as soon as the survivors fit into fewer
+        // waves every live photon's state is moved through LDS into the lowest waves and the
+        // emptied waves retire.  Which lane carries a photon never affects its history (RNG
+        // stream, seen-mask and log rows travel with it), so results stay bit-identical.
+        if (exhausted && !counted) {
+            counted = true;
+            if (lane == 0) atomicAdd(&ctl[CTL_EXHAUSTED], 1);
+        }
+        if (!in_regime) {
+            if (__ballot(alive) == 0ull) break;  // wave drained and cursor exhausted
+            if (A.xslots > 0 && exhausted && !solo &&
+                __hip_atomic_load(&ctl[CTL_EXHAUSTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kWaves) {
+                in_regime = true;
+                if (lane == 0) ctl[CTL_IN + wave] = 1;
+                __syncthreads();  // R0: everybody still running is now in lock-step
+                members = (ctl[CTL_IN] ? 1 : 0) | (ctl[CTL_IN + 1] ? 2 : 0) | (ctl[CTL_IN + 2] ? 4 : 0) |
+                          (ctl[CTL_IN + 3] ? 8 : 0);
+            }
+        }
+        if (in_regime) {
+            const unsigned long long live_mask = __ballot(alive);
+            const int live = __popcll(live_mask);
+            int* live_tab = ctl + CTL_LIVE + parity * kWaves;  // double-buffered by iteration parity
+            parity ^= 1;
+            if (lane == 0) live_tab[wave] = live;
+            __syncthreads();  // A
+            int l[kWaves], total = 0, nw = 0, before = 0, pos_in_set = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) {
+                l[w] = ((members >> w) & 1) ? live_tab[w] : 0;
+                if (l[w] == 0) members &= ~(1 << w);  // that wave retires now (it sees its own 0)
+                else {
+                    if (w < wave) { before += l[w]; pos_in_set += 1; }
+                    total += l[w];
+                    nw += 1;
+                }
+            }
+            if (live == 0) break;
+            if (nw == 1) {
+                in_regime = false;
+                solo = true;  // last wave standing: no more rendezvous
+            } else if (total <= 64 * (nw - 1) && total <= A.xslots) {
+                const int X = A.xslots;
+                if (alive) {
+                    const int slot = before + (int)__popcll(live_mask & lane_lt);
+                    xbuf[0 * X + slot] = pvt_d2u(pos.x); xbuf[1 * X + slot] = pvt_d2u(pos.y); xbuf[2 * X + slot] = pvt_d2u(pos.z);
+                    xbuf[3 * X + slot] = pvt_d2u(dir.x); xbuf[4 * X + slot] = pvt_d2u(dir.y); xbuf[5 * X + slot] = pvt_d2u(dir.z);
+                    xbuf[6 * X + slot] = pvt_d2u(wl); xbuf[7 * X + slot] = pvt_d2u(travelled); xbuf[8 * X + slot] = pvt_d2u(duration);
+                    xbuf[9 * X + slot] = rng.s0; xbuf[10 * X + slot] = rng.s1; xbuf[11 * X + slot] = rng.s2; xbuf[12 * X + slot] = rng.s3;
+                    xbuf[13 * X + slot] = (unsigned long long)(unsigned int)count | ((unsigned long long)(unsigned int)source << 32);
+#pragma unroll
+                    for (int w = 0; w < SEENW; w++) xbuf[(14 + w) * X + slot] = seen.w[w];
+                    if constexpr (RECORD) {
+                        xbuf[(14 + SEENW) * X + slot] = (unsigned long long)base;
+                        xbuf[(15 + SEENW) * X + slot] = (unsigned long long)rec_slot;
+                        xbuf[(16 + SEENW) * X + slot] = (unsigned long long)(unsigned int)nev;
+                    }
+                }
+                __syncthreads();  // B
+                const int keep = (total + 63) >> 6;  // waves that stay, lowest ids of the set
+                if (pos_in_set >= keep) { alive = false; break; }
+                const int slot = pos_in_set * 64 + lane;
+                alive = slot < total;
+                if (alive) {
+                    pos = V3{pvt_u2d(xbuf[0 * X + slot]), pvt_u2d(xbuf[1 * X + slot]), pvt_u2d(xbuf[2 * X + slot])};
+                    dir = V3{pvt_u2d(xbuf[3 * X + slot]), pvt_u2d(xbuf[4 * X + slot]), pvt_u2d(xbuf[5 * X + slot])};
+                    wl = pvt_u2d(xbuf[6 * X + slot]); travelled = pvt_u2d(xbuf[7 * X + slot]); duration = pvt_u2d(xbuf[8 * X + slot]);
+                    rng.s0 = xbuf[9 * X + slot]; rng.s1 = xbuf[10 * X + slot]; rng.s2 = xbuf[11 * X + slot]; rng.s3 = xbuf[12 * X + slot];
+                    const unsigned long long cs_ = xbuf[13 * X + slot];
+                    count = (int)(unsigned int)cs_;
+                    source = (int)(unsigned int)(cs_ >> 32);
+#pragma unroll
+                    for (int w = 0; w < SEENW; w++) seen.w[w] = xbuf[(14 + w) * X + slot];
+                    if constexpr (RECORD) {
+                        base = (long long)xbuf[(14 + SEENW) * X + slot];
+                        rec_slot = (long long)xbuf[(15 + SEENW) * X + slot];
+                        nev = (int)(unsigned int)xbuf[(16 + SEENW) * X + slot];
+                    }
+                }
+                // the set shrinks to its `keep` lowest members
+                int kept = 0, m2 = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; w++)
+                    if (((members >> w) & 1) && kept < keep) { m2 |= 1 << w; kept += 1; }
+                members = m2;
+                if (keep == 1) { in_regime = false; solo = true; }
+            }
+        }
+#if PVT_STATS
+        {
+            unsigned long long live = __popcll(__ballot(alive));
+            st_iters += 1; st_lane_steps += live;
+            if (exhausted) { st_drain_iters += 1; st_drain_lane_steps += live; }
+        }
+#endif
 
         // ================= one step for every live lane ==================
         // deferred event of this step
@@ -610,7 +741,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                             double alpha = 0.0, pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0;
                             for (int k = 0; k < ccount; k++) {
                                 const int ci = L.comp_i + (cbase + k) * CI;
-                                alpha += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N));
+                                alpha += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
+                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE));
                                 if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
                                 else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
                             }
@@ -632,7 +764,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                     double running = 0.0;
                                     for (int k = 0; k < ccount; k++) {
                                         const int ci = L.comp_i + (cbase + k) * CI;
-                                        running += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N));
+                                        running += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
+                                                                  T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE));
                                         if (target <= running) { comp = cbase + k; break; }
                                     }
                                 }
@@ -660,10 +793,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                                 double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
                                                 e_nm = 1240.0 / e_ev;
                                             }
-                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en);
+                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_X));
                                         }
                                         double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
-                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en);
+                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_C));
                                         double tau = T.dv(L.comp_d + comp * CD + CD_TAU_RAD);
                                         if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
                                         ev_kind = PVT_EV_EMIT;
@@ -922,19 +1055,34 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         }
     }
 
-    // ---- flush workgroup accumulators -------------------------------------
-    __syncthreads();
-    for (int i = threadIdx.x; i < A.n_rec; i += kBlock) {
+#if PVT_STATS
+    if (lane == 0) {
+        unsigned long long* c = reinterpret_cast<unsigned long long*>(A.cursor) + 1;
+        atomicAdd(c + 0, st_iters); atomicAdd(c + 1, st_lane_steps);
+        atomicAdd(c + 2, st_drain_iters); atomicAdd(c + 3, st_drain_lane_steps);
+        atomicAdd(c + 4, 1ull);
+    }
+#endif
+    // ---- flush workgroup accumulators: done by the LAST wave to leave -------
+    // (no closing barrier: retiring waves must never be counted by the drain-phase
+    // rendezvous barriers of the waves still running)
+    __threadfence_block();
+    int order = 0;
+    if (lane == 0) order = atomicAdd(&ctl[CTL_DONE], 1);
+    order = __builtin_amdgcn_readfirstlane(order);
+    if (order != kWaves - 1) return;
+    __threadfence_block();
+    for (int i = lane; i < A.n_rec; i += 64) {
         unsigned int c = acc_cross[i], d = acc_distinct[i];
         if (c) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_crossings) + i, (unsigned long long)c);
         if (d) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_distinct) + i, (unsigned long long)d);
     }
-    for (int i = threadIdx.x; i < A.n_rec * 8; i += kBlock) {
+    for (int i = lane; i < A.n_rec * 8; i += 64) {
         double v = acc_sums[i];
         if (v != 0.0) atomicAdd(A.rec_sums + i, v);
     }
     if (A.bins_in_lds)
-        for (int i = threadIdx.x; i < A.total_bins; i += kBlock) {
+        for (int i = lane; i < A.total_bins; i += 64) {
             unsigned int v = acc_bins[i];
             if (v) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + i, (unsigned long long)v);
         }
@@ -1014,7 +1162,21 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.coat_i = lay.hist_i + H * HI;
     lay.cand_i = lay.coat_i + K * KI;
     lay.cand_list = lay.cand_i + N * 7 * 2;
-    std::vector<int> gi((size_t)lay.cand_list + R + 1, 0);
+    const int guide0 = lay.cand_list + R;  // guide tables: one entry per table point, per searched array
+    std::vector<int> gi((size_t)guide0 + (size_t)t->n_abs + 2 * (size_t)t->n_ems + 1, 0);
+    // guide[b] = largest i <= n-2 with xs[i] <= xs[0] + b*(xs[n-1]-xs[0])/(n-1), b = 0..n-1
+    auto build_guide = [&](const double* xs, int n, int at, double* scale) {
+        *scale = 0.0;
+        if (n < 2 || !(xs[n - 1] > xs[0])) return;
+        const int Kb = n - 1;
+        *scale = (double)Kb / (xs[n - 1] - xs[0]);
+        int i = 0;
+        for (int b = 0; b <= Kb; b++) {
+            const double edge = xs[0] + (double)b * ((xs[n - 1] - xs[0]) / (double)Kb);
+            while (i + 1 <= n - 2 && xs[i + 1] <= edge) i++;
+            gi[at + b] = i;
+        }
+    };
     {   // recorders grouped by the (node, selector) they listen to, ascending id within a group
         int at = 0;
         for (int key = 0; key < N * 7; key++) {
@@ -1055,6 +1217,12 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[CI_EMS_X] = ems_x0 + t->comp_ems_start[c];
         q[CI_EMS_CDF] = ems_c0 + t->comp_ems_start[c];
         q[CI_EMS_N] = t->comp_ems_n[c];
+        q[CI_ABS_G] = guide0 + t->comp_abs_start[c];
+        q[CI_EMS_GX] = guide0 + t->n_abs + t->comp_ems_start[c];
+        q[CI_EMS_GC] = guide0 + t->n_abs + t->n_ems + t->comp_ems_start[c];
+        build_guide(t->abs_x + t->comp_abs_start[c], t->comp_abs_n[c], q[CI_ABS_G], &d[CD_ABS_SCALE]);
+        build_guide(t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GX], &d[CD_EMS_SCALE_X]);
+        build_guide(t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GC], &d[CD_EMS_SCALE_C]);
     }
     for (int r = 0; r < R; r++) {
         double* d = gd.data() + lay.rec_d + r * RD;
@@ -1230,7 +1398,7 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
         HIP_TRY(hipMemsetAsync(log->travelled, 0, rows * 8, st));
         HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
     }
-    HIP_TRY(hipMemsetAsync(s->d_cursor, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(s->d_cursor, 0, PVT_STATS ? 64 : 4, st));
 
     // LDS budget: tables (if they fit) + recorder accumulators (+ bins if they fit)
     const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 2 * 4);
@@ -1240,7 +1408,16 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     bool tab_lds = acc_bytes + tab_bytes <= budget;
     size_t lds = acc_bytes + (tab_lds ? tab_bytes : 0);
     a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
-    if (a.bins_in_lds) lds += bins_bytes;
+    if (a.bins_in_lds) lds += (bins_bytes + 7) & ~(size_t)7;
+    lds += CTL_WORDS * 4;
+    // drain-phase consolidation buffer: kXSlots photon states, if four workgroups still fit a CU
+    const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 3 : 0);
+    const size_t xbytes = (size_t)kXSlots * xw * 8;
+    a.xslots = 0;
+    if (!getenv("PVT_NO_CONSOLIDATE") && lds + xbytes <= 40 * 1024) {
+        a.xslots = kXSlots;
+        lds += xbytes;
+    }
     if (lds > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
     lds = (lds + 15) & ~(size_t)15;
 
@@ -1265,6 +1442,17 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
                     : launch_seen<false, false>(s->n_rec, emit, (int)grid, lds, st, a);
     }
     if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
+#if PVT_STATS
+    {
+        unsigned long long c[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(c, s->d_cursor, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[pvt stats] waves %llu  wave-iterations %llu (drain %llu)  lane-steps %llu (drain %llu)  "
+                "mean live lanes/iter %.1f (bulk %.1f, drain %.1f)  iters/wave %.1f (drain %.1f)\n",
+                c[5], c[1], c[3], c[2], c[4], (double)c[2] / c[1], (double)(c[2] - c[4]) / (double)(c[1] - c[3] + 1e-9),
+                (double)c[4] / (c[3] + 1e-9), (double)c[1] / c[5], (double)c[3] / c[5]);
+    }
+#endif
     return PVT_OK;
 }
 
