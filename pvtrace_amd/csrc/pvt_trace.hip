@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +52,7 @@ namespace {
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
 constexpr int kWaves = kBlock / 64;
+constexpr int kCursorSlots = 16;
 constexpr int kXSlots = 128;         // LDS photon-state slots used to repack a draining workgroup
 // workgroup control words in LDS
 enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_WORDS = 16 };
@@ -1121,7 +1123,9 @@ struct PvtScene {
     int* d_gi = nullptr;
     double* d_ed = nullptr;
     int* d_ei = nullptr;
-    unsigned int* d_cursor = nullptr;
+    unsigned int* d_cursor = nullptr;   // ring of kCursorSlots cursors (64 B apart): launches on
+                                        // different streams may overlap, each needs its own
+    std::atomic<unsigned int> launches{0};
     int num_cu = 0;
     int last_grid = 0, last_lds = 0;
     size_t lds_limit = 0;
@@ -1274,7 +1278,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->lds_limit = prop.sharedMemPerBlock;
     HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
     HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
-    HIP_TRY(hipMalloc(&s->d_cursor, 64));
+    HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots));
     HIP_TRY(hipMemcpy(s->d_gd, gd.data(), gd.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_gi, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice));
     *out = s;
@@ -1398,7 +1402,8 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
         HIP_TRY(hipMemsetAsync(log->travelled, 0, rows * 8, st));
         HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
     }
-    HIP_TRY(hipMemsetAsync(s->d_cursor, 0, PVT_STATS ? 64 : 4, st));
+    a.cursor = s->d_cursor + 16 * (s->launches.fetch_add(1) % kCursorSlots);
+    HIP_TRY(hipMemsetAsync(a.cursor, 0, PVT_STATS ? 64 : 4, st));
 
     // LDS budget: tables (if they fit) + recorder accumulators (+ bins if they fit)
     const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 2 * 4);
@@ -1446,7 +1451,7 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     {
         unsigned long long c[8];
         (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(c, s->d_cursor, 64, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(c, a.cursor, 64, hipMemcpyDeviceToHost);
         fprintf(stderr, "[pvt stats] waves %llu  wave-iterations %llu (drain %llu)  lane-steps %llu (drain %llu)  "
                 "mean live lanes/iter %.1f (bulk %.1f, drain %.1f)  iters/wave %.1f (drain %.1f)\n",
                 c[5], c[1], c[3], c[2], c[4], (double)c[2] / c[1], (double)(c[2] - c[4]) / (double)(c[1] - c[3] + 1e-9),

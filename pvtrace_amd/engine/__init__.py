@@ -8,6 +8,7 @@ from pvtrace_amd.engine.compiler import CompiledScene, UnsupportedSceneError, co
 from pvtrace_amd.engine.recorder import Heatmap, Histogram, Recorder
 from pvtrace_amd.engine.tally import tally_histories
 from pvtrace_amd.engine.native import EngineUnavailableError
+from pvtrace_amd.engine.pipeline import BundlePipeline, trace_stream
 from pvtrace_amd.engine.api import (
     EngineResult,
     RecorderResult,
@@ -19,5 +20,5 @@ from pvtrace_amd.engine.api import (
 __all__ = [
     "CompiledScene", "UnsupportedSceneError", "compile_scene", "Recorder", "Histogram",
     "Heatmap", "EngineResult", "RecorderResult", "EngineUnavailableError", "is_available",
-    "simulate", "simulate_stream", "tally_histories",
+    "simulate", "simulate_stream", "tally_histories", "BundlePipeline", "trace_stream",
 ]

@@ -1,0 +1,136 @@
+"""Bundle pipelining: keep several photon bundles in flight on separate HIP streams.
+
+A launch of n photons ends with a *drain*: once the ray cursor is dry the kernel lives
+for `longest remaining history x step latency` (~0.4 ms for the LSC scene whatever n is)
+while most of the chip idles.  For one huge bundle that is noise; for a STREAM of
+moderate bundles (the reference's `simulate_stream`, api.py:249-264; the studio's
+consumer loop, studio/server.py:218-256) it is half the wall time at 10^6 photons per
+bundle.  `BundlePipeline` enqueues bundle k+1 on another stream before bundle k has
+finished, so the next bundle's bulk phase fills the CUs the draining bundle vacates.
+Every bundle is still traced completely and tallied into its own buffers; results are
+identical to running the bundles one after another (per-ray RNG streams).
+"""
+import numpy as np
+
+from pvtrace_amd.engine import native
+
+
+class BundlePipeline:
+    def __init__(self, dscene, depth=2, distributed=False, group=None):
+        import torch
+
+        self.torch = torch
+        self.dscene = dscene
+        self.device = torch.device("cuda", dscene.device)
+        self.depth = max(1, int(depth))
+        self.distributed = distributed
+        self.group = group
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.slots = [dscene.new_tallies() for _ in range(self.depth)]
+        self.totals = [dscene.new_tallies() for _ in range(self.depth)]
+        self.events = []       # (start, stop) HIP events of every trace launch
+        self.submitted = 0
+
+    def submit(self, rays, n_rays, seed, ray_offset=0, emit_seed=0, maxsteps=1000, max_events=128,
+               emit_method=0, timed=True):
+        """Enqueue one tally-mode bundle (record_every=0) on the next stream; returns its slot."""
+        torch = self.torch
+        k = self.submitted % self.depth
+        self.submitted += 1
+        stream, tallies, total = self.streams[k], self.slots[k], self.totals[k]
+        with torch.cuda.stream(stream):
+            tallies["_ints"].zero_()
+            tallies["_sums"].zero_()
+            ev = None
+            if timed:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(stream)
+            self.dscene.trace(rays, n_rays, seed=seed, tallies=tallies, ray_offset=ray_offset,
+                              emit_seed=emit_seed, record_every=0, maxsteps=maxsteps,
+                              max_events=max_events, emit_method=emit_method,
+                              stream=stream.cuda_stream)
+            if timed:
+                ev[1].record(stream)
+                self.events.append(ev)
+            if self.distributed:
+                from pvtrace_amd.engine.distributed import all_reduce_tallies
+
+                all_reduce_tallies(tallies, group=self.group)
+            total["_ints"] += tallies["_ints"]
+            total["_sums"] += tallies["_sums"]
+        return k
+
+    def wait_for_inputs(self):
+        """Make every pipeline stream wait for work already queued on the current stream
+        (e.g. the upload of the rays)."""
+        cur = self.torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def reset_totals(self):
+        self.synchronize()
+        for t in self.totals:
+            t["_ints"].zero_()
+            t["_sums"].zero_()
+        self.events = []
+
+    def totals_host(self):
+        """Sum of every bundle submitted since the last reset -> host numpy dict."""
+        self.synchronize()
+        ints = sum(t["_ints"] for t in self.totals)
+        sums = sum(t["_sums"] for t in self.totals)
+        c = self.dscene.compiled
+        nrec = max(int(c.rec_node.shape[0]), 1)
+        ints, sums = ints.cpu().numpy(), sums.cpu().numpy()
+        r = int(c.rec_node.shape[0])
+        return {
+            "rec_distinct": ints[:nrec][:r], "rec_crossings": ints[nrec:2 * nrec][:r],
+            "rec_bins": ints[2 * nrec:][: int(c.total_bins)],
+            "rec_sums": sums[: r * 8].reshape(r, 4, 2),
+        }
+
+    def kernel_ms(self):
+        self.synchronize()
+        return [a.elapsed_time(b) for a, b in self.events]
+
+
+def trace_stream(scene, num_rays, bundle, seed, emit_seed=0, maxsteps=1000, max_events=128,
+                 emit_method="kT", device=None, depth=2):
+    """Tally-mode trace of `num_rays` photons as pipelined bundles with device-side emission.
+    Returns (data dict with the rec_* arrays of the WHOLE job, elapsed seconds)."""
+    import time
+
+    import torch
+
+    from pvtrace_amd.engine import emit as emit_mod
+    from pvtrace_amd.engine.api import _default_device
+    from pvtrace_amd.engine.compiler import EMIT_METHODS, compile_scene
+
+    if emit_method not in EMIT_METHODS:
+        raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
+    compiled = compile_scene(scene)
+    if device is None:
+        device = _default_device()
+    emitter = emit_mod.EmitterTables(scene, strict=True)
+    dscene = native.DeviceScene(compiled, device=device, emitter=emitter)
+    try:
+        with torch.cuda.device(device):
+            pipe = BundlePipeline(dscene, depth=depth)
+            torch.cuda.synchronize(device)
+            tic = time.perf_counter()
+            traced = 0
+            while traced < num_rays:
+                n = min(bundle, num_rays - traced)
+                pipe.submit(None, n, seed=int(seed), ray_offset=traced, emit_seed=int(emit_seed),
+                            maxsteps=maxsteps, max_events=max_events,
+                            emit_method=EMIT_METHODS[emit_method], timed=False)
+                traced += n
+            data = pipe.totals_host()
+            elapsed = time.perf_counter() - tic
+    finally:
+        dscene.close()
+    return compiled, data, elapsed
