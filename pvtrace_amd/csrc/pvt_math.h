@@ -197,6 +197,9 @@ PVT_HD_STATIC double pvt_asin_R(double z) {
     return p / q;
 }
 
+// asin / acos evaluate the rational R(z) exactly once: the argument of R is selected
+// first (z = x^2 for |x| < 0.5, (1-|x|)/2 otherwise), so no branch duplicates the
+// polynomial and SIMD lanes on either side of 0.5 share one evaluation.
 PVT_HD_STATIC double pvt_asin(double x) {
     const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
     uint64_t u = pvt_d2u(x);
@@ -206,13 +209,12 @@ PVT_HD_STATIC double pvt_asin(double x) {
         if (((ix - 0x3ff00000u) | (uint32_t)u) == 0) return x * pio2_hi;
         return (x - x) / (x - x);
     }
-    if (ix < 0x3fe00000u) {  // |x| < 0.5
-        if (ix < 0x3e500000u) return x;
-        return x + x * pvt_asin_R(x * x);
-    }
-    double z = (1.0 - pvt_fabs(x)) * 0.5;
-    double s = pvt_sqrt(z);
-    double r = pvt_asin_R(z);
+    const int small = ix < 0x3fe00000u;  // |x| < 0.5
+    if (small && ix < 0x3e500000u) return x;
+    const double z = small ? x * x : (1.0 - pvt_fabs(x)) * 0.5;
+    const double r = pvt_asin_R(z);
+    if (small) return x + x * r;
+    const double s = pvt_sqrt(z);
     double res;
     if (ix >= 0x3fef3333u) {  // |x| > 0.975
         res = pio2_hi - (2.0 * (s + s * r) - pio2_lo);
@@ -233,21 +235,19 @@ PVT_HD_STATIC double pvt_acos(double x) {
         if (((ix - 0x3ff00000u) | (uint32_t)u) == 0) return (hx >> 31) ? 2.0 * pio2_hi : 0.0;
         return (x - x) / (x - x);
     }
-    if (ix < 0x3fe00000u) {  // |x| < 0.5
-        if (ix <= 0x3c600000u) return pio2_hi;
-        return pio2_hi - (x - (pio2_lo - x * pvt_asin_R(x * x)));
-    }
+    const int small = ix < 0x3fe00000u;  // |x| < 0.5
+    if (small && ix <= 0x3c600000u) return pio2_hi;
+    const double z = small ? x * x : (1.0 - pvt_fabs(x)) * 0.5;  // (1+x)/2 for x < -0.5: same bits
+    const double r = pvt_asin_R(z);
+    if (small) return pio2_hi - (x - (pio2_lo - x * r));
+    const double s = pvt_sqrt(z);
     if (hx >> 31) {  // x < -0.5
-        double z = (1.0 + x) * 0.5;
-        double s = pvt_sqrt(z);
-        double w = pvt_asin_R(z) * s - pio2_lo;
+        double w = r * s - pio2_lo;
         return 2.0 * (pio2_hi - (s + w));
     }
-    double z = (1.0 - x) * 0.5;  // x > 0.5
-    double s = pvt_sqrt(z);
-    double df = pvt_clear_lo(s);
+    double df = pvt_clear_lo(s);  // x > 0.5
     double c = (z - df * df) / (s + df);
-    double w = pvt_asin_R(z) * s + c;
+    double w = r * s + c;
     return 2.0 * (df + w);
 }
 

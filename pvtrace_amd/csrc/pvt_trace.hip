@@ -607,6 +607,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         bool t_normal = false;
         double t_angle = 0.0;
         V3 nrm{0, 0, 0}, lpos{0, 0, 0};
+        bool em = false, em_acos = false;   // re-emission pending: acos argument (or theta) and phi
+        double em_x = 0.0, em_phi = 0.0;
 
         if (alive) {
             count += 1;
@@ -778,9 +780,31 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                 bool radiative = false;
                                 if (ctype == PVT_COMP_SCATTERER || ctype == PVT_COMP_LUMINOPHORE)
                                     radiative = rng_uniform(rng) < T.dv(L.comp_d + comp * CD + CD_QY);
+                                double tau = 0.0;
                                 if (radiative) {
-                                    if (ABL(3)) { double a_ = rng_uniform(rng), b_ = rng_uniform(rng); double c_ = 2.0 * a_ - 1.0; double s_ = pvt_sqrt(1.0 - c_ * c_); dir = V3{s_ * (2.0 * b_ - 1.0), s_ * pvt_sqrt(1.0 - (2.0 * b_ - 1.0) * (2.0 * b_ - 1.0)), c_}; }
-                                    else dir = sample_phase(T.iv(L.comp_i + comp * CI + CI_PHASE), T.dv(L.comp_d + comp * CD + CD_PHASE), rng);
+                                    // phase function (_kernel.pyx:455-476): only the DRAWS happen here, in the
+                                    // reference's order; acos / sincos run later at the sites shared with the
+                                    // surface lanes, and the new direction is written before the event is logged
+                                    const int pt = T.iv(L.comp_i + comp * CI + CI_PHASE);
+                                    const double pp = T.dv(L.comp_d + comp * CD + CD_PHASE);
+                                    if (pt == PVT_PHASE_HG && pvt_fabs(pp) >= kEps) {
+                                        double g1 = rng_uniform(rng);
+                                        double sg = 2.0 * g1 - 1.0;
+                                        double q = (1.0 - pp * pp) / (1.0 + pp * sg);
+                                        em_x = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
+                                        em_phi = 2.0 * kPi * rng_uniform(rng);
+                                        em_acos = true;
+                                    } else if (pt == PVT_PHASE_CONE) {
+                                        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+                                        em_x = pvt_asin(pvt_sqrt(g1) * pvt_sin(pp));  // theta itself
+                                        em_phi = 2.0 * kPi * g2;
+                                    } else {
+                                        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+                                        em_phi = 2.0 * kPi * g1;
+                                        em_x = 2.0 * g2 - 1.0;
+                                        em_acos = true;
+                                    }
+                                    em = true;
                                     source = comp;
                                     if (ctype == PVT_COMP_LUMINOPHORE) {
                                         const int ci = L.comp_i + comp * CI;
@@ -799,20 +823,20 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                         }
                                         double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
                                         wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_C));
-                                        double tau = T.dv(L.comp_d + comp * CD + CD_TAU_RAD);
-                                        if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
+                                        tau = T.dv(L.comp_d + comp * CD + CD_TAU_RAD);
                                         ev_kind = PVT_EV_EMIT;
                                     } else {
                                         ev_kind = PVT_EV_SCATTER;
                                     }
                                 } else {
-                                    double tau = T.dv(L.comp_d + comp * CD + CD_TAU_NR);
-                                    if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
+                                    tau = T.dv(L.comp_d + comp * CD + CD_TAU_NR);
                                     if (ctype == PVT_COMP_REACTOR) { ev_kind = PVT_EV_REACT; t_sel = PVT_REC_REACTED; }
                                     else { ev_kind = PVT_EV_NONRADIATIVE; t_sel = PVT_REC_LOST; }
                                     t_node = container;
                                     terminal = true;
                                 }
+                                // radiative / non-radiative lifetime: the last draw of either branch
+                                if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
                             } else {
                                 // ---- surface interaction (:834-895) ---------
                                 pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
@@ -881,90 +905,119 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             }
         }
 
+        // ---- shared transcendental sites --------------------------------------
+        // Re-emitting lanes (new direction), surface lanes (incidence angle + Fresnel) and
+        // exiting lanes (exit angle) all need an acos, the first two a sincos of its result:
+        // run each ONCE for the whole wave instead of once per divergent branch.
+        const bool surf = alive && t_normal && ev_kind != PVT_EV_EXIT;
+        V3 nf = nrm;
+        double ac_arg = em_x;
+        bool need_acos = em && em_acos;
         if (alive && t_normal) {
             if (ev_kind == PVT_EV_EXIT) {
                 double dd = pvt_fabs(dot3(nrm, dir));
                 if (dd > 1.0) dd = 1.0;
-                t_angle = pvt_acos(dd);
+                ac_arg = dd;
             } else {
-                // ---- Fresnel / coating decision at the surface ------------
-                const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
-                V3 nf = nrm;
                 if (dot3(nf, dir) < 0.0) nf = V3{-nf.x, -nf.y, -nf.z};
                 double ddot = dot3(nf, dir);
                 if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
-                const double angle = pvt_acos(ddot);
-                t_angle = angle;
-                const bool fres = T.iv(hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
-                double r = 0.0, n1 = 0.0, n2 = 0.0;
-                if (fres) {
-                    n1 = T.dv(container * ND + ND_N);
-                    n2 = T.dv(adjacent * ND + ND_N);
-                    r = ABL(1) ? (n2 < n1 && angle > 0.7297 ? 1.0 : 0.04) : fresnel_reflectivity(angle, n1, n2);
-                }
-                int coat = -1;
-                if (coated) {
-                    if (fres) {
-                        const int cs = T.iv(hit * NI + NI_KSTART), ce = cs + T.iv(hit * NI + NI_KCOUNT);
-                        const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
-                        for (int c = cs; c < ce && coat < 0; c++) {
-                            bool ok = true;
-#pragma unroll
-                            for (int a = 0; a < 3; a++) {
-                                double f = T.dv(L.coat_d + c * KD + KD_FACET + a);
-                                if (pvt_fabs(nl3[a] - f) > 1e-8 + 1e-5 * pvt_fabs(f)) ok = false;
-                                if (!(pl3[a] > T.dv(L.coat_d + c * KD + KD_LO + a) && pl3[a] < T.dv(L.coat_d + c * KD + KD_HI + a))) ok = false;
-                            }
-                            if (ok) coat = c;
-                        }
-                        if (coat >= 0) {
-                            double cr = T.dv(L.coat_d + coat * KD + KD_REFL);
-                            if (cr >= 0.0) r = cr;
-                        }
-                    }
-                }
-                double u = 1.0;
-                if (r > 0.0) u = rng_uniform(rng);
-                if (u < r) {
-                    bool lamb = false;
-                    if (coat >= 0) lamb = T.iv(L.coat_i + coat * KI + KI_RMODE) == 1;
-                    if (lamb) {
-                        // cosine-weighted about the incoming side's normal, in the node frame
-                        double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
-                        V3 mm{side * nloc.x, side * nloc.y, side * nloc.z};
-                        double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
-                        V3 s = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
-                        double sign = mm.z < 0.0 ? -1.0 : 1.0;
-                        double a = -1.0 / (sign + mm.z);
-                        double b = mm.x * mm.y * a;
-                        V3 t1v{1.0 + sign * mm.x * mm.x * a, sign * b, -sign * mm.x};
-                        V3 t2v{b, sign + mm.y * mm.y * a, -mm.y};
-                        V3 dl{s.x * t1v.x + s.y * t2v.x + s.z * mm.x, s.x * t1v.y + s.y * t2v.y + s.z * mm.y,
-                              s.x * t1v.z + s.y * t2v.z + s.z * mm.z};
-                        const int q = hit * ND + ND_L2W;
-                        dir.x = T.dv(q + 0) * dl.x + T.dv(q + 1) * dl.y + T.dv(q + 2) * dl.z;
-                        dir.y = T.dv(q + 3) * dl.x + T.dv(q + 4) * dl.y + T.dv(q + 5) * dl.z;
-                        dir.z = T.dv(q + 6) * dl.x + T.dv(q + 7) * dl.y + T.dv(q + 8) * dl.z;
-                    } else {  // specular (:422-433): nf is nrm flipped along dir
-                        double dd = dot3(nf, dir);
-                        dir = V3{dir.x - 2.0 * dd * nf.x, dir.y - 2.0 * dd * nf.y, dir.z - 2.0 * dd * nf.z};
-                    }
-                    ev_kind = PVT_EV_REFLECT;
-                    t_sel = (container != hit) ? PVT_REC_REFLECTED : -1;
+                ac_arg = ddot;
+            }
+            need_acos = true;
+        }
+        double ac = 0.0;
+        if (need_acos) ac = pvt_acos(ac_arg);
+        if (alive && t_normal) t_angle = ac;
+        const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
+        double s1 = 0.0, c1 = 1.0;
+        if (em || fres) pvt_sincos(em ? (em_acos ? ac : em_x) : ac, &s1, &c1);
+        if (em) {
+            double sp, cp;
+            pvt_sincos(em_phi, &sp, &cp);
+            dir = V3{s1 * cp, s1 * sp, c1};
+        }
+
+        if (surf) {
+            // ---- Fresnel / coating decision at the surface (:865-895) ------------
+            const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
+            const double angle = ac;
+            double r = 0.0, n1 = 0.0, n2 = 0.0;
+            if (fres) {  // unpolarised Fresnel, 1.0 beyond the critical angle (:406-419)
+                n1 = T.dv(container * ND + ND_N);
+                n2 = T.dv(adjacent * ND + ND_N);
+                if (n2 < n1 && angle > pvt_asin(n2 / n1)) {
+                    r = 1.0;
                 } else {
-                    bool matched = false;
-                    if (coat >= 0) matched = T.iv(L.coat_i + coat * KI + KI_TMODE) == 1;
-                    if (fres && !matched) {  // Snell, vector form (:436-446)
-                        double n = n1 / n2;
-                        double dd = dot3(dir, nf);
-                        double c = pvt_sqrt(1.0 - n * n * (1.0 - dd * dd));
-                        double sign = dd < 0.0 ? -1.0 : 1.0;
-                        double k = sign * (c - sign * n * dd);
-                        dir = V3{n * dir.x + k * nf.x, n * dir.y + k * nf.y, n * dir.z + k * nf.z};
-                    }
-                    ev_kind = PVT_EV_TRANSMIT;
-                    t_sel = (container == hit) ? PVT_REC_ESCAPING : PVT_REC_ENTERING;
+                    double q = n1 / n2 * s1;
+                    double k = pvt_sqrt(1.0 - q * q);
+                    double rs1 = n1 * c1 - n2 * k, rs2 = n1 * c1 + n2 * k;
+                    double rs = (rs1 / rs2) * (rs1 / rs2);
+                    double rp1 = n1 * k - n2 * c1, rp2 = n1 * k + n2 * c1;
+                    double rp = (rp1 / rp2) * (rp1 / rp2);
+                    r = 0.5 * (rs + rp);
                 }
+            }
+            int coat = -1;
+            if (coated && fres) {
+                const int cs = T.iv(hit * NI + NI_KSTART), ce = cs + T.iv(hit * NI + NI_KCOUNT);
+                const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
+                for (int c = cs; c < ce && coat < 0; c++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        double f = T.dv(L.coat_d + c * KD + KD_FACET + a);
+                        if (pvt_fabs(nl3[a] - f) > 1e-8 + 1e-5 * pvt_fabs(f)) ok = false;
+                        if (!(pl3[a] > T.dv(L.coat_d + c * KD + KD_LO + a) && pl3[a] < T.dv(L.coat_d + c * KD + KD_HI + a))) ok = false;
+                    }
+                    if (ok) coat = c;
+                }
+                if (coat >= 0) {
+                    double cr = T.dv(L.coat_d + coat * KD + KD_REFL);
+                    if (cr >= 0.0) r = cr;
+                }
+            }
+            double u = 1.0;
+            if (r > 0.0) u = rng_uniform(rng);
+            if (u < r) {
+                bool lamb = false;
+                if (coat >= 0) lamb = T.iv(L.coat_i + coat * KI + KI_RMODE) == 1;
+                if (lamb) {
+                    // cosine-weighted about the incoming side's normal, in the node frame
+                    double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
+                    V3 mm{side * nloc.x, side * nloc.y, side * nloc.z};
+                    double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
+                    V3 sd = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
+                    double sign = mm.z < 0.0 ? -1.0 : 1.0;
+                    double a = -1.0 / (sign + mm.z);
+                    double b = mm.x * mm.y * a;
+                    V3 t1v{1.0 + sign * mm.x * mm.x * a, sign * b, -sign * mm.x};
+                    V3 t2v{b, sign + mm.y * mm.y * a, -mm.y};
+                    V3 dl{sd.x * t1v.x + sd.y * t2v.x + sd.z * mm.x, sd.x * t1v.y + sd.y * t2v.y + sd.z * mm.y,
+                          sd.x * t1v.z + sd.y * t2v.z + sd.z * mm.z};
+                    const int q = hit * ND + ND_L2W;
+                    dir.x = T.dv(q + 0) * dl.x + T.dv(q + 1) * dl.y + T.dv(q + 2) * dl.z;
+                    dir.y = T.dv(q + 3) * dl.x + T.dv(q + 4) * dl.y + T.dv(q + 5) * dl.z;
+                    dir.z = T.dv(q + 6) * dl.x + T.dv(q + 7) * dl.y + T.dv(q + 8) * dl.z;
+                } else {  // specular (:422-433): nf is nrm flipped along dir
+                    double dd = dot3(nf, dir);
+                    dir = V3{dir.x - 2.0 * dd * nf.x, dir.y - 2.0 * dd * nf.y, dir.z - 2.0 * dd * nf.z};
+                }
+                ev_kind = PVT_EV_REFLECT;
+                t_sel = (container != hit) ? PVT_REC_REFLECTED : -1;
+            } else {
+                bool matched = false;
+                if (coat >= 0) matched = T.iv(L.coat_i + coat * KI + KI_TMODE) == 1;
+                if (fres && !matched) {  // Snell, vector form (:436-446)
+                    double n = n1 / n2;
+                    double dd = dot3(dir, nf);
+                    double c = pvt_sqrt(1.0 - n * n * (1.0 - dd * dd));
+                    double sign = dd < 0.0 ? -1.0 : 1.0;
+                    double k = sign * (c - sign * n * dd);
+                    dir = V3{n * dir.x + k * nf.x, n * dir.y + k * nf.y, n * dir.z + k * nf.z};
+                }
+                ev_kind = PVT_EV_TRANSMIT;
+                t_sel = (container == hit) ? PVT_REC_ESCAPING : PVT_REC_ENTERING;
             }
         }
 
