@@ -150,21 +150,22 @@ PVT_HD_STATIC int pvt_rem_pio2(double x, double* y0, double* y1) {
     return n;
 }
 
+// One evaluation of each kernel whatever the argument: arguments inside [-pi/4, pi/4] are
+// their own reduction (n = 0, tail 0), so SIMD lanes with small and large angles share the
+// same instructions instead of serialising two copies of the polynomials.
 PVT_HD_STATIC void pvt_sincos(double x, double* s, double* c) {
     uint32_t ix = pvt_hi(x) & 0x7fffffffu;
-    if (ix <= 0x3fe921fbu) {  // |x| <= ~pi/4
-        *s = (ix < 0x3e500000u) ? x : pvt_ksin(x, 0.0, 0);
-        *c = (ix < 0x3e46a09eu) ? 1.0 : pvt_kcos(x, 0.0);
-        return;
-    }
     if (ix >= 0x7ff00000u) {
         *s = *c = x - x;
         return;
     }
-    double y0, y1;
-    int n = pvt_rem_pio2(x, &y0, &y1);
+    double y0 = x, y1 = 0.0;
+    int n = 0;
+    if (ix > 0x3fe921fbu) n = pvt_rem_pio2(x, &y0, &y1);  // |x| > ~pi/4
     double ks = pvt_ksin(y0, y1, 1);
     double kc = pvt_kcos(y0, y1);
+    if (ix < 0x3e500000u) ks = x;    // |x| < 2^-26: sin x == x
+    if (ix < 0x3e46a09eu) kc = 1.0;  // |x| < 2^-27*sqrt2: cos x == 1
     switch (n & 3) {
         case 0: *s = ks; *c = kc; break;
         case 1: *s = kc; *c = -ks; break;
