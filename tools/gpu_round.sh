@@ -1,14 +1,15 @@
 #!/bin/bash
-# One GPU-box pass: tests, smoke, bench, rocprof kernel trace (summaries -> gpurun_out/)
+# One GPU-box pass: tests, smoke, bench (default flags), serial bench, rocprof kernel trace of both
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 > gpurun_out/pytest_gpu.log
-cat gpurun_out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 2>gpurun_out/bench.err | tee gpurun_out/bench.json
-tail -3 gpurun_out/bench.err
+R=$GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
+timeout 600 python bench.py 2>gpurun_out/bench.err | tee gpurun_out/bench.json
+timeout 600 python bench.py --streams 1 --no-cpu-baseline 2>>gpurun_out/bench.err | tee gpurun_out/bench_serial.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err
-cd $GRAFT_REPO_ROOT
-find gpurun_out/prof -type f | head -20; find gpurun_out/prof -name "*kernel_stats*" -exec head -8 {} \;
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_serial -o bench -- python $R/bench.py --streams 1 --no-cpu-baseline > $R/gpurun_out/prof_bench_serial.json 2> $R/gpurun_out/prof_serial.err
+cd $R
+head -3 gpurun_out/prof/bench_kernel_stats.csv | cut -c1-200; head -3 gpurun_out/prof_serial/bench_kernel_stats.csv | cut -c1-200
