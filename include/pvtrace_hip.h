@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 1
+#define PVT_ABI_VERSION 2
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -115,6 +115,10 @@ typedef struct PvtSceneTables {
     const double* coat_reflectivity;/* <0: keep Fresnel */
     const int32_t* coat_reflect_mode;   /* 0 specular, 1 lambertian */
     const int32_t* coat_transmit_mode;  /* 0 Fresnel refraction, 1 index matched */
+    /* recorder source filter (extension; NULL = no filter): 0 any, 1 photons emitted by a
+     * light (source id < 0), 2 by any component, 3 by component rec_source_id */
+    const int32_t* rec_source_mode;
+    const int32_t* rec_source_id;
 } PvtSceneTables;
 
 /* ---- optional device-side emission (replaces the Python/numpy emitter,

@@ -273,11 +273,17 @@ static inline double prop_value(int prop, double wl, double angle, double durati
         default: return lpos[2];
     }
 }
-static void tally(const PvtSceneTables* S, Acc* A, int sel, int node, unsigned char* seen,
+static void tally(const PvtSceneTables* S, Acc* A, int source, int sel, int node, unsigned char* seen,
                   const double* wnormal, const double* lpos, double angle, double wl,
                   double travelled, double duration) {
     for (int r = 0; r < S->n_recorders; r++) {
         if (S->rec_node[r] != node || S->rec_event[r] != sel) continue;
+        if (S->rec_source_mode && S->rec_source_mode[r] != 0) { /* EXTENSION: source filter */
+            int mode = S->rec_source_mode[r];
+            if (mode == 1 && source >= 0) continue;
+            if (mode == 2 && source < 0) continue;
+            if (mode == 3 && source != S->rec_source_id[r]) continue;
+        }
         if (S->rec_has_facet[r] != 0) {
             if (wnormal == NULL) continue;
             if (fabs(S->rec_facet[r * 3] - wnormal[0]) > S->rec_atol[r]) continue;
@@ -428,7 +434,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
                    dir, NULL, wl, travelled, duration);
             if (S->n_recorders > 0) {
                 xform_point(S->world_to_local + container * 16, pos, lp);
-                tally(S, A, PVT_REC_KILLED, container, seen, NULL, lp, 0.0, wl, travelled, duration);
+                tally(S, A, source, PVT_REC_KILLED, container, seen, NULL, lp, 0.0, wl, travelled, duration);
             }
             break;
         }
@@ -446,7 +452,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
                 xform_vector(S->local_to_world + hit * 16, nl, nrm);
                 double dd = fabs(dot3(nrm, dir));
                 if (dd > 1.0) dd = 1.0;
-                tally(S, A, PVT_REC_EXIT, hit, seen, nrm, lp, m_acos(M, dd), wl, travelled, duration);
+                tally(S, A, source, PVT_REC_EXIT, hit, seen, nrm, lp, m_acos(M, dd), wl, travelled, duration);
             }
             break;
         }
@@ -522,7 +528,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
                 }
                 if (S->n_recorders > 0) {
                     xform_point(S->world_to_local + container * 16, pos, lp);
-                    tally(S, A, sel, container, seen, NULL, lp, 0.0, wl, travelled, duration);
+                    tally(S, A, source, sel, container, seen, NULL, lp, 0.0, wl, travelled, duration);
                 }
                 break;
             }
@@ -572,7 +578,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
             record(L, max_events, base, &nevents, PVT_EV_REFLECT, hit, container, adjacent, -1, source,
                    pos, dir, nrm, wl, travelled, duration);
             if (S->n_recorders > 0 && container != hit)
-                tally(S, A, PVT_REC_REFLECTED, hit, seen, nrm, lp, angle, wl, travelled, duration);
+                tally(S, A, source, PVT_REC_REFLECTED, hit, seen, nrm, lp, angle, wl, travelled, duration);
             continue;
         } else {
             if (fres && !(coat >= 0 && S->coat_transmit_mode[coat] == 1)) {
@@ -583,7 +589,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
                    pos, dir, nrm, wl, travelled, duration);
             if (S->n_recorders > 0) {
                 int sel = (container == hit) ? PVT_REC_ESCAPING : PVT_REC_ENTERING;
-                tally(S, A, sel, hit, seen, nrm, lp, angle, wl, travelled, duration);
+                tally(S, A, source, sel, hit, seen, nrm, lp, angle, wl, travelled, duration);
             }
             continue;
         }

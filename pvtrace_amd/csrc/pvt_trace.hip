@@ -71,7 +71,7 @@ enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X,
 enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N,
        CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI };  // *_G*: guide tables (bucket -> bracketing index)
 enum { RD_FACET = 0, RD_ATOL = 3, RD = 4 };                                     // recorder
-enum { RI_NODE = 0, RI_EVENT, RI_HAS_FACET, RI_HSTART, RI_HN, RI };
+enum { RI_NODE = 0, RI_EVENT, RI_HAS_FACET, RI_HSTART, RI_HN, RI_SRC_MODE, RI_SRC_ID, RI };
 enum { HD_LO_A = 0, HD_HI_A, HD_LO_B, HD_HI_B, HD };                             // histogram
 enum { HI_PA = 0, HI_PB, HI_NA, HI_NB, HI_OFF, HI };
 enum { KD_FACET = 0, KD_LO = 3, KD_HI = 6, KD_REFL = 9, KD = 10 };              // coating
@@ -1045,7 +1045,13 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     const int r = T.iv(L.cand_list + cs + j);
                     const int ri = L.rec_i + r * RI;
                     bool match = true;
-                    if (T.iv(ri + RI_HAS_FACET) != 0) {
+                    const int smode = T.iv(ri + RI_SRC_MODE);  // source filter (extension)
+                    if (smode != 0) {
+                        if (smode == 1) match = source < 0;
+                        else if (smode == 2) match = source >= 0;
+                        else match = source == T.iv(ri + RI_SRC_ID);
+                    }
+                    if (match && T.iv(ri + RI_HAS_FACET) != 0) {
                         const int rd = L.rec_d + r * RD;
                         const double atol = T.dv(rd + RD_ATOL);
                         if (!t_normal) match = false;
@@ -1291,6 +1297,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[RI_HAS_FACET] = t->rec_has_facet[r];
         q[RI_HSTART] = t->rec_hist_start[r];
         q[RI_HN] = t->rec_hist_n[r];
+        q[RI_SRC_MODE] = t->rec_source_mode ? t->rec_source_mode[r] : 0;
+        q[RI_SRC_ID] = t->rec_source_id ? t->rec_source_id[r] : -1;
     }
     for (int h = 0; h < H; h++) {
         double* d = gd.data() + lay.hist_d + h * HD;

@@ -202,21 +202,23 @@ class LSC(object):
         self._scene = Scene(world)
 
     def _default_recorders(self):
-        """Face / loss tallies the summary is built from (the reference derives
-        the same counts from a per-ray pandas frame, lsc.py:379-633)."""
+        """Recorders the report is built from.  The reference derives its "Solar In/Out,
+        Luminescent In/Out" table from a per-ray pandas frame filtered by facet and by the
+        ray's source (lsc.py:440-489); here the same split is tallied on the GPU by facet
+        recorders with a source filter (light-emitted vs component-emitted photons)."""
         lo, hi = float(self.wavelength_range.min()), float(self.wavelength_range.max()) + 1.0
         nbins = max(int(round((hi - lo) / 5.0)), 1)
-        recs = [
-            Recorder(f"escaping-{label}", event="escaping", facet=normal,
-                     histograms=[Histogram("wavelength", lo, hi, nbins)])
-            for label, normal in FACETS.items()
-        ]
-        recs += [
-            Recorder(f"entering-{label}", event="entering", facet=normal)
-            for label, normal in FACETS.items()
-        ]
-        recs += [Recorder("reflected", event="reflected"), Recorder("lost", event="lost"),
-                 Recorder("killed", event="killed")]
+        recs = []
+        for label, normal in FACETS.items():
+            recs += [
+                Recorder(f"solar-in-{label}", event="entering", facet=normal, source="lights"),
+                Recorder(f"solar-out-{label}", event="escaping", facet=normal, source="lights"),
+                Recorder(f"solar-reflected-{label}", event="reflected", facet=normal, source="lights"),
+                Recorder(f"lum-in-{label}", event="entering", facet=normal, source="components"),
+                Recorder(f"lum-out-{label}", event="escaping", facet=normal, source="components",
+                         histograms=[Histogram("wavelength", lo, hi, nbins)]),
+            ]
+        recs += [Recorder("lost", event="lost"), Recorder("killed", event="killed")]
         return recs
 
     @property
@@ -248,20 +250,72 @@ class LSC(object):
         return self._result
 
     def counts(self):
-        """dict: rays escaping / entering per facet, lost, reflected, killed."""
+        """Surface counts per facet, columns as in the reference's report (lsc.py:440-489):
+        Solar In / Solar Out / Luminescent Out / Luminescent In (distinct photons).
+        "Solar Out" adds the photons reflected off a facet to those transmitted out of it,
+        like the reference's exit-ray bookkeeping.  Returns a pandas DataFrame when pandas
+        is available, else a dict of dicts."""
         if self._result is None:
             raise ValueError("Run a simulation before calling this method.")
-        return {name: rec.rays for name, rec in self._result.recorders.items()}
+        r = {name: rec.rays for name, rec in self._result.recorders.items()}
+        table = {
+            "Solar In": {f: r[f"solar-in-{f}"] for f in FACETS},
+            "Solar Out": {f: r[f"solar-out-{f}"] + r[f"solar-reflected-{f}"] for f in FACETS},
+            "Luminescent Out": {f: r[f"lum-out-{f}"] for f in FACETS},
+            "Luminescent In": {f: r[f"lum-in-{f}"] for f in FACETS},
+        }
+        try:
+            import pandas as pd
+
+            return pd.DataFrame(table, index=list(FACETS))
+        except ImportError:
+            return table
 
     def summary(self):
-        """Fractions of the incident photons leaving through each face / lost."""
-        c = self.counts()
-        n = float(self._result.num_rays)
-        out = {f"escaping-{k}": c[f"escaping-{k}"] / n for k in FACETS}
-        out["lost"] = c["lost"] / n
-        out["reflected"] = c["reflected"] / n
-        edges = sum(c[f"escaping-{k}"] for k in ("left", "right", "near", "far"))
-        entered = sum(c[f"entering-{k}"] for k in FACETS)
-        out["optical-efficiency"] = edges / n
-        out["entered"] = entered / n
-        return out
+        """Headline figures of the reference's LSC.summary() (lsc.py:583-620)."""
+        counts = self.counts()
+        get = (lambda col, f: int(counts[col][f]))
+        cells = set(self._solar_cell_surfaces)
+        lum_collected = sum(get("Luminescent Out", f) for f in cells)
+        lum_escaped = sum(get("Luminescent Out", f) for f in FACETS if f not in cells)
+        incident = sum(get("Solar In", f) for f in FACETS)
+        lost = self._result.recorders["lost"].rays
+        (l, w, d) = self.size
+        cg = (w * l) / (2 * l * d + 2 * w * d)
+        n = self.n1
+        nan = float("nan")
+        out = {
+            "Optical Efficiency": lum_collected / incident if incident else nan,
+            "Waveguide Efficiency": (lum_collected / (lum_collected + lum_escaped)
+                                     if lum_collected + lum_escaped else nan),
+            "Waveguide Efficiency (Thermodynamic Prediction)": n ** 2 / (cg + n ** 2),
+            "Non-radiative Loss (fraction):": lost / incident if incident else nan,
+            "Incident": incident,
+            "Geometric Concentration": cg,
+            "Refractive Index": n,
+            "Cell Surfaces": cells,
+            "Components": self.component_names(),
+            "Lights": self.light_names(),
+        }
+        try:
+            import pandas as pd
+
+            return pd.Series(out)
+        except ImportError:
+            return out
+
+    def spectrum(self, facets=("left", "right", "near", "far", "top", "bottom")):
+        """(bin edges, counts) of the luminescent photons leaving through `facets`."""
+        if self._result is None:
+            raise ValueError("Run a simulation before calling this method.")
+        total, edges = None, None
+        for f in facets:
+            edges, values = self._result.recorders[f"lum-out-{f}"].histogram(0)
+            total = values.copy() if total is None else total + values
+        return edges, total
+
+    def report(self):
+        print("\nSimulation Report\n-----------------\n\nSurface Counts:")
+        print(self.counts())
+        print("\nSummary:")
+        print(self.summary())

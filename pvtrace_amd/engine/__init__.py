@@ -7,6 +7,7 @@ uploads them once, and runs the per-photon loop as a HIP kernel on gfx950
 from pvtrace_amd.engine.compiler import CompiledScene, UnsupportedSceneError, compile_scene
 from pvtrace_amd.engine.recorder import Heatmap, Histogram, Recorder
 from pvtrace_amd.engine.tally import tally_histories
+from pvtrace_amd.engine.instrument import auto_recorders, instrument, recorders_from_spec
 from pvtrace_amd.engine.native import EngineUnavailableError
 from pvtrace_amd.engine.pipeline import BundlePipeline, trace_stream
 from pvtrace_amd.engine.api import (
@@ -20,5 +21,5 @@ from pvtrace_amd.engine.api import (
 __all__ = [
     "CompiledScene", "UnsupportedSceneError", "compile_scene", "Recorder", "Histogram",
     "Heatmap", "EngineResult", "RecorderResult", "EngineUnavailableError", "is_available",
-    "simulate", "simulate_stream", "tally_histories", "BundlePipeline", "trace_stream",
+    "simulate", "simulate_stream", "tally_histories", "BundlePipeline", "trace_stream", "auto_recorders", "instrument", "recorders_from_spec",
 ]

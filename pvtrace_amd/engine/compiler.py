@@ -18,6 +18,10 @@ import numpy as np
 from pvtrace_amd.engine.recorder import (
     EVENTS,
     PROPERTIES,
+    SOURCE_ANY,
+    SOURCE_COMPONENT,
+    SOURCE_COMPONENTS,
+    SOURCE_LIGHTS,
     VOLUME_EVENTS,
     Heatmap,
     Histogram,
@@ -322,6 +326,8 @@ class CompiledScene:
         self.rec_atol = np.zeros(n, dtype=_F64)
         self.rec_hist_start = np.zeros(n, dtype=_I32)
         self.rec_hist_n = np.zeros(n, dtype=_I32)
+        self.rec_source_mode = np.zeros(n, dtype=_I32)
+        self.rec_source_id = np.full(n, -1, dtype=_I32)
 
         hist = {k: [] for k in ("pa", "pb", "na", "nb", "loa", "hia", "lob", "hib", "off")}
         offset = 0
@@ -332,6 +338,20 @@ class CompiledScene:
                 self.rec_has_facet[r] = 1
                 self.rec_facet[r] = recorder.facet
             self.rec_atol[r] = recorder.atol
+            src = getattr(recorder, "source", None)
+            if src is not None:
+                if src == "lights":
+                    self.rec_source_mode[r] = SOURCE_LIGHTS
+                elif src == "components":
+                    self.rec_source_mode[r] = SOURCE_COMPONENTS
+                elif src in self.component_names:
+                    self.rec_source_mode[r] = SOURCE_COMPONENT
+                    self.rec_source_id[r] = self.component_names.index(src)
+                else:
+                    raise UnsupportedSceneError(
+                        f"Recorder {recorder.name!r}: unknown source {src!r} (use 'lights', "
+                        "'components' or a component name)."
+                    )
             self.rec_hist_start[r] = len(hist["pa"])
             for spec in recorder.histograms:
                 if isinstance(spec, Heatmap):
@@ -366,7 +386,7 @@ class CompiledScene:
         "comp_phase_type", "comp_phase_param", "comp_abs_start", "comp_abs_n",
         "comp_ems_start", "comp_ems_n", "abs_x", "abs_y", "ems_x", "ems_cdf",
         "rec_node", "rec_event", "rec_has_facet", "rec_facet", "rec_atol",
-        "rec_hist_start", "rec_hist_n", "hist_prop_a", "hist_prop_b", "hist_na",
+        "rec_hist_start", "rec_hist_n", "rec_source_mode", "rec_source_id", "hist_prop_a", "hist_prop_b", "hist_na",
         "hist_nb", "hist_lo_a", "hist_hi_a", "hist_lo_b", "hist_hi_b",
         "hist_offset",
         "coat_start", "coat_count", "coat_facet", "coat_lo", "coat_hi",

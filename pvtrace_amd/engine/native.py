@@ -51,6 +51,7 @@ class PvtSceneTables(C.Structure):
         ("coat_facet", _p_f64), ("coat_lo", _p_f64), ("coat_hi", _p_f64),
         ("coat_reflectivity", _p_f64), ("coat_reflect_mode", _p_i32),
         ("coat_transmit_mode", _p_i32),
+        ("rec_source_mode", _p_i32), ("rec_source_id", _p_i32),
     ]
 
 

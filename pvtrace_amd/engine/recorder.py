@@ -34,6 +34,11 @@ EVENTS = {
 
 VOLUME_EVENTS = frozenset(("lost", "reacted", "killed"))
 
+# optional source filter (EXTENSION; the reference's recorders have none, its CLI count
+# queries filter by source instead, pvtrace/cli/db.py:61-83): which emitter the photon's
+# current incarnation came from
+SOURCE_ANY, SOURCE_LIGHTS, SOURCE_COMPONENTS, SOURCE_COMPONENT = 0, 1, 2, 3
+
 
 class Histogram:
     """`bins` equal-width bins of `prop` over [start, stop)."""
@@ -81,12 +86,16 @@ class Recorder:
         equals this vector within `atol` per component.
     atol : float
     histograms : list of Histogram / Heatmap, optional
+    source : None | "lights" | "components" | component name, optional
+        Only tally photons last emitted by a light / by any luminophore or scatterer / by
+        the named component (extension; splits e.g. "solar" from "luminescent" counts).
 
     Counts, moments and histograms are per *distinct* ray (first matching
     interaction); every matching interaction also increments `crossings`.
     """
 
-    def __init__(self, name, event="entering", facet=None, atol=1e-6, histograms=None):
+    def __init__(self, name, event="entering", facet=None, atol=1e-6, histograms=None,
+                 source=None):
         if event not in EVENTS:
             raise ValueError(f"Unknown event {event!r}; use one of {sorted(EVENTS)}")
         self.name = name
@@ -94,6 +103,7 @@ class Recorder:
         self.facet = None if facet is None else tuple(float(v) for v in facet)
         self.atol = float(atol)
         self.histograms = [] if histograms is None else list(histograms)
+        self.source = source
         for hist in self.histograms:
             if not isinstance(hist, (Histogram, Heatmap)):
                 raise ValueError("histograms must contain Histogram or Heatmap objects.")

@@ -16,6 +16,18 @@ _SURFACE_SELECTOR = {"entering": "adjacent", "escaping": "container"}
 _VOLUME_EVENT = {"lost": Event.NONRADIATIVE, "reacted": Event.REACT, "killed": Event.KILL}
 
 
+def _source_ok(recorder, ray_source, component_names):
+    want = getattr(recorder, "source", None)
+    if want is None:
+        return True
+    from_component = ray_source in component_names
+    if want == "lights":
+        return not from_component
+    if want == "components":
+        return from_component
+    return ray_source == want
+
+
 def _fires(recorder, name, event, meta):
     kind = recorder.event
     if event == Event.TRANSMIT:
@@ -72,6 +84,8 @@ def tally_histories(scene, histories):
     def to_local(node, position):
         return tuple(position) if node is root else root.point_to_node(position, node)
 
+    component_names = {c.name for n in root.preorder() if n.geometry is not None
+                       and n.geometry.material is not None for c in n.geometry.material.components}
     for history in histories:
         seen = set()
         previous = None
@@ -79,6 +93,8 @@ def tally_histories(scene, histories):
             meta = meta or {}
             for node, rec, state in slots:
                 if not _fires(rec, node.name, event, meta):
+                    continue
+                if not _source_ok(rec, ray.source, component_names):
                     continue
                 normal = meta.get("normal")
                 if event == Event.EXIT and normal is None:

@@ -127,19 +127,80 @@ def test_device_emission_mode_equals_oracle():
 
 
 def test_lsc_high_level_api_runs_on_the_engine():
+    """LSC().simulate/counts/summary (reference lsc.py:338-620) on recorder tallies."""
+    n = 200000
     lsc = LSC((5.0, 5.0, 1.0))
-    lsc.simulate(200000, seed=4, emit_seed=6)
+    lsc.simulate(n, seed=4, emit_seed=6)
+    c = lsc.counts()
     s = lsc.summary()
-    assert abs(s["escaping-top"] - 0.207) < 0.006 and abs(s["lost"] - 0.340) < 0.006
-    assert abs(s["entered"] - 0.960) < 0.003
+    assert abs(c["Solar In"]["top"] / n - 0.960) < 0.003 and c["Solar In"]["bottom"] == 0
+    assert abs(c["Solar Out"]["top"] / n - 0.040) < 0.003            # Fresnel reflection off the top
+    lum_out = sum(c["Luminescent Out"][f] for f in ("left", "right", "near", "far", "top", "bottom"))
+    assert abs(lum_out / n - 0.62) < 0.01 and c["Luminescent In"]["top"] == 0
+    assert s["Optical Efficiency"] == 0.0 and s["Incident"] == sum(c["Solar In"])   # no cells attached
+    assert abs(s["Non-radiative Loss (fraction):"] - 0.340 / 0.960) < 0.01
+    edges, spectrum = lsc.spectrum()
+    assert spectrum.sum() == lum_out and edges[np.argmax(spectrum)] > 580
     cells = LSC((5.0, 5.0, 1.0)); cells.add_solar_cell({"left", "right", "near", "far"}); cells.add_back_surface_mirror()
-    cells.simulate(200000, seed=4, emit_seed=6)
-    t = cells.summary()
-    assert t["escaping-bottom"] == 0.0                       # perfect back mirror
-    assert t["optical-efficiency"] > s["optical-efficiency"]  # index-matched cells collect more
+    cells.simulate(n, seed=4, emit_seed=6)
+    t, ct = cells.summary(), cells.counts()
+    assert ct["Luminescent Out"]["bottom"] == 0 and ct["Solar Out"]["bottom"] == 0   # perfect back mirror
+    assert 0.2 < t["Optical Efficiency"] < 0.6 and 0.5 < t["Waveguide Efficiency"] < 0.9
+    assert abs(t["Waveguide Efficiency (Thermodynamic Prediction)"] - 2.25 / (1.25 + 2.25)) < 1e-12
     mirror = LSC((5.0, 5.0, 1.0)); mirror.add_air_gap_mirror(lambertian=True)
     r = mirror.simulate(50000, seed=4, emit_seed=6)
     assert r.compiled.node_names == ["World", "LSC", "Air Gap Mirror"]
+
+
+def test_source_filtered_recorders_and_auto_instrumentation():
+    from pvtrace_amd.engine import auto_recorders, instrument, recorders_from_spec
+
+    scene = scenes.bench_slab(recorders=False)
+    slab = scene.root.children[0]
+    instrument(slab)                                  # the `record: true` shorthand
+    recorders_from_spec({
+        "solar-out": {"node": "slab", "event": "escaping", "source": "lights"},
+        "lum-out": {"node": "slab", "event": "escaping", "source": "components",
+                    "histograms": {"wavelength": [300, 1000, 70], "position": ["x", "y", [-2.5, 2.5, 10], [-2.5, 2.5, 10]]}},
+        "dye-out": {"node": "slab", "event": "escaping", "source": "dye"},
+        "all-out": {"node": "slab", "event": "escaping"},
+    }, {"slab": slab})
+    assert {r.name for r in auto_recorders(slab)} == {"slab-lost", "slab-top", "slab-bottom", "slab-east",
+                                                      "slab-west", "slab-north", "slab-south"}
+    result = engine.simulate(scene, 20000, seed=3, emit_seed=1, max_events=200)
+    recs = result.recorders
+    assert recs["lum-out"].rays == recs["dye-out"].rays > 0 and recs["solar-out"].rays > 0
+    assert recs["all-out"].crossings == recs["lum-out"].crossings + recs["solar-out"].crossings
+    assert recs["lum-out"].mean("wavelength") > 570 > 556 > recs["solar-out"].mean("wavelength") - 1e-9
+    faces = sum(recs[f"slab-{f}"].crossings for f in ("top", "bottom", "east", "west", "north", "south"))
+    assert faces == recs["all-out"].crossings
+    # the pure-Python tally (with the same source semantics) reproduces every recorder exactly
+    python_side = tally_histories(scene, result.histories())
+    for name, rec in recs.items():
+        assert python_side[name].rays == rec.rays and python_side[name].crossings == rec.crossings, name
+    # and the oracle agrees bit for bit
+    pos, dirs, wl, _ = emit_bundle(scene, 20000, seed=1)
+    cpu = O.trace_bundle(result.compiled, pos, dirs, wl, 3, 1000, 200, 0, 1, 1, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(result.data, cpu, sums_rtol=1e-12)
+
+
+def test_sharded_simulate_over_rccl_world_size_one():
+    """The N>1 code path (index-range shard + RCCL all-reduce of int64/f64 tallies) on the one
+    GPU we have: a single-rank nccl group must reproduce simulate() exactly."""
+    import torch.distributed as dist
+
+    from pvtrace_amd.engine.distributed import simulate_sharded
+
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    try:
+        scene = scenes.lsc_equivalent()
+        sharded = simulate_sharded(scene, 300000, seed=8, emit_seed=2, record_every=0, device=0)
+        whole = engine.simulate(scene, 300000, seed=8, record_every=0, emission="device", emit_seed=2)
+        for key in ("rec_distinct", "rec_crossings", "rec_bins"):
+            assert np.array_equal(sharded.data[key], whole.data[key]), key
+        assert sharded.shard == (0, 300000)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_unsupported_scene_and_bad_arguments_raise():

@@ -230,3 +230,49 @@ def test_coating_semantics_on_the_oracle():
     idx = np.flatnonzero(rows)
     assert idx.size > 100
     assert np.array_equal(out["direction"][idx], out["direction"][idx - 1])   # straight through the cell faces
+
+
+def test_source_filter_on_the_oracle_and_python_tally():
+    """Recorder(source=...) (extension): lights / components / a named component."""
+    from pvtrace_amd.engine.recorder import SOURCE_COMPONENT, SOURCE_COMPONENTS, SOURCE_LIGHTS
+
+    scene = scenes.bench_slab(recorders=False)
+    slab = scene.root.children[0]
+    slab.recorders = [Recorder("any", event="escaping"), Recorder("solar", event="escaping", source="lights"),
+                      Recorder("lum", event="escaping", source="components"),
+                      Recorder("dye", event="escaping", source="dye"),
+                      Recorder("bg", event="escaping", source="background")]
+    compiled = compile_scene(scene)
+    assert compiled.rec_source_mode.tolist() == [0, SOURCE_LIGHTS, SOURCE_COMPONENTS, SOURCE_COMPONENT, SOURCE_COMPONENT]
+    assert compiled.rec_source_id.tolist() == [-1, -1, -1, 0, 1]
+    pos, dirs, wl, src = emit_bundle(scene, 3000, seed=2)
+    data = O.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 256, 0, 1, 1)
+    result = EngineResult(compiled, data, src, 256, 1, 0.0)
+    recs = result.recorders
+    assert recs["any"].crossings == recs["solar"].crossings + recs["lum"].crossings
+    assert recs["lum"].rays == recs["dye"].rays > 0 and recs["bg"].rays == 0 and recs["solar"].rays > 0
+    python_side = tally_histories(scene, result.histories())
+    for name, rec in recs.items():
+        assert python_side[name].rays == rec.rays and python_side[name].crossings == rec.crossings, name
+    slab.recorders = [Recorder("bad", event="escaping", source="nobody")]
+    with pytest.raises(UnsupportedSceneError):
+        compile_scene(scene)
+
+
+def test_auto_recorders_match_the_reference_shorthand():
+    """reference tests/test_engine.py:376-415 (`record: true`): 6 faces + volume loss for a box."""
+    from pvtrace_amd.engine import auto_recorders, instrument
+
+    scene = scenes.bench_slab(recorders=False)
+    slab = scene.root.children[0]
+    recs = {r.name: r for r in auto_recorders(slab)}
+    assert len(recs) == 7 and recs["slab-top"].facet == (0.0, 0.0, 1.0) and "slab-lost" in recs
+    assert len(recs["slab-top"].histograms) == 3
+    assert recs["slab-top"].histograms[2].a.bins == 50 and recs["slab-east"].histograms[2].b.bins == 10
+    ball = Node(name="ball", geometry=Sphere(1.0, material=Material(1.5)))
+    assert {r.name for r in auto_recorders(ball)} == {"ball-lost", "ball-escaping"}
+    instrument(slab, explicit=[Recorder("slab-top", event="escaping", facet=(0, 0, 1))])
+    names = [r.name for r in slab.recorders]
+    assert len(names) == 7 and len(set(names)) == 7
+    assert len([r for r in slab.recorders if r.name == "slab-top"][0].histograms) == 0   # explicit wins
+    compile_scene(scene)
