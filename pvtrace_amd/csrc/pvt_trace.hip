@@ -81,7 +81,8 @@ struct Lay {  // record bases (elements) inside the blobs; spectra follow the re
               // addressed by absolute offsets stored in the component records
     int comp_d, rec_d, hist_d, coat_d;
     int comp_i, rec_i, hist_i, coat_i;
-    int cand_i;     // (n_nodes*7) x {start, count}: recorders that can fire for (node, selector)
+    int cand_i;     // (n_nodes*7) x {start, count, bin[6]}: recorders that can fire for a
+                    // (node, selector): a list to walk + facet recorders found by normal bin
     int cand_list;  // recorder ids, ascending within each (node, selector)
 };
 
@@ -1034,15 +1035,26 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         // chains, no software scan).  Recorder order per lane is ascending, as in the
         // reference's loop (_kernel.pyx:517-556).
         if (!ABL(0) && A.n_rec > 0) {
-            int cs = 0, cn = 0;
+            // Facet recorders whose facets have distinct dominant axes (the usual "one recorder
+            // per box face") are found in O(1): the host files each under the bin (dominant axis,
+            // sign) of its facet, the lane looks up the bin of ITS normal and verifies that one
+            // recorder with the full tolerance test (trip j = -1).  Everything else is walked.
+            int cs = 0, cn = 0, rbin = -1;
             if (alive && t_sel >= 0) {
-                const int key = L.cand_i + (t_node * 7 + t_sel) * 2;
+                const int key = L.cand_i + (t_node * 7 + t_sel) * 8;
                 cs = T.iv(key);
                 cn = T.iv(key + 1);
+                if (t_normal) {
+                    const double ax = pvt_fabs(nrm.x), ay = pvt_fabs(nrm.y), az = pvt_fabs(nrm.z);
+                    int b = (ax >= ay && ax >= az) ? (nrm.x > 0.0 ? 1 : 0)
+                          : (ay >= az)             ? (nrm.y > 0.0 ? 3 : 2)
+                                                   : (nrm.z > 0.0 ? 5 : 4);
+                    rbin = T.iv(key + 2 + b);
+                }
             }
-            for (int j = 0; __ballot(j < cn) != 0ull; j++) {
-                if (j < cn) {
-                    const int r = T.iv(L.cand_list + cs + j);
+            for (int j = -1; __ballot(j < 0 ? (rbin >= 0 || cn > 0) : j < cn) != 0ull; j++) {
+                if (j < 0 ? rbin >= 0 : j < cn) {
+                    const int r = j < 0 ? rbin : T.iv(L.cand_list + cs + j);
                     const int ri = L.rec_i + r * RI;
                     bool match = true;
                     const int smode = T.iv(ri + RI_SRC_MODE);  // source filter (extension)
@@ -1224,7 +1236,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.hist_i = lay.rec_i + R * RI;
     lay.coat_i = lay.hist_i + H * HI;
     lay.cand_i = lay.coat_i + K * KI;
-    lay.cand_list = lay.cand_i + N * 7 * 2;
+    lay.cand_list = lay.cand_i + N * 7 * 8;
     const int guide0 = lay.cand_list + R;  // guide tables: one entry per table point, per searched array
     std::vector<int> gi((size_t)guide0 + (size_t)t->n_abs + 2 * (size_t)t->n_ems + 1, 0);
     // guide[b] = largest i <= n-2 with xs[i] <= xs[0] + b*(xs[n-1]-xs[0])/(n-1), b = 0..n-1
@@ -1240,13 +1252,38 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             gi[at + b] = i;
         }
     };
-    {   // recorders grouped by the (node, selector) they listen to, ascending id within a group
+    {   // recorders grouped by the (node, selector) they listen to.  A facet recorder whose facet
+        // has a clearly dominant component, alone in its (axis, sign) bin, goes to the bin table;
+        // the rest (no facet, oblique facets, bin collisions) to the walked list, ascending id.
         int at = 0;
         for (int key = 0; key < N * 7; key++) {
-            gi[lay.cand_i + key * 2] = at;
-            for (int r = 0; r < R; r++)
-                if (t->rec_node[r] * 7 + t->rec_event[r] == key) gi[lay.cand_list + at++] = r;
-            gi[lay.cand_i + key * 2 + 1] = at - gi[lay.cand_i + key * 2];
+            int* rec = gi.data() + lay.cand_i + key * 8;
+            rec[0] = at;
+            int owner[6] = {-1, -1, -1, -1, -1, -1};
+            bool clash[6] = {false, false, false, false, false, false};
+            auto bin_of = [&](int r) -> int {
+                if (!t->rec_has_facet[r]) return -1;
+                const double* f = t->rec_facet + r * 3;
+                const double a[3] = {std::fabs(f[0]), std::fabs(f[1]), std::fabs(f[2])};
+                int k = (a[0] >= a[1] && a[0] >= a[2]) ? 0 : (a[1] >= a[2] ? 1 : 2);
+                const double other = std::fmax(a[(k + 1) % 3], a[(k + 2) % 3]);
+                // any normal within atol of the facet must have the same dominant axis and sign
+                if (!(a[k] - other > 4.0 * t->rec_atol[r] + 1e-9) || !(a[k] > 2.0 * t->rec_atol[r])) return -1;
+                return k * 2 + (f[k] > 0.0 ? 1 : 0);
+            };
+            for (int r = 0; r < R; r++) {
+                if (t->rec_node[r] * 7 + t->rec_event[r] != key) continue;
+                int b = bin_of(r);
+                if (b >= 0) { if (owner[b] >= 0) clash[b] = true; else owner[b] = r; }
+            }
+            for (int b = 0; b < 6; b++) rec[2 + b] = (owner[b] >= 0 && !clash[b]) ? owner[b] : -1;
+            for (int r = 0; r < R; r++) {
+                if (t->rec_node[r] * 7 + t->rec_event[r] != key) continue;
+                int b = bin_of(r);
+                if (b >= 0 && !clash[b]) continue;  // served by the bin table
+                gi[lay.cand_list + at++] = r;
+            }
+            rec[1] = at - rec[0];
         }
     }
     for (int n = 0; n < N; n++) {
