@@ -45,7 +45,7 @@
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
-#define ABL(bit) ((PVT_ABLATE >> (bit)) & 1)   // 0 tally, 1 fresnel, 2 emission wl, 3 phase, 4 interp, 5 refill rng
+#define ABL(bit) ((PVT_ABLATE >> (bit)) & 1)   // 0 tally, 2 emission wl, 4 merged acos+sincos, 5 depth log, 6 frame/normal
 
 namespace {
 
@@ -198,13 +198,16 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
     b = b < 0 ? 0 : (b > n - 2 ? n - 2 : b);
     int lo = T.iv(guide + b), hi = T.iv(guide + b + 1) + 1;
     if (hi > n - 1) hi = n - 1;
-    if (!(T.dv(xs + lo) <= x)) lo = 0;
-    if (!(x < T.dv(xs + hi))) hi = n - 1;
+    // the abscissae travel with the indices, so nothing is re-read after the search
+    double xlo = T.dv(xs + lo), xhi = T.dv(xs + hi);
+    if (!(xlo <= x)) { lo = 0; xlo = x0; }
+    if (!(x < xhi)) { hi = n - 1; xhi = xl; }
     while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (T.dv(xs + mid) <= x) lo = mid; else hi = mid;
+        const int mid = (lo + hi) >> 1;
+        const double xm = T.dv(xs + mid);
+        if (xm <= x) { lo = mid; xlo = xm; } else { hi = mid; xhi = xm; }
     }
-    double xlo = T.dv(xs + lo), xhi = T.dv(xs + hi), ylo = T.dv(ys + lo), yhi = T.dv(ys + hi);
+    const double ylo = T.dv(ys + lo), yhi = T.dv(ys + hi);
     if (xhi == xlo) return ylo;
     return ylo + (yhi - ylo) * (x - xlo) / (xhi - xlo);
 }
@@ -752,7 +755,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                 else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
                             }
                             double depth = INFINITY;
-                            if (alpha > kAlphaZero) depth = -pvt_log(1.0 - rng_uniform(rng)) / alpha;
+                            if (alpha > kAlphaZero) depth = ABL(5) ? rng_uniform(rng) / alpha : -pvt_log(1.0 - rng_uniform(rng)) / alpha;
 
                             if (depth < t0) {  // absorbed (:762-832)
                                 pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
@@ -928,14 +931,14 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             need_acos = true;
         }
         double ac = 0.0;
-        if (need_acos) ac = pvt_acos(ac_arg);
+        if (need_acos) ac = ABL(4) ? 1.5 - ac_arg : pvt_acos(ac_arg);
         if (alive && t_normal) t_angle = ac;
         const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
         double s1 = 0.0, c1 = 1.0;
-        if (em || fres) pvt_sincos(em ? (em_acos ? ac : em_x) : ac, &s1, &c1);
+        if (em || fres) { if (ABL(4)) { s1 = ac * 0.6; c1 = 1.0 - 0.5 * ac * ac * 0.3; } else pvt_sincos(em ? (em_acos ? ac : em_x) : ac, &s1, &c1); }
         if (em) {
             double sp, cp;
-            pvt_sincos(em_phi, &sp, &cp);
+            if (ABL(4)) { sp = em_phi * 0.1; cp = 1.0 - sp * sp; } else pvt_sincos(em_phi, &sp, &cp);
             dir = V3{s1 * cp, s1 * sp, c1};
         }
 
