@@ -321,3 +321,32 @@ EXTENSION_SCENES = {   # need the coating extension
     "lambertian_sheet": lambertian_sheet,
 }
 ALL_SCENES = dict(REFERENCE_SCENES, **EXTENSION_SCENES)
+
+
+def bose_fluro_red_sample(depth=0.26):
+    """The FULLSPECTRUM validation sample (reference examples/Validation.ipynb cell 6 and
+    tests/test_3D_flux_comparison.py:11-64): 4.8 x 1.8 x `depth` cm plate, Fluro Red dye
+    (peak 11.387815 cm^-1, qy 0.95) + 0.02 cm^-1 host absorption, n = 1.5, uniform
+    top-surface illumination with the fitted lamp spectrum.  Returns an `LSC` object
+    (built-in light delegates, so it also runs with device-side emission)."""
+    from pvtrace_amd import LSC
+    from pvtrace_amd.data import fluro_red
+    from pvtrace_amd.light import RectangularMask
+
+    x = np.arange(400, 801, dtype=float)
+    size = (l, w, d) = (4.8, 1.8, depth)
+    lsc = LSC(size, wavelength_range=x, n1=1.5)
+    lsc.add_luminophore("Fluro Red", np.column_stack((x, fluro_red.absorption(x) * 11.387815)),
+                        np.column_stack((x, fluro_red.emission(x))), quantum_yield=0.95)
+    lsc.add_absorber("PMMA", 0.02)
+
+    def g(v, a, p, wd):
+        return a * np.exp(-(((p - v) / wd) ** 2))
+
+    lamp = (g(x, 0.53025700136646192, 512.91400020614333, 93.491838802960473)
+            + g(x, 0.63578999789955015, 577.63100003089369, 66.031706473985736))
+    lsc.add_light("Oriel Lamp + Filter", (0.0, 0.0, 0.5 * d + 0.01),
+                  rotation=(np.radians(180), (1, 0, 0)),
+                  wavelength=SpectrumWavelengthMask(Distribution(x, lamp)),
+                  position=RectangularMask(l / 2, w / 2))
+    return lsc

@@ -135,3 +135,36 @@ def Event_TRANSMIT():
 def Event_REFLECT():
     from pvtrace_amd.light import Event
     return Event.REFLECT
+
+
+def test_published_physics_validation_numbers():
+    """The reference's own physics validation (examples/Validation.ipynb cells 8-14):
+    exit percentages of the Bose Fluro-Red sample, pvtrace 48.79 / 13.84 / 7.02 / 5.58 %
+    (bottom / top / long edge / short edge, +-1.2 / 1.0 / 1.0 / 0.7 from 10x1000 rays) next to
+    three independent codes (ICL ray trace 49.2/13.6/7.3/6.6, ICL 3D flux 49.9/13.8/7.1/5.8,
+    ECN 49.7/13.6/7.2/6.4); and tests/test_3D_flux_comparison.py: edge 0.25, escape 0.64,
+    lost 0.11 (atol 0.04).  Here with 10^6 photons (sigma ~ 0.05 %)."""
+    n = 1_000_000
+    lsc = scenes.bose_fluro_red_sample(0.26)
+    lsc.simulate(n, seed=3, emit_method="redshift", emission="device", emit_seed=4)
+    c = lsc.counts()
+    pct = {f: 100.0 * (c["Solar Out"][f] + c["Luminescent Out"][f]) / n
+           for f in ("left", "right", "near", "far", "top", "bottom")}
+    assert abs(pct["bottom"] - 48.79) < 2.0 and 47.0 < pct["bottom"] < 51.0
+    assert abs(pct["top"] - 13.84) < 1.5
+    long_edge = 0.5 * (pct["near"] + pct["far"])
+    short_edge = 0.5 * (pct["left"] + pct["right"])
+    assert abs(long_edge - 7.02) < 1.0 and abs(short_edge - 5.58) < 1.2
+    assert abs(pct["near"] - pct["far"]) < 0.3 and abs(pct["left"] - pct["right"]) < 0.3   # symmetry
+    # 3D-flux comparison (0.25 cm plate)
+    lsc = scenes.bose_fluro_red_sample(0.25)
+    r = lsc.simulate(n, seed=5, emit_method="redshift", emission="device", emit_seed=6)
+    c = lsc.counts()
+    out = {f: c["Solar Out"][f] + c["Luminescent Out"][f] for f in ("left", "right", "near", "far", "top", "bottom")}
+    incident = c["Solar In"]["top"] + r.recorders["solar-reflected-top"].rays
+    assert abs(incident - n) <= 5                     # every lamp photon meets the top face
+    edge = (out["left"] + out["right"] + out["near"] + out["far"]) / incident
+    escape = (out["top"] + out["bottom"]) / incident
+    lost = r.recorders["lost"].rays / incident
+    assert abs(edge - 0.25) < 0.04 and abs(escape - 0.64) < 0.04 and abs(lost - 0.11) < 0.04
+    assert abs(edge + escape + lost - 1.0) < 1e-4
