@@ -17,3 +17,4 @@ from pvtrace_amd.material import (
 from pvtrace_amd.scene import Node, Scene
 from pvtrace_amd import engine
 from pvtrace_amd.device.lsc import LSC
+from pvtrace_amd import spec
