@@ -102,7 +102,7 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("PVT_BENCH_FORCE_DIST") == "1"  # (1-rank RCCL self-test)
     if not native.library_built():
         entry.build()
     if not native.is_available():
