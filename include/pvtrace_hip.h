@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 2
+#define PVT_ABI_VERSION 3
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -119,6 +119,12 @@ typedef struct PvtSceneTables {
      * light (source id < 0), 2 by any component, 3 by component rec_source_id */
     const int32_t* rec_source_mode;
     const int32_t* rec_source_id;
+    /* histogram-sampled spectra (extension; NULL = all interpolated).  The reference engine
+     * rejects hist=True distributions (compiler.py:274-279, :313-317); semantics follow the
+     * Python Distribution's hist branch (material/distribution.py:82-84, :127-129, :171-176):
+     * value(x) = y[#{x_i < x}], sample(p) = x[#{cdf_i < p}], no interpolation. */
+    const int32_t* comp_abs_hist;
+    const int32_t* comp_ems_hist;
 } PvtSceneTables;
 
 /* ---- optional device-side emission (replaces the Python/numpy emitter,

@@ -57,6 +57,8 @@ def lib():
         L.pvt_oracle_fresnel_reflectivity.restype = C.c_double
         L.pvt_oracle_interp.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         L.pvt_oracle_interp.restype = C.c_double
+        L.pvt_oracle_step_lookup.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+        L.pvt_oracle_step_lookup.restype = C.c_double
         L.pvt_oracle_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pvt_oracle_intersect.restype = C.c_int
         L.pvt_oracle_normal.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -182,6 +184,11 @@ def specular_reflect(d, normal):
 def interp(x, xs, ys):
     xs = np.ascontiguousarray(xs, dtype=np.float64); ys = np.ascontiguousarray(ys, dtype=np.float64)
     return lib().pvt_oracle_interp(float(x), xs.ctypes.data, ys.ctypes.data, xs.size)
+
+
+def step_lookup(x, xs, ys):
+    xs = np.ascontiguousarray(xs, dtype=np.float64); ys = np.ascontiguousarray(ys, dtype=np.float64)
+    return lib().pvt_oracle_step_lookup(float(x), xs.ctypes.data, ys.ctypes.data, xs.size)
 
 
 def intersect(geom_type, params, origin, direction):

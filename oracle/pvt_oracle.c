@@ -100,6 +100,25 @@ static double interp_clamped(double x, const double* xs, const double* ys, int n
     return ys[lo] + (ys[hi] - ys[lo]) * (x - xs[lo]) / (xs[hi] - xs[lo]);
 }
 
+/* EXTENSION: histogram-sampled table (Distribution hist branch, material/distribution.py:82-84,
+ * :127-129, :171-176): value = ys[#{xs_i < x}] (numpy searchsorted 'left'), index clamped to the
+ * table.  Used for coefficient(x), lookup(x) on (x, cdf) and sample(p) on (cdf, x). */
+static double step_lookup(double x, const double* xs, const double* ys, int n) {
+    int count = 0;
+    if (n == 1 || x <= xs[0]) return ys[0];
+    if (x > xs[n - 1]) return ys[n - 1];
+    int lo = 0, hi = n - 1; /* xs[lo] < x <= xs[hi] */
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xs[mid] < x) lo = mid; else hi = mid;
+    }
+    count = hi;
+    return ys[count];
+}
+static inline double table_value(int hist, double x, const double* xs, const double* ys, int n) {
+    return hist ? step_lookup(x, xs, ys, n) : interp_clamped(x, xs, ys, n);
+}
+
 /* ---- intersections in the local frame (_kernel.pyx:245-356) ------------- */
 static int hit_box(const double* size, const double* o, const double* d, double* ts) {
     double tmin = -INFINITY, tmax = INFINITY;
@@ -462,8 +481,8 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
         double alpha = 0.0;
         for (int k = 0; k < ccount; k++) {
             int c = cbase + k;
-            alpha += interp_clamped(wl, S->abs_x + S->comp_abs_start[c], S->abs_y + S->comp_abs_start[c],
-                                    S->comp_abs_n[c]);
+            alpha += table_value(S->comp_abs_hist ? S->comp_abs_hist[c] : 0, wl, S->abs_x + S->comp_abs_start[c],
+                                 S->abs_y + S->comp_abs_start[c], S->comp_abs_n[c]);
         }
         double depth = INFINITY;
         if (alpha > ALPHA_ZERO) depth = -m_log(M, 1.0 - rng_uniform(&rng)) / alpha;
@@ -475,8 +494,9 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
             double target = rng_uniform(&rng) * alpha, running = 0.0;
             int comp = cbase;
             for (int k = 0; k < ccount; k++) {
-                running += interp_clamped(wl, S->abs_x + S->comp_abs_start[cbase + k],
-                                          S->abs_y + S->comp_abs_start[cbase + k], S->comp_abs_n[cbase + k]);
+                running += table_value(S->comp_abs_hist ? S->comp_abs_hist[cbase + k] : 0, wl,
+                                       S->abs_x + S->comp_abs_start[cbase + k],
+                                       S->abs_y + S->comp_abs_start[cbase + k], S->comp_abs_n[cbase + k]);
                 if (target <= running) { comp = cbase + k; break; }
             }
             record(L, max_events, base, &nevents, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
@@ -491,6 +511,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
                     const double* ax = S->ems_x + S->comp_ems_start[comp];
                     const double* ay = S->ems_cdf + S->comp_ems_start[comp];
                     int an = S->comp_ems_n[comp];
+                    int ehist = S->comp_ems_hist ? S->comp_ems_hist[comp] : 0;
                     double p1;
                     if (emit_method == PVT_EMIT_FULL) {
                         p1 = 0.0;
@@ -500,10 +521,10 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
                             double e_ev = 1240.0 / e_nm + 1.5 * KB_EV * 300.0;
                             e_nm = 1240.0 / e_ev;
                         }
-                        p1 = interp_clamped(e_nm, ax, ay, an);
+                        p1 = table_value(ehist, e_nm, ax, ay, an);
                     }
                     double gamma = p1 + (1.0 - p1) * rng_uniform(&rng);
-                    wl = interp_clamped(gamma, ay, ax, an);
+                    wl = table_value(ehist, gamma, ay, ax, an);
                     if (S->comp_tau_rad[comp] > 0.0)
                         duration += -m_log(M, 1.0 - rng_uniform(&rng)) * S->comp_tau_rad[comp];
                     record(L, max_events, base, &nevents, PVT_EV_EMIT, -1, container, -1, comp, source,
@@ -774,6 +795,9 @@ void pvt_oracle_specular_reflect(const double* d, const double* normal, double* 
 }
 double pvt_oracle_interp(double x, const double* xs, const double* ys, int n) {
     return interp_clamped(x, xs, ys, n);
+}
+double pvt_oracle_step_lookup(double x, const double* xs, const double* ys, int n) {
+    return step_lookup(x, xs, ys, n);
 }
 int pvt_oracle_intersect(int geom_type, const double* params, const double* o, const double* d, double* ts) {
     switch (geom_type) {

@@ -69,7 +69,7 @@ enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND = 26 };           
 enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI };  // node ints
 enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C, CD };                         // component doubles
 enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N,
-       CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI };  // *_G*: guide tables (bucket -> bracketing index)
+       CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI_ABS_HIST, CI_EMS_HIST, CI };  // *_G*: guide tables; *_HIST: step tables
 enum { RD_FACET = 0, RD_ATOL = 3, RD = 4 };                                     // recorder
 enum { RI_NODE = 0, RI_EVENT, RI_HAS_FACET, RI_HSTART, RI_HN, RI_SRC_MODE, RI_SRC_ID, RI };
 enum { HD_LO_A = 0, HD_HI_A, HD_LO_B, HD_HI_B, HD };                             // histogram
@@ -189,17 +189,28 @@ __device__ __forceinline__ double dot3(const V3& a, const V3& b) { return a.x * 
 // runs inside the bracket: typically 0-1 steps instead of ~log2(n) dependent LDS reads.
 template <bool TAB_LDS>
 __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n,
-                                                 int guide, double scale) {
+                                                 int guide, double scale, int hist) {
     if (n == 1) return T.dv(ys);
     const double x0 = T.dv(xs), xl = T.dv(xs + n - 1);
     if (x <= x0) return T.dv(ys);
-    if (x >= xl) return T.dv(ys + n - 1);
+    if (hist ? x > xl : x >= xl) return T.dv(ys + n - 1);  // step tables search x == xl (plateaus)
     int b = (int)((x - x0) * scale);
     b = b < 0 ? 0 : (b > n - 2 ? n - 2 : b);
     int lo = T.iv(guide + b), hi = T.iv(guide + b + 1) + 1;
     if (hi > n - 1) hi = n - 1;
     // the abscissae travel with the indices, so nothing is re-read after the search
     double xlo = T.dv(xs + lo), xhi = T.dv(xs + hi);
+    if (hist) {
+        // histogram-sampled table (extension; Python Distribution's hist branch): the value of
+        // the first abscissa >= x, i.e. ys[#{xs_i < x}] — same bracket, strict comparison
+        if (!(xlo < x)) lo = 0;          // xs[0] < x is known here
+        if (!(x <= xhi)) hi = n - 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (T.dv(xs + mid) < x) lo = mid; else hi = mid;
+        }
+        return T.dv(ys + hi);
+    }
     if (!(xlo <= x)) { lo = 0; xlo = x0; }
     if (!(x < xhi)) { hi = n - 1; xhi = xl; }
     while (hi - lo > 1) {
@@ -446,6 +457,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
 
 #if PVT_STATS
     unsigned long long st_iters = 0, st_lane_steps = 0, st_drain_iters = 0, st_drain_lane_steps = 0;
+    unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_mark = 0;
+#define PVT_MARK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); if (solo) st_t[k] += now_ - st_mark; st_mark = now_; } while (0)
+#else
+#define PVT_MARK(k) do {} while (0)
 #endif
     // wave-uniform ray window claimed from the global cursor
     unsigned int w_next = 0, w_end = 0;
@@ -603,6 +618,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         }
 #endif
 
+        PVT_MARK(0);  // refill + drain bookkeeping
         // ================= one step for every live lane ==================
         // deferred event of this step
         int ev_kind = -1, ev_hit = -1, ev_container = -1, ev_adjacent = -1, ev_component = -1;
@@ -713,6 +729,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     if (nl == 1 && tfirst < cbest) { cbest = tfirst; cnode = node; }
                 }
 
+                PVT_MARK(1);  // node loop
                 if (nhits == 0) {
                     terminal = true;  // nothing ahead: the ray vanishes silently (:681-682)
                 } else {
@@ -750,7 +767,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                             for (int k = 0; k < ccount; k++) {
                                 const int ci = L.comp_i + (cbase + k) * CI;
                                 alpha += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
-                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE));
+                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST));
                                 if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
                                 else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
                             }
@@ -773,7 +790,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                     for (int k = 0; k < ccount; k++) {
                                         const int ci = L.comp_i + (cbase + k) * CI;
                                         running += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
-                                                                  T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE));
+                                                                  T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST));
                                         if (target <= running) { comp = cbase + k; break; }
                                     }
                                 }
@@ -823,10 +840,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                                 double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
                                                 e_nm = 1240.0 / e_ev;
                                             }
-                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_X));
+                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_X), T.iv(ci + CI_EMS_HIST));
                                         }
                                         double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
-                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_C));
+                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_C), T.iv(ci + CI_EMS_HIST));
                                         tau = T.dv(L.comp_d + comp * CD + CD_TAU_RAD);
                                         ev_kind = PVT_EV_EMIT;
                                     } else {
@@ -861,6 +878,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             }
         }
 
+        PVT_MARK(2);  // classification + absorption + emission draws
         // ---- local point + outward world normal of the node the event refers to.
         // Shared by EXIT and surface events (re-converged: one copy of the code).
         const bool need_frame = alive && (t_normal || (t_sel >= 0 && t_node >= 0));
@@ -909,6 +927,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             }
         }
 
+        PVT_MARK(3);  // frame + normal
         // ---- shared transcendental sites --------------------------------------
         // Re-emitting lanes (new direction), surface lanes (incidence angle + Fresnel) and
         // exiting lanes (exit angle) all need an acos, the first two a sincos of its result:
@@ -942,6 +961,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             dir = V3{s1 * cp, s1 * sp, c1};
         }
 
+        PVT_MARK(4);  // acos + sincos
         if (surf) {
             // ---- Fresnel / coating decision at the surface (:865-895) ------------
             const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
@@ -1025,6 +1045,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             }
         }
 
+        PVT_MARK(5);  // fresnel / reflect / refract
         // ================= deferred event: log row + tallies ==============
         if (alive && ev_kind >= 0)
             log_row<RECORD>(A, base, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
@@ -1123,6 +1144,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             }
         }
 
+        PVT_MARK(6);  // log + tally
         if (alive && terminal) {
             if constexpr (RECORD) {
                 if (base >= 0) A.log.counts[rec_slot] = nev;
@@ -1137,6 +1159,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         atomicAdd(c + 0, st_iters); atomicAdd(c + 1, st_lane_steps);
         atomicAdd(c + 2, st_drain_iters); atomicAdd(c + 3, st_drain_lane_steps);
         atomicAdd(c + 4, 1ull);
+        for (int k = 0; k < 7; k++) atomicAdd(c + 8 + k, st_t[k]);
+        atomicAdd(c + 15, solo ? 1ull : 0ull);
     }
 #endif
     // ---- flush workgroup accumulators: done by the LAST wave to leave -------
@@ -1320,6 +1344,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[CI_EMS_X] = ems_x0 + t->comp_ems_start[c];
         q[CI_EMS_CDF] = ems_c0 + t->comp_ems_start[c];
         q[CI_EMS_N] = t->comp_ems_n[c];
+        q[CI_ABS_HIST] = t->comp_abs_hist ? t->comp_abs_hist[c] : 0;
+        q[CI_EMS_HIST] = t->comp_ems_hist ? t->comp_ems_hist[c] : 0;
         q[CI_ABS_G] = guide0 + t->comp_abs_start[c];
         q[CI_EMS_GX] = guide0 + t->n_abs + t->comp_ems_start[c];
         q[CI_EMS_GC] = guide0 + t->n_abs + t->n_ems + t->comp_ems_start[c];
@@ -1505,6 +1531,12 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     }
     a.cursor = s->d_cursor + 16 * (s->launches.fetch_add(1) % kCursorSlots);
     HIP_TRY(hipMemsetAsync(a.cursor, 0, PVT_STATS ? 64 : 4, st));
+#if PVT_STATS
+    static unsigned long long* g_stats = nullptr;
+    if (!g_stats) (void)hipMalloc(&g_stats, 256);
+    (void)hipMemsetAsync(g_stats, 0, 256, st);
+    a.cursor = reinterpret_cast<unsigned int*>(g_stats);  // dev build: counters live in their own buffer
+#endif
 
     // LDS budget: tables (if they fit) + recorder accumulators (+ bins if they fit)
     const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 2 * 4);
@@ -1550,13 +1582,15 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
 #if PVT_STATS
     {
-        unsigned long long c[8];
+        unsigned long long c[32];
         (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(c, a.cursor, 64, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(c, a.cursor, 256, hipMemcpyDeviceToHost);
         fprintf(stderr, "[pvt stats] waves %llu  wave-iterations %llu (drain %llu)  lane-steps %llu (drain %llu)  "
                 "mean live lanes/iter %.1f (bulk %.1f, drain %.1f)  iters/wave %.1f (drain %.1f)\n",
                 c[5], c[1], c[3], c[2], c[4], (double)c[2] / c[1], (double)(c[2] - c[4]) / (double)(c[1] - c[3] + 1e-9),
                 (double)c[4] / (c[3] + 1e-9), (double)c[1] / c[5], (double)c[3] / c[5]);
+        fprintf(stderr, "[pvt stats] solo-wave cycles: refill %llu nodes %llu absorb %llu frame %llu trig %llu surface %llu tally %llu (solo waves %llu)\n",
+                c[9], c[10], c[11], c[12], c[13], c[14], c[15], c[16]);
     }
 #endif
     return PVT_OK;

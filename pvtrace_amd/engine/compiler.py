@@ -120,7 +120,7 @@ class CompiledScene:
             key: []
             for key in (
                 "type", "qy", "tau_rad", "tau_nr", "phase_type", "phase_param",
-                "abs_start", "abs_n", "ems_start", "ems_n",
+                "abs_start", "abs_n", "ems_start", "ems_n", "abs_hist", "ems_hist",
             )
         }
         coat_rows = []
@@ -158,6 +158,8 @@ class CompiledScene:
         self.comp_abs_n = np.array(comp_cols["abs_n"], dtype=_I32)
         self.comp_ems_start = np.array(comp_cols["ems_start"], dtype=_I32)
         self.comp_ems_n = np.array(comp_cols["ems_n"], dtype=_I32)
+        self.comp_abs_hist = np.array(comp_cols["abs_hist"], dtype=_I32)
+        self.comp_ems_hist = np.array(comp_cols["ems_hist"], dtype=_I32)
 
         self.abs_x = np.array(pools["abs_x"], dtype=_F64)
         self.abs_y = np.array(pools["abs_y"], dtype=_F64)
@@ -254,14 +256,10 @@ class CompiledScene:
         a_start, a_n = self._pool_spectrum(
             node, component._abs_dist, pools["abs_x"], pools["abs_y"]
         )
-        e_start, e_n = 0, 0
+        e_start, e_n, e_hist = 0, 0, 0
         if ctype == COMP_LUMINOPHORE:
             dist = component._ems_dist
-            if dist.hist:
-                raise UnsupportedSceneError(
-                    f"Node {node.name!r}: histogram-sampled emission spectra "
-                    "are not supported."
-                )
+            e_hist = 1 if dist.hist else 0   # histogram-sampled emission (extension, see header)
             e_start = len(pools["ems_x"])
             pools["ems_x"].extend(np.asarray(dist._x, dtype=_F64).tolist())
             pools["ems_cdf"].extend(np.asarray(dist._cdf, dtype=_F64).tolist())
@@ -277,12 +275,13 @@ class CompiledScene:
         cols["abs_n"].append(a_n)
         cols["ems_start"].append(e_start)
         cols["ems_n"].append(e_n)
+        cols["abs_hist"].append(1 if (component._abs_dist.hist and component._abs_dist._x is not None) else 0)
+        cols["ems_hist"].append(e_hist)
 
     def _pool_spectrum(self, node, dist, xs, ys):
-        if dist.hist:
-            raise UnsupportedSceneError(
-                f"Node {node.name!r}: histogram-sampled spectra are not supported."
-            )
+        # hist=True spectra are pooled like interpolated ones; the per-component hist flag
+        # switches the device lookup to the step-function rule (extension: the reference
+        # compiler raises here, compiler.py:313-317)
         start = len(xs)
         if dist._x is None:
             # constant coefficient -> a one-point table
@@ -384,7 +383,7 @@ class CompiledScene:
         "refractive_index", "surface_type", "comp_start", "comp_count",
         "comp_type", "comp_qy", "comp_tau_rad", "comp_tau_nr",
         "comp_phase_type", "comp_phase_param", "comp_abs_start", "comp_abs_n",
-        "comp_ems_start", "comp_ems_n", "abs_x", "abs_y", "ems_x", "ems_cdf",
+        "comp_ems_start", "comp_ems_n", "comp_abs_hist", "comp_ems_hist", "abs_x", "abs_y", "ems_x", "ems_cdf",
         "rec_node", "rec_event", "rec_has_facet", "rec_facet", "rec_atol",
         "rec_hist_start", "rec_hist_n", "rec_source_mode", "rec_source_id", "hist_prop_a", "hist_prop_b", "hist_na",
         "hist_nb", "hist_lo_a", "hist_hi_a", "hist_lo_b", "hist_hi_b",

@@ -52,6 +52,7 @@ class PvtSceneTables(C.Structure):
         ("coat_reflectivity", _p_f64), ("coat_reflect_mode", _p_i32),
         ("coat_transmit_mode", _p_i32),
         ("rec_source_mode", _p_i32), ("rec_source_id", _p_i32),
+        ("comp_abs_hist", _p_i32), ("comp_ems_hist", _p_i32),
     ]
 
 

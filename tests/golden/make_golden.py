@@ -174,6 +174,19 @@ def make_lsc_tallies():
          rec_sums=ref["rec_sums"], rec_bins=ref["rec_bins"], **table_dump(compiled))
 
 
+def make_hist_spectra():
+    """Histogram-sampled Distribution (hist=True) known answers from the reference class."""
+    dist = ref_module("pvtrace.material.distribution")
+    rng = np.random.default_rng(8)
+    x = np.array([400.0, 410.0, 425.0, 430.0, 455.0, 500.0, 520.0, 600.0, 610.0, 700.0])
+    y = np.array([0.0, 0.0, 1.0, 3.0, 2.0, 0.0, 0.0, 4.0, 1.0, 0.0])     # zero runs -> CDF plateaus
+    d = dist.Distribution(x, y, hist=True)
+    q = np.concatenate((x, rng.uniform(400.0, 700.0, 200)))
+    p = np.concatenate(([0.0, 1.0], np.asarray(d._cdf), rng.random(200)))
+    save("spectra_hist.npz", x=x, y=y, cdf=np.asarray(d._cdf), query_x=q, value=np.asarray(d(q)),
+         lookup=np.asarray(d.lookup(q)), query_p=p, sample=np.asarray(d.sample(p)))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
@@ -183,3 +196,6 @@ if __name__ == "__main__":
     make_transforms()
     make_traces()
     make_lsc_tallies()
+    make_hist_spectra()
+
+

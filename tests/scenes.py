@@ -306,6 +306,29 @@ def lambertian_sheet():
     return Scene(world)
 
 
+def hist_slab():
+    """Histogram-sampled spectra (hist=True; the reference engine rejects these, its Python
+    Distribution defines them): a dye with step-function absorption and emission tables."""
+    xa = np.array([380.0, 420.0, 470.0, 500.0, 530.0, 560.0, 600.0, 650.0])
+    ya = np.array([0.0, 0.5, 2.0, 4.0, 3.0, 1.0, 0.2, 0.0])
+    xe = np.array([520.0, 560.0, 590.0, 610.0, 640.0, 680.0, 720.0, 760.0])
+    ye = np.array([0.0, 1.0, 3.0, 4.0, 2.0, 1.0, 0.0, 0.0])
+    world = Node(name="world", geometry=Box((30.0, 30.0, 30.0), material=Material(refractive_index=1.0)))
+    slab = Node(name="slab", parent=world, geometry=Box((6.0, 6.0, 0.8), material=Material(
+        refractive_index=1.5, components=[
+            Luminophore(np.column_stack((xa, ya)), emission=np.column_stack((xe, ye)), hist=True,
+                        quantum_yield=0.9, name="step-dye"),
+            Absorber(np.column_stack((xa, 0.05 + 0.0 * ya)), hist=True, name="step-host")])))
+    slab.recorders = face_recorders(hist=False) + [
+        Recorder("out-spectrum", event="escaping", histograms=[Histogram("wavelength", 380, 780, 40)])]
+    spectrum = Distribution(np.linspace(400.0, 620.0, 23), gaussian(np.linspace(400.0, 620.0, 23), 1.0, 500.0, 50.0))
+    light = Node(name="lamp", parent=world, light=Light(wavelength=SpectrumWavelengthMask(spectrum),
+                                                        direction=Cone(0.4), name="lamp"))
+    light.location = (0.0, 0.0, 4.0)
+    light.rotate(np.pi, (1, 0, 0))
+    return Scene(world)
+
+
 REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
     "hello_world": hello_world,
     "lsc_equivalent": lsc_equivalent,
@@ -319,6 +342,7 @@ REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
 EXTENSION_SCENES = {   # need the coating extension
     "coated_slab": coated_slab,
     "lambertian_sheet": lambertian_sheet,
+    "hist_slab": hist_slab,
 }
 ALL_SCENES = dict(REFERENCE_SCENES, **EXTENSION_SCENES)
 

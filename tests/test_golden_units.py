@@ -157,3 +157,19 @@ def test_transformable_and_node_poses_golden():
     p = (0.3, -0.2, 0.9)
     assert np.allclose(world.point_to_node(b.point_to_node(p, world), b), p)
     assert np.allclose(np.linalg.norm(b.vector_to_node((0, 0, 1), world)), 1.0)
+
+
+def test_histogram_sampled_distribution_golden():
+    """hist=True spectra (extension over the reference ENGINE, which rejects them): the step-table
+    rule of the reference's Python Distribution, pinned by vectors from that class."""
+    g = load("spectra_hist.npz")
+    d = Distribution(g["x"], g["y"], hist=True)
+    assert np.array_equal(d._cdf, g["cdf"])
+    assert np.array_equal(d(g["query_x"]), g["value"])
+    assert np.array_equal(d.lookup(g["query_x"]), g["lookup"])
+    assert np.array_equal(d.sample(g["query_p"]), g["sample"])
+    for q, v, l in zip(g["query_x"], g["value"], g["lookup"]):
+        assert O.step_lookup(q, g["x"], g["y"]) == v
+        assert O.step_lookup(q, g["x"], g["cdf"]) == l
+    for p, s in zip(g["query_p"], g["sample"]):
+        assert O.step_lookup(p, g["cdf"], g["x"]) == s, p

@@ -70,9 +70,11 @@ def test_compile_rejects_what_the_reference_rejects():
         compile_scene(scene_with(Material(1.5, surface=Surface(delegate=Custom()))))
     with pytest.raises(UnsupportedSceneError):   # custom phase function
         compile_scene(scene_with(Material(1.5, components=[Scatterer(1.0, phase_function=lambda: (0, 0, 1))])))
-    with pytest.raises(UnsupportedSceneError):   # histogram-sampled spectrum
-        x = np.linspace(400, 800, 10)
-        compile_scene(scene_with(Material(1.5, components=[Absorber(np.column_stack((x, x * 0 + 1)), hist=True)])))
+    # histogram-sampled spectra: the reference compiler raises (compiler.py:313-317); here they are
+    # lowered with a per-component flag (extension)
+    x = np.linspace(400, 800, 10)
+    ch = compile_scene(scene_with(Material(1.5, components=[Absorber(np.column_stack((x, x * 0 + 1)), hist=True)])))
+    assert ch.comp_abs_hist.tolist() == [1] and ch.comp_ems_hist.tolist() == [0]
     with pytest.raises(UnsupportedSceneError):   # geometry without material
         compile_scene(scene_with(None))
     with pytest.raises(UnsupportedSceneError):   # facet on a volume event
