@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 3
+#define PVT_ABI_VERSION 4
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -36,7 +36,7 @@ enum {
     PVT_EV_REACT = 8, PVT_EV_KILL = 9
 };
 /* geometry / surface / component / phase / emit-method tags (compiler.py:25-48) */
-enum { PVT_GEOM_BOX = 0, PVT_GEOM_SPHERE = 1, PVT_GEOM_CYLINDER = 2 };
+enum { PVT_GEOM_BOX = 0, PVT_GEOM_SPHERE = 1, PVT_GEOM_CYLINDER = 2, PVT_GEOM_MESH = 3 };
 enum { PVT_SURF_FRESNEL = 0, PVT_SURF_NULL = 1 };
 enum { PVT_COMP_ABSORBER = 0, PVT_COMP_SCATTERER = 1, PVT_COMP_LUMINOPHORE = 2, PVT_COMP_REACTOR = 3 };
 enum { PVT_PHASE_ISOTROPIC = 0, PVT_PHASE_HG = 1, PVT_PHASE_CONE = 2 };
@@ -125,6 +125,21 @@ typedef struct PvtSceneTables {
      * value(x) = y[#{x_i < x}], sample(p) = x[#{cdf_i < p}], no interpolation. */
     const int32_t* comp_abs_hist;
     const int32_t* comp_ems_hist;
+    /* triangle meshes (extension; geom_type PVT_GEOM_MESH).  The reference engine rejects
+     * Mesh nodes (compiler.py:220-223); its Python tracer traces them through trimesh
+     * (geometry/mesh.py:44-61).  Semantics here: every forward crossing (t > EPS) of the
+     * node-local ray with a face is a hit, exactly as for the analytic shapes, so the
+     * container rule (_kernel.pyx:684-714) applies unchanged; the normal of a hit is the
+     * face normal (geometry/mesh.py:63-86).  The ray/triangle test is the watertight
+     * shear-and-edge-function test with a half-plane tie rule for exact zeros, so a ray
+     * through a shared edge or vertex crosses the surface exactly once.  Vertices are in
+     * the node's local frame (already centred on the centre of mass, mesh.py:17). */
+    int32_t n_mesh_vertices, n_mesh_faces;
+    const int32_t* mesh_face_start; /* (n_nodes) first face of the node's mesh, 0 if none */
+    const int32_t* mesh_face_count; /* (n_nodes) 0 for non-mesh nodes */
+    const double* mesh_vertices;    /* (n_mesh_vertices,3) pooled */
+    const int32_t* mesh_faces;      /* (n_mesh_faces,3) indices into the pooled vertices */
+    const double* mesh_normals;     /* (n_mesh_faces,3) outward unit face normals */
 } PvtSceneTables;
 
 /* ---- optional device-side emission (replaces the Python/numpy emitter,

@@ -62,6 +62,9 @@ def lib():
         L.pvt_oracle_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pvt_oracle_intersect.restype = C.c_int
         L.pvt_oracle_normal.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pvt_oracle_mesh_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int]
+        L.pvt_oracle_mesh_hits.restype = C.c_int
         L.pvt_oracle_uniforms.argtypes = [C.c_uint64, C.c_void_p, C.c_int]
         L.pvt_oracle_fresnel_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.pvt_oracle_specular_reflect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -205,6 +208,17 @@ def normal(geom_type, params, point):
     out = np.zeros(3)
     lib().pvt_oracle_normal(geom_type, prm.ctypes.data, p.ctypes.data, out.ctypes.data)
     return out
+
+
+def mesh_hits(vertices, faces, origin, direction):
+    """(t, face) of every forward crossing of a ray with a triangle list, in face order."""
+    v = np.ascontiguousarray(vertices, dtype=np.float64); f = np.ascontiguousarray(faces, dtype=np.int32)
+    o = np.ascontiguousarray(origin, dtype=np.float64); d = np.ascontiguousarray(direction, dtype=np.float64)
+    cap = max(len(f), 1)
+    ts = np.zeros(cap); tris = np.zeros(cap, dtype=np.int32)
+    n = lib().pvt_oracle_mesh_hits(v.ctypes.data, f.ctypes.data, len(f), o.ctypes.data, d.ctypes.data,
+                                   ts.ctypes.data, tris.ctypes.data, cap)
+    return ts[:n].copy(), tris[:n].copy()
 
 
 # ---------------------------------------------------------------------------

@@ -185,6 +185,69 @@ static int hit_cylinder(const double* prm, const double* o, const double* d, dou
         if (cand[i] > EPS) ts[n++] = cand[i];
     return n;
 }
+
+/* EXTENSION: triangle meshes (no counterpart in _kernel.pyx; the Python tracer delegates to
+ * trimesh, geometry/mesh.py:44-61).  Watertight ray/triangle test after Woop, Benthin & Wald,
+ * "Watertight Ray/Triangle Intersection" (JCGT 2013): translate the vertices to the ray origin,
+ * shear so the ray runs along +z, and evaluate the three 2-D edge functions at the origin.  An
+ * edge shared by two faces yields exactly negated edge values on the two sides (a*b - c*d versus
+ * c*d - a*b, no contraction), so a ray can never slip between them.  Exact zeros (ray through an
+ * edge or a vertex) are resolved by a half-plane rule: the face owns the edge iff its interior
+ * lies on the (+x, then +y) side of it, which assigns the crossing to exactly one face of a
+ * consistently wound fan.  Returns 1 and *t_out for a crossing (any t; the caller applies
+ * t > EPS as for the analytic shapes). */
+typedef struct { int kx, ky, kz; double sx, sy, sz; } RayShear;
+static void ray_shear(const double* d, RayShear* R) {
+    double ax = fabs(d[0]), ay = fabs(d[1]), az = fabs(d[2]);
+    int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
+    if (d[kz] < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
+    R->kx = kx; R->ky = ky; R->kz = kz;
+    R->sx = d[kx] / d[kz]; R->sy = d[ky] / d[kz]; R->sz = 1.0 / d[kz];
+}
+static int edge_owned(double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); }
+static int tri_hit(const RayShear* R, const double* o, const double* v0, const double* v1,
+                   const double* v2, double* t_out) {
+    double a[3] = {v0[0] - o[0], v0[1] - o[1], v0[2] - o[2]};
+    double b[3] = {v1[0] - o[0], v1[1] - o[1], v1[2] - o[2]};
+    double c[3] = {v2[0] - o[0], v2[1] - o[1], v2[2] - o[2]};
+    double ax = a[R->kx] - R->sx * a[R->kz], ay = a[R->ky] - R->sy * a[R->kz];
+    double bx = b[R->kx] - R->sx * b[R->kz], by = b[R->ky] - R->sy * b[R->kz];
+    double cx = c[R->kx] - R->sx * c[R->kz], cy = c[R->ky] - R->sy * c[R->kz];
+    double u = cx * by - cy * bx;
+    double v = ax * cy - ay * cx;
+    double w = bx * ay - by * ax;
+    if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) return 0;
+    double det = u + v + w;
+    if (det == 0.0) return 0;
+    double sg = det < 0.0 ? -1.0 : 1.0;
+    if (u == 0.0 && !edge_owned(sg * (cy - by), sg * (bx - cx))) return 0;
+    if (v == 0.0 && !edge_owned(sg * (ay - cy), sg * (cx - ax))) return 0;
+    if (w == 0.0 && !edge_owned(sg * (by - ay), sg * (ax - bx))) return 0;
+    double az = R->sz * a[R->kz], bz = R->sz * b[R->kz], cz = R->sz * c[R->kz];
+    *t_out = (u * az + v * bz + w * cz) / det;
+    return 1;
+}
+/* all forward crossings of one mesh node, brute force in face order; keeps the two smallest by
+ * (t, face) and the total count -- all the container rule needs */
+static int hit_mesh(const PvtSceneTables* S, int node, const double* o, const double* d,
+                    double* ts, int* tris) {
+    RayShear R;
+    ray_shear(d, &R);
+    int count = 0;
+    int f0 = S->mesh_face_start[node], f1 = f0 + S->mesh_face_count[node];
+    for (int f = f0; f < f1; f++) {
+        const int32_t* idx = S->mesh_faces + 3 * (long)f;
+        double t;
+        if (!tri_hit(&R, o, S->mesh_vertices + 3 * (long)idx[0], S->mesh_vertices + 3 * (long)idx[1],
+                     S->mesh_vertices + 3 * (long)idx[2], &t)) continue;
+        if (!(t > EPS)) continue;
+        if (count == 0 || t < ts[0]) { ts[1] = ts[0]; tris[1] = tris[0]; ts[0] = t; tris[0] = f; }
+        else if (count == 1 || t < ts[1]) { ts[1] = t; tris[1] = f; }
+        count += 1;
+    }
+    return count;
+}
 static int hit_node(const PvtSceneTables* S, int node, const double* o, const double* d, double* ts) {
     const double* prm = S->geom_params + node * 4;
     switch (S->geom_type[node]) {
@@ -195,10 +258,13 @@ static int hit_node(const PvtSceneTables* S, int node, const double* o, const do
 }
 
 /* outward normal at local point p (_kernel.pyx:359-400) */
-static void local_normal(const PvtSceneTables* S, int node, const double* p, double* out) {
+static void local_normal(const PvtSceneTables* S, int node, int tri, const double* p, double* out) {
     const double* prm = S->geom_params + node * 4;
     int g = S->geom_type[node];
-    if (g == PVT_GEOM_BOX) {
+    if (g == PVT_GEOM_MESH) { /* face normal of the crossed triangle (geometry/mesh.py:63-86) */
+        const double* fn = S->mesh_normals + 3 * (long)tri;
+        out[0] = fn[0]; out[1] = fn[1]; out[2] = fn[2];
+    } else if (g == PVT_GEOM_BOX) {
         double best = INFINITY;
         int best_axis = 0, best_sign = 1;
         for (int a = 0; a < 3; a++)
@@ -395,6 +461,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
     unsigned char seen[PVT_MAX_RECORDERS];
     double hit_t[PVT_MAX_HITS];
     int hit_node_id[PVT_MAX_HITS];
+    int hit_tri[PVT_MAX_HITS];
     int node_hits[PVT_MAX_NODES];
     double node_min_t[PVT_MAX_NODES];
     double lo[3], ld[3], lp[3], ts[8], nl[3], nrm[3], nf[3], nd[3];
@@ -419,9 +486,18 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
             node_min_t[node] = INFINITY;
             xform_point(S->world_to_local + node * 16, pos, lo);
             xform_vector(S->world_to_local + node * 16, dir, ld);
+            if (S->geom_type[node] == PVT_GEOM_MESH) {
+                int mt[2];
+                int total = hit_mesh(S, node, lo, ld, ts, mt);
+                for (int k = 0; k < total && k < 2; k++)
+                    if (nhits < PVT_MAX_HITS) { hit_t[nhits] = ts[k]; hit_node_id[nhits] = node; hit_tri[nhits] = mt[k]; nhits++; }
+                node_hits[node] = total;
+                if (total > 0) node_min_t[node] = ts[0];
+                continue;
+            }
             int nl_ = hit_node(S, node, lo, ld, ts);
             for (int k = 0; k < nl_; k++) {
-                if (nhits < PVT_MAX_HITS) { hit_t[nhits] = ts[k]; hit_node_id[nhits] = node; nhits++; }
+                if (nhits < PVT_MAX_HITS) { hit_t[nhits] = ts[k]; hit_node_id[nhits] = node; hit_tri[nhits] = -1; nhits++; }
                 node_hits[node] += 1;
                 if (ts[k] < node_min_t[node]) node_min_t[node] = ts[k];
             }
@@ -435,6 +511,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
         for (int i = 0; i < nhits; i++)
             if (i != first && (second < 0 || hit_t[i] < hit_t[second])) second = i;
         int hit = hit_node_id[first];
+        int tri0 = hit_tri[first];
         double t0 = hit_t[first];
         int container, adjacent;
         if (nhits == 1) {
@@ -467,7 +544,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
                    pos, dir, NULL, wl, travelled, duration);
             if (S->n_recorders > 0) {
                 xform_point(S->world_to_local + hit * 16, pos, lp);
-                local_normal(S, hit, lp, nl);
+                local_normal(S, hit, tri0, lp, nl);
                 xform_vector(S->local_to_world + hit * 16, nl, nrm);
                 double dd = fabs(dot3(nrm, dir));
                 if (dd > 1.0) dd = 1.0;
@@ -565,7 +642,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
             break;
         }
         xform_point(S->world_to_local + hit * 16, pos, lp);
-        local_normal(S, hit, lp, nl);
+        local_normal(S, hit, tri0, lp, nl);
         xform_vector(S->local_to_world + hit * 16, nl, nrm);
         nf[0] = nrm[0]; nf[1] = nrm[1]; nf[2] = nrm[2];
         if (dot3(nf, dir) < 0.0) { nf[0] = -nf[0]; nf[1] = -nf[1]; nf[2] = -nf[2]; }
@@ -812,7 +889,24 @@ void pvt_oracle_normal(int geom_type, const double* params, const double* p, dou
     int32_t g = geom_type;
     S.geom_type = &g;
     S.geom_params = params;
-    local_normal(&S, 0, p, out);
+    local_normal(&S, 0, -1, p, out);
+}
+/* every forward crossing (t > EPS) of a ray with a face list, in face order; returns the count
+ * (only the first `cap` are stored) */
+int pvt_oracle_mesh_hits(const double* vertices, const int32_t* faces, int n_faces, const double* o,
+                         const double* d, double* ts, int32_t* tris, int cap) {
+    RayShear R;
+    ray_shear(d, &R);
+    int count = 0;
+    for (int f = 0; f < n_faces; f++) {
+        double t;
+        if (!tri_hit(&R, o, vertices + 3 * (long)faces[3 * f], vertices + 3 * (long)faces[3 * f + 1],
+                     vertices + 3 * (long)faces[3 * f + 2], &t)) continue;
+        if (!(t > EPS)) continue;
+        if (count < cap) { ts[count] = t; tris[count] = f; }
+        count += 1;
+    }
+    return count;
 }
 void pvt_oracle_uniforms(uint64_t seed, double* out, int n) {
     Rng r;

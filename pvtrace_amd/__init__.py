@@ -5,7 +5,7 @@ __version__ = "0.1.0"
 
 from pvtrace_amd.common import AppError, GeometryError, TraceError
 from pvtrace_amd.data import fluro_red, lumogen_f_red_305
-from pvtrace_amd.geometry import Box, Cylinder, Sphere, Transformable
+from pvtrace_amd.geometry import Box, Cylinder, Mesh, Sphere, Transformable
 from pvtrace_amd.light import (
     Event, Light, Ray, circular_mask, cube_mask, rectangular_mask,
 )

@@ -1,0 +1,143 @@
+// Host-side construction of the triangle BVH the trace kernel walks for PVT_GEOM_MESH nodes.
+//
+// Layout is made for a per-lane, stack-free walk on the GPU: nodes are stored in depth-first
+// order and every node carries a `skip` link (index of the first node after its subtree), so
+// the traversal is `i = hit ? i + 1 : skip[i]` with no per-lane stack in scratch or LDS.  A
+// photon needs EVERY forward crossing of a mesh (the container rule counts them,
+// _kernel.pyx:684-714), so front-to-back ordering buys nothing and a fixed order is free.
+// Leaves hold up to kLeafTris triangles, pre-gathered (vertices + face normal + face id) so a
+// leaf is one contiguous run of 104-byte records.
+//
+// The boxes are padded by 1e-7 of the mesh diagonal: culling must be conservative with respect
+// to the (differently rounded) watertight triangle test, so that the set of crossings found
+// through the BVH equals the set a brute-force loop over the faces finds (which is what
+// oracle/pvt_oracle.c does) bit for bit.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace pvt {
+
+struct BvhNode {      // 64 bytes
+    double lo[3], hi[3];
+    int skip;         // next node when this subtree is culled or finished
+    int tri_start;    // leaves: first triangle record; inner nodes: -1
+    int tri_count;    // leaves: 1..kLeafTris; inner nodes: 0
+    int pad;
+};
+struct MeshTri {      // 104 bytes
+    double v[9];      // three vertices, node-local frame
+    double n[3];      // outward unit face normal
+    long long face;   // index in the scene's pooled face table (tie-break key, diagnostics)
+};
+
+constexpr int kLeafTris = 4;
+
+class BvhBuilder {
+public:
+    BvhBuilder(const double* vertices, const int32_t* faces, const double* normals,
+               std::vector<BvhNode>& nodes, std::vector<MeshTri>& tris)
+        : v_(vertices), f_(faces), n_(normals), nodes_(nodes), tris_(tris) {}
+
+    // Adds the BVH of faces [f0, f0 + count) and returns the index of its root node.
+    int add_mesh(int f0, int count) {
+        order_.resize(count);
+        std::iota(order_.begin(), order_.end(), f0);
+        cx_.resize(3 * (size_t)count);
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < count; k++) {
+            const int32_t* idx = f_ + 3 * (size_t)(f0 + k);
+            for (int a = 0; a < 3; a++) {
+                double s = 0.0;
+                for (int c = 0; c < 3; c++) {
+                    double x = v_[3 * (size_t)idx[c] + a];
+                    s += x;
+                    lo[a] = std::min(lo[a], x);
+                    hi[a] = std::max(hi[a], x);
+                }
+                cx_[3 * (size_t)k + a] = s / 3.0;
+            }
+        }
+        double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
+                                (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        pad_ = 1e-7 * diag + 1e-300;
+        f0_ = f0;
+        const int root = (int)nodes_.size();
+        build(0, count);
+        return root;
+    }
+
+private:
+    void bounds(int begin, int end, double* lo, double* hi) const {
+        for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (int k = begin; k < end; k++) {
+            const int32_t* idx = f_ + 3 * (size_t)order_[k];
+            for (int c = 0; c < 3; c++)
+                for (int a = 0; a < 3; a++) {
+                    double x = v_[3 * (size_t)idx[c] + a];
+                    lo[a] = std::min(lo[a], x);
+                    hi[a] = std::max(hi[a], x);
+                }
+        }
+    }
+    void build(int begin, int end) {
+        const int me = (int)nodes_.size();
+        nodes_.push_back(BvhNode{});
+        double lo[3], hi[3];
+        bounds(begin, end, lo, hi);
+        for (int a = 0; a < 3; a++) { nodes_[me].lo[a] = lo[a] - pad_; nodes_[me].hi[a] = hi[a] + pad_; }
+        if (end - begin <= kLeafTris) {
+            nodes_[me].tri_start = (int)tris_.size();
+            nodes_[me].tri_count = end - begin;
+            std::sort(order_.begin() + begin, order_.begin() + end);   // face order inside a leaf
+            for (int k = begin; k < end; k++) {
+                const int face = order_[k];
+                const int32_t* idx = f_ + 3 * (size_t)face;
+                MeshTri t{};
+                for (int c = 0; c < 3; c++)
+                    for (int a = 0; a < 3; a++) t.v[3 * c + a] = v_[3 * (size_t)idx[c] + a];
+                for (int a = 0; a < 3; a++) t.n[a] = n_[3 * (size_t)face + a];
+                t.face = face;
+                tris_.push_back(t);
+            }
+        } else {
+            // median split of the centroids along their widest axis
+            double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int k = begin; k < end; k++)
+                for (int a = 0; a < 3; a++) {
+                    double c = cx_[3 * (size_t)(order_[k] - f0_) + a];
+                    clo[a] = std::min(clo[a], c);
+                    chi[a] = std::max(chi[a], c);
+                }
+            int axis = 0;
+            if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+            if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+            const int mid = (begin + end) / 2;
+            std::nth_element(order_.begin() + begin, order_.begin() + mid, order_.begin() + end,
+                             [&](int a, int b) {
+                                 double ca = cx_[3 * (size_t)(a - f0_) + axis], cb = cx_[3 * (size_t)(b - f0_) + axis];
+                                 return ca < cb || (ca == cb && a < b);
+                             });
+            nodes_[me].tri_start = -1;
+            nodes_[me].tri_count = 0;
+            build(begin, mid);
+            build(mid, end);
+        }
+        nodes_[me].skip = (int)nodes_.size();
+    }
+
+    const double* v_;
+    const int32_t* f_;
+    const double* n_;
+    std::vector<BvhNode>& nodes_;
+    std::vector<MeshTri>& tris_;
+    std::vector<int> order_;
+    std::vector<double> cx_;
+    double pad_ = 0.0;
+    int f0_ = 0;
+};
+
+}  // namespace pvt

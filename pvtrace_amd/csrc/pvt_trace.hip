@@ -37,6 +37,7 @@
 
 #include "../../include/pvtrace_hip.h"
 #include "pvt_math.h"
+#include "pvt_bvh.h"
 
 // Developer-only ablation switches (timing experiments; results are WRONG when set).
 #ifndef PVT_ABLATE
@@ -66,7 +67,7 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // table element is addressed as base + index*stride + field with compile-time strides
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
 enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND = 26 };           // node doubles
-enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI };  // node ints
+enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI };  // node ints (NI_MESH: BVH root, -1 = none)
 enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C, CD };                         // component doubles
 enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N,
        CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI_ABS_HIST, CI_EMS_HIST, CI };  // *_G*: guide tables; *_HIST: step tables
@@ -96,6 +97,8 @@ struct KArgs {
     const int* gi;      // scene int blob
     const double* ed;   // emitter blobs (may be null)
     const int* ei;
+    const pvt::BvhNode* bvh;    // triangle meshes (null when the scene has none): stay in HBM/L2
+    const pvt::MeshTri* tris;
     Lay lay;
     EmitOff eoff;
     int nd, ni;         // blob lengths
@@ -409,7 +412,9 @@ struct Seen {
 };
 
 // --------------------------------------------------------------- kernel
-template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
+// MESH: the scene has triangle-mesh nodes.  The BVH walk costs ~35 VGPRs, so scenes made of
+// analytic shapes run the variant compiled without it (one more wave per SIMD).
+template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
 __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     extern __shared__ double smem[];
     const Lay L = A.lay;
@@ -627,6 +632,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         bool t_normal = false;
         double t_angle = 0.0;
         V3 nrm{0, 0, 0}, lpos{0, 0, 0};
+        int tri1 = -1;   // triangle record of the nearest crossing when it lies on a mesh
         bool em = false, em_acos = false;   // re-emission pending: acos argument (or theta) and phi
         double em_x = 0.0, em_phi = 0.0;
 
@@ -641,6 +647,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             } else {
                 // ---- intersect every node, fold nearest/second/container ----
                 int nhits = 0, n1 = -1, n2 = -1, cnode = -1;
+                tri1 = -1;
                 double t1 = INFINITY, t2 = INFINITY, cbest = INFINITY;
                 for (int node = 0; node < A.n_nodes; node++) {
                     const int m = node * ND + ND_W2L;
@@ -666,7 +673,80 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
                         nhits += 1;
                     };
-                    if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
+                    if (MESH && gt == PVT_GEOM_MESH) {
+                        // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
+                        // forward crossing of the node's triangles, found by a stack-free walk of
+                        // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
+                        // (t, face) so the result does not depend on the walk order.
+                        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+                        const double ax = pvt_fabs(d.x), ay = pvt_fabs(d.y), az = pvt_fabs(d.z);
+                        const int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+                        int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+                        auto pick = [](const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
+                        const double dz = pick(dd, kz);
+                        if (dz < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
+                        const double shx = pick(dd, kx) / dz, shy = pick(dd, ky) / dz, shz = 1.0 / dz;
+                        double inv[3];
+                        bool par[3];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) { par[a] = pvt_fabs(dd[a]) < 1e-300; inv[a] = 1.0 / dd[a]; }
+                        long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
+                        int i = T.iu(node * NI + NI_MESH);
+                        const int end = A.bvh[i].skip;
+                        while (i < end) {
+                            const pvt::BvhNode* b = A.bvh + i;
+                            double tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                double ta = (b->lo[a] - oo[a]) * inv[a], tb = (b->hi[a] - oo[a]) * inv[a];
+                                if (par[a]) {
+                                    const bool outside = oo[a] < b->lo[a] || oo[a] > b->hi[a];
+                                    ta = outside ? INFINITY : -INFINITY;
+                                    tb = outside ? -INFINITY : INFINITY;
+                                }
+                                if (ta > tb) { double tmp = ta; ta = tb; tb = tmp; }
+                                if (ta > tmin) tmin = ta;
+                                if (tb < tmax) tmax = tb;
+                            }
+                            if (tmax < tmin || tmax < 0.0) { i = b->skip; continue; }
+                            const int tn = b->tri_count;
+                            const pvt::MeshTri* tr = A.tris + b->tri_start;
+                            for (int k = 0; k < tn; k++, tr++) {
+                                double va[3], vb[3], vc[3];
+#pragma unroll
+                                for (int a = 0; a < 3; a++) {
+                                    va[a] = tr->v[a] - oo[a]; vb[a] = tr->v[3 + a] - oo[a]; vc[a] = tr->v[6 + a] - oo[a];
+                                }
+                                const double az_ = pick(va, kz), bz_ = pick(vb, kz), cz_ = pick(vc, kz);
+                                const double axs = pick(va, kx) - shx * az_, ays = pick(va, ky) - shy * az_;
+                                const double bxs = pick(vb, kx) - shx * bz_, bys = pick(vb, ky) - shy * bz_;
+                                const double cxs = pick(vc, kx) - shx * cz_, cys = pick(vc, ky) - shy * cz_;
+                                const double u = cxs * bys - cys * bxs;
+                                const double v = axs * cys - ays * cxs;
+                                const double w = bxs * ays - bys * axs;
+                                if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) continue;
+                                const double det = u + v + w;
+                                if (det == 0.0) continue;
+                                const double sg = det < 0.0 ? -1.0 : 1.0;
+                                auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
+                                if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) continue;
+                                if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) continue;
+                                if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
+                                const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
+                                if (!(t > kEps)) continue;
+                                const long long face = tr->face;
+                                const int tri = b->tri_start + k;
+                                if (nl == 0 || t < tfirst) tfirst = t;
+                                nl += 1;
+                                if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
+                                else if (t < t1 || (t == t1 && f1 >= 0 && face < f1)) {
+                                    t2 = t1; n2 = n1; f2 = f1; t1 = t; n1 = node; tri1 = tri; f1 = face;
+                                } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
+                                nhits += 1;
+                            }
+                            i += 1;
+                        }
+                    } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
                         double tmin = -INFINITY, tmax = INFINITY;
                         bool miss = false;
                         const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
@@ -891,7 +971,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             if (t_normal) {  // outward normal (_kernel.pyx:359-400)
                 const int gp = t_node * ND + ND_PARAMS;
                 const int gt = T.iv(t_node * NI + NI_GEOM);
-                if (gt == PVT_GEOM_BOX) {
+                if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
+                    const pvt::MeshTri* tr = A.tris + tri1;
+                    nloc = V3{tr->n[0], tr->n[1], tr->n[2]};
+                } else if (gt == PVT_GEOM_BOX) {
                     double best = INFINITY;
                     int baxis = 0;
                     double bsign = 1.0;
@@ -1221,6 +1304,8 @@ struct PvtScene {
     int* d_gi = nullptr;
     double* d_ed = nullptr;
     int* d_ei = nullptr;
+    pvt::BvhNode* d_bvh = nullptr;      // triangle meshes: BVH nodes + gathered triangles
+    pvt::MeshTri* d_tris = nullptr;
     unsigned int* d_cursor = nullptr;   // ring of kCursorSlots cursors (64 B apart): launches on
                                         // different streams may overlap, each needs its own
     std::atomic<unsigned int> launches{0};
@@ -1249,6 +1334,20 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipSetDevice(device));
 
     const int N = t->n_nodes, C = t->n_components, R = t->n_recorders, H = t->n_hists, K = t->n_coatings;
+    std::vector<pvt::BvhNode> bvh_nodes;
+    std::vector<pvt::MeshTri> bvh_tris;
+    for (int n = 0; n < N; n++) {
+        const int g = t->geom_type[n];
+        if (g < PVT_GEOM_BOX || g > PVT_GEOM_MESH) return fail(PVT_ERR_INVALID, "unknown geometry type");
+        if (g != PVT_GEOM_MESH) continue;
+        if (!t->mesh_face_start || !t->mesh_face_count || !t->mesh_vertices || !t->mesh_faces || !t->mesh_normals)
+            return fail(PVT_ERR_INVALID, "mesh node without mesh tables");
+        const long long f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
+        if (fc <= 0 || f0 < 0 || f0 + fc > t->n_mesh_faces) return fail(PVT_ERR_INVALID, "mesh face range out of bounds");
+        for (long long k = 3 * f0; k < 3 * (f0 + fc); k++)
+            if (t->mesh_faces[k] < 0 || t->mesh_faces[k] >= t->n_mesh_vertices)
+                return fail(PVT_ERR_INVALID, "mesh face indexes a missing vertex");
+    }
     // fixed-stride records, then the pooled spectra (see the enums next to struct Lay)
     Lay lay{};
     lay.comp_d = N * ND;
@@ -1328,6 +1427,12 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[NI_CCOUNT] = t->comp_count[n];
         q[NI_KSTART] = K > 0 ? t->coat_start[n] : 0;
         q[NI_KCOUNT] = K > 0 ? t->coat_count[n] : 0;
+        q[NI_MESH] = -1;
+        if (t->geom_type[n] == PVT_GEOM_MESH) {
+            const int f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
+            q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris)
+                             .add_mesh(f0, fc);
+        }
     }
     for (int c = 0; c < C; c++) {
         double* d = gd.data() + lay.comp_d + c * CD;
@@ -1406,6 +1511,12 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
     HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots));
+    if (!bvh_nodes.empty()) {
+        HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
+        HIP_TRY(hipMalloc(&s->d_tris, bvh_tris.size() * sizeof(pvt::MeshTri)));
+        HIP_TRY(hipMemcpy(s->d_bvh, bvh_nodes.data(), bvh_nodes.size() * sizeof(pvt::BvhNode), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_tris, bvh_tris.data(), bvh_tris.size() * sizeof(pvt::MeshTri), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(s->d_gd, gd.data(), gd.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_gi, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice));
     *out = s;
@@ -1451,6 +1562,8 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_ed) (void)hipFree(s->d_ed);
     if (s->d_ei) (void)hipFree(s->d_ei);
     if (s->d_cursor) (void)hipFree(s->d_cursor);
+    if (s->d_bvh) (void)hipFree(s->d_bvh);
+    if (s->d_tris) (void)hipFree(s->d_tris);
     delete s;
 }
 
@@ -1461,6 +1574,7 @@ namespace {
 KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
     KArgs a{};
     a.gd = s->d_gd; a.gi = s->d_gi; a.ed = s->d_ed; a.ei = s->d_ei;
+    a.bvh = s->d_bvh; a.tris = s->d_tris;
     a.lay = s->lay; a.eoff = s->eoff;
     a.nd = s->nd; a.ni = s->ni;
     a.n_nodes = s->n_nodes; a.root = s->root; a.n_rec = s->n_rec; a.total_bins = s->total_bins;
@@ -1477,8 +1591,14 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
 
 template <bool RECORD, bool TAB_LDS, int SEENW>
 hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
-    if (emit) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    const bool mesh = a.bvh != nullptr;
+    if (emit) {
+        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, true>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    } else {
+        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    }
     return hipGetLastError();
 }
 

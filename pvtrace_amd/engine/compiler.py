@@ -27,7 +27,7 @@ from pvtrace_amd.engine.recorder import (
     Histogram,
     Recorder,
 )
-from pvtrace_amd.geometry import Box, Cylinder, Sphere
+from pvtrace_amd.geometry import Box, Cylinder, Mesh, Sphere
 from pvtrace_amd.material import (
     Absorber,
     CoatedSurfaceDelegate,
@@ -45,7 +45,7 @@ from pvtrace_amd.material import (
 MAX_NODES = 128       # device limit (reference _kernel.pyx:66, :929-930)
 MAX_RECORDERS = 256   # per-photon distinct-ray bitmask width (compiler.py:23)
 
-GEOM_BOX, GEOM_SPHERE, GEOM_CYLINDER = 0, 1, 2
+GEOM_BOX, GEOM_SPHERE, GEOM_CYLINDER, GEOM_MESH = 0, 1, 2, 3
 SURF_FRESNEL, SURF_NULL = 0, 1
 COMP_ABSORBER, COMP_SCATTERER, COMP_LUMINOPHORE, COMP_REACTOR = 0, 1, 2, 3
 PHASE_ISOTROPIC, PHASE_HENYEY_GREENSTEIN, PHASE_CONE = 0, 1, 2
@@ -114,6 +114,9 @@ class CompiledScene:
         self.comp_count = np.zeros(count, dtype=_I32)
         self.coat_start = np.zeros(count, dtype=_I32)
         self.coat_count = np.zeros(count, dtype=_I32)
+        self.mesh_face_start = np.zeros(count, dtype=_I32)
+        self.mesh_face_count = np.zeros(count, dtype=_I32)
+        self._mesh_pool = {"vertices": [], "faces": [], "normals": [], "nv": 0, "nf": 0}
 
         pools = {"abs_x": [], "abs_y": [], "ems_x": [], "ems_cdf": []}
         comp_cols = {
@@ -184,6 +187,13 @@ class CompiledScene:
             self.coat_transmit_mode[r] = Coating.TRANSMISSION_MODES[coating.transmission]
         self.n_coatings = ncoat
 
+        pool = self._mesh_pool
+        self.n_mesh_vertices, self.n_mesh_faces = pool["nv"], pool["nf"]
+        self.mesh_vertices = (np.concatenate(pool["vertices"]) if pool["nv"] else np.zeros((0, 3), dtype=_F64))
+        self.mesh_faces = (np.concatenate(pool["faces"]).astype(_I32) if pool["nf"] else np.zeros((0, 3), dtype=_I32))
+        self.mesh_normals = (np.concatenate(pool["normals"]) if pool["nf"] else np.zeros((0, 3), dtype=_F64))
+        del self._mesh_pool
+
         self._lower_recorders(nodes)
 
     # -- geometry & pose -------------------------------------------------
@@ -198,6 +208,19 @@ class CompiledScene:
             self.geom_type[i] = GEOM_CYLINDER
             self.geom_params[i, 0] = float(geometry.length)
             self.geom_params[i, 1] = float(geometry.radius)
+        elif isinstance(geometry, Mesh):
+            # EXTENSION: the reference engine rejects meshes (compiler.py:220-223)
+            pool = self._mesh_pool
+            self.geom_type[i] = GEOM_MESH
+            self.mesh_face_start[i] = pool["nf"]
+            self.mesh_face_count[i] = len(geometry.faces)
+            pool["vertices"].append(np.asarray(geometry.vertices, dtype=_F64))
+            pool["faces"].append(np.asarray(geometry.faces, dtype=_I32) + pool["nv"])
+            pool["normals"].append(np.asarray(geometry.face_normals, dtype=_F64))
+            pool["nv"] += len(geometry.vertices)
+            pool["nf"] += len(geometry.faces)
+            lo, hi = geometry.vertices.min(axis=0), geometry.vertices.max(axis=0)
+            self.geom_params[i, :3] = hi - lo          # informational: local AABB size
         else:
             raise UnsupportedSceneError(
                 f"Geometry type {type(geometry).__name__} is not supported."
@@ -390,6 +413,7 @@ class CompiledScene:
         "hist_offset",
         "coat_start", "coat_count", "coat_facet", "coat_lo", "coat_hi",
         "coat_reflectivity", "coat_reflect_mode", "coat_transmit_mode",
+        "mesh_face_start", "mesh_face_count", "mesh_vertices", "mesh_faces", "mesh_normals",
     )
 
     def tables(self):

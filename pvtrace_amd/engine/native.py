@@ -53,6 +53,9 @@ class PvtSceneTables(C.Structure):
         ("coat_transmit_mode", _p_i32),
         ("rec_source_mode", _p_i32), ("rec_source_id", _p_i32),
         ("comp_abs_hist", _p_i32), ("comp_ems_hist", _p_i32),
+        ("n_mesh_vertices", C.c_int32), ("n_mesh_faces", C.c_int32),
+        ("mesh_face_start", _p_i32), ("mesh_face_count", _p_i32), ("mesh_vertices", _p_f64),
+        ("mesh_faces", _p_i32), ("mesh_normals", _p_f64),
     ]
 
 
@@ -131,6 +134,8 @@ def scene_tables_struct(compiled):
     st.n_hists = int(compiled.hist_prop_a.shape[0])
     st.total_bins = int(compiled.total_bins)
     st.n_coatings = int(getattr(compiled, "n_coatings", 0))
+    st.n_mesh_vertices = int(getattr(compiled, "n_mesh_vertices", 0))
+    st.n_mesh_faces = int(getattr(compiled, "n_mesh_faces", 0))
     for name in _TABLE_POINTER_FIELDS:
         want = np.int32 if dict(PvtSceneTables._fields_)[name] is _p_i32 else np.float64
         value = getattr(compiled, name, None)
@@ -222,6 +227,7 @@ ABI_SYMBOLS = (
 )
 
 _lib = None
+ABI_VERSION = 4   # include/pvtrace_hip.h PVT_ABI_VERSION
 
 
 def library_built():
@@ -265,6 +271,11 @@ def load_library():
         _preload_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         declare_signatures(lib, ABI_SYMBOLS)
+        if lib.pvt_abi_version() != ABI_VERSION:   # a stale .so would misread the table struct
+            raise EngineUnavailableError(
+                f"{LIB_PATH} implements ABI v{lib.pvt_abi_version()}, this package needs v{ABI_VERSION}; "
+                "rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)."
+            )
         _lib = lib
     return _lib
 

@@ -267,3 +267,117 @@ class Cylinder(Geometry):
         if r == 0.0:
             raise GeometryError("Point on the cylinder axis has no radial normal.")
         return (p[0] / r, p[1] / r, 0.0)
+
+
+class Mesh(Geometry):
+    """Closed triangle mesh (reference pvtrace/geometry/mesh.py:11-24: `Mesh(trimesh, material)`).
+
+    `trimesh` is anything with `.vertices` (V,3) and `.faces` (F,3) -- a `trimesh.Trimesh`
+    works, so does a `(vertices, faces)` pair.  As in the reference the vertices are re-centred
+    on the centre of mass (mesh.py:17).  The surface must be closed and consistently wound
+    (every edge shared by two faces, once per direction); an inward winding is flipped.
+
+    Ray queries follow the device semantics: every crossing with distance > EPS_ZERO counts,
+    the normal of a crossing is the face normal (mesh.py:63-86), and the watertight
+    ray/triangle test of the kernel (see `pvtrace_amd.mesh.ray_triangle_distances`) decides
+    which face owns a ray through an edge or a vertex.
+    """
+
+    def __init__(self, trimesh=None, material=None, *, recenter=True):
+        super(Mesh, self).__init__(material=material)
+        from pvtrace_amd import mesh as M
+
+        if hasattr(trimesh, "vertices") and hasattr(trimesh, "faces"):
+            vertices, faces = trimesh.vertices, trimesh.faces
+        else:
+            vertices, faces = trimesh
+        vertices = np.array(vertices, dtype=np.float64).reshape(-1, 3)
+        faces = np.array(faces, dtype=np.int32).reshape(-1, 3)
+        if faces.size == 0 or faces.min() < 0 or faces.max() >= len(vertices):
+            raise GeometryError("Mesh faces must index into the vertex array.")
+        if not M.is_watertight(faces):
+            raise GeometryError("Mesh must be a closed, consistently wound surface.")
+        if M.signed_volume(vertices, faces) < 0.0:
+            faces = faces[:, ::-1].copy()
+        if recenter:
+            vertices = vertices - M.center_of_mass(vertices, faces)
+        self.vertices = vertices
+        self.faces = faces
+        self.face_normals = M.face_normals(vertices, faces)
+
+    # -- constructors ------------------------------------------------------
+    @classmethod
+    def icosphere(cls, subdivisions=3, radius=1.0, material=None):
+        from pvtrace_amd import mesh as M
+
+        return cls(M.icosphere(subdivisions, radius), material=material)
+
+    @classmethod
+    def box(cls, size, material=None):
+        from pvtrace_amd import mesh as M
+
+        return cls(M.box_mesh(size), material=material)
+
+    @classmethod
+    def from_file(cls, path, material=None):
+        from pvtrace_amd import mesh as M
+
+        return cls(M.load_stl(path), material=material)
+
+    # -- queries -------------------------------------------------------------
+    def _crossings(self, origin, direction):
+        from pvtrace_amd import mesh as M
+
+        return M.ray_triangle_distances(self.vertices, self.faces, origin, direction)
+
+    def _ray_distances(self, o, d):
+        return list(self._crossings(o, d)[0])
+
+    def contains(self, point):
+        """Strictly inside: odd number of crossings along +z and not on the surface."""
+        if self.is_on_surface(point):
+            return False
+        ts, _ = self._crossings(np.asarray(point, dtype=np.float64), np.array([0.0, 0.0, 1.0]))
+        return bool(len(ts) % 2 == 1)
+
+    def _closest_face(self, point):
+        """(distance, face) of the closest point of the surface."""
+        p = np.asarray(point, dtype=np.float64)
+        tri = self.vertices[self.faces]
+        a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+        # closest point on each triangle (Ericson, Real-Time Collision Detection 5.1.5), vectorised
+        ab, ac, ap = b - a, c - a, p - a
+        d1, d2 = np.einsum("ij,ij->i", ab, ap), np.einsum("ij,ij->i", ac, ap)
+        bp = p - b
+        d3, d4 = np.einsum("ij,ij->i", ab, bp), np.einsum("ij,ij->i", ac, bp)
+        cp = p - c
+        d5, d6 = np.einsum("ij,ij->i", ab, cp), np.einsum("ij,ij->i", ac, cp)
+        vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+        with np.errstate(divide="ignore", invalid="ignore"):
+            denom = va + vb + vc
+            v, w = vb / denom, vc / denom
+            q = a + ab * v[:, None] + ac * w[:, None]                       # interior
+            sel = (vc <= 0) & (d1 >= 0) & (d3 <= 0)                            # edge ab
+            q = np.where(sel[:, None], a + ab * (d1 / (d1 - d3))[:, None], q)
+            sel = (vb <= 0) & (d2 >= 0) & (d6 <= 0)                            # edge ac
+            q = np.where(sel[:, None], a + ac * (d2 / (d2 - d6))[:, None], q)
+            sel = (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0)              # edge bc
+            q = np.where(sel[:, None], b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[:, None], q)
+        q = np.where(((d1 <= 0) & (d2 <= 0))[:, None], a, q)
+        q = np.where(((d3 >= 0) & (d4 <= d3))[:, None], b, q)
+        q = np.where(((d6 >= 0) & (d5 <= d6))[:, None], c, q)
+        dist = np.sqrt(np.einsum("ij,ij->i", q - p, q - p))
+        k = int(np.argmin(dist))
+        return float(dist[k]), k
+
+    def is_on_surface(self, point):
+        return bool(self._closest_face(point)[0] < EPS_ZERO)
+
+    def normal(self, point):
+        dist, face = self._closest_face(point)
+        if not dist < EPS_ZERO:
+            raise GeometryError("Point is not on surface.")
+        return tuple(self.face_normals[face].tolist())
+
+    def is_entering(self, point, direction):
+        return bool(np.dot(self.normal(point), np.asarray(direction, dtype=np.float64)) < 0.0)

@@ -6,8 +6,8 @@ section (absorber / scatterer / luminophore, constant coefficient or a named / C
 scaled to a peak coefficient), a `nodes` section (box / sphere / cylinder with a material, or a
 light with wavelength / position / direction masks; `parent`, `location`, `direction`), the
 `record: true` shorthand and an explicit `recorders` section.  The spec is walked by a small
-builder class rather than the reference's nested closures; meshes are refused
-(`UnsupportedSceneError`), as the reference engine refuses them (compiler.py:220-223).
+builder class rather than the reference's nested closures; `mesh` nodes load STL files (the
+reference goes through trimesh's loaders, cli/parse.py:130-138).
 
     scene = pvtrace_amd.spec.load("scene.yml")
     result = pvtrace_amd.engine.simulate(scene, 10**6, record_every=0)
@@ -19,7 +19,7 @@ import numpy as np
 from pvtrace_amd.data import fluro_red, lumogen_f_red_305
 from pvtrace_amd.engine.compiler import UnsupportedSceneError
 from pvtrace_amd.engine.instrument import auto_recorders, recorders_from_spec
-from pvtrace_amd.geometry import Box, Cylinder, Sphere
+from pvtrace_amd.geometry import Box, Cylinder, Mesh, Sphere
 from pvtrace_amd.light import (
     CircularMask, ConstantWavelengthMask, CubeMask, Light, RectangularMask, SpectrumWavelengthMask,
 )
@@ -196,8 +196,12 @@ class _Builder:
             g = entry["cylinder"]
             return Node(name=name, geometry=Cylinder(g["length"], g["radius"],
                                                      material=self.material(g["material"])))
-        if "mesh" in entry:
-            raise UnsupportedSceneError(f"Node {name!r}: mesh geometry is not supported by the engine.")
+        if "mesh" in entry:   # reference: trimesh.exchange.load (cli/parse.py:130-138); here STL only
+            g = entry["mesh"]
+            path = g["file"] if os.path.isabs(g["file"]) else os.path.join(self.base, g["file"])
+            if not path.lower().endswith(".stl"):
+                raise UnsupportedSceneError(f"Node {name!r}: only STL mesh files are supported.")
+            return Node(name=name, geometry=Mesh.from_file(path, material=self.material(g["material"])))
         if "light" in entry:
             e = entry["light"]
             wavelength = ConstantWavelengthMask(e["wavelength"]) if e.get("wavelength") else None

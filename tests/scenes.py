@@ -10,7 +10,7 @@ import functools
 import numpy as np
 
 from pvtrace_amd import (
-    Absorber, Box, Coating, CoatedSurfaceDelegate, Cylinder, Light, Luminophore, Material, Node,
+    Absorber, Box, Coating, CoatedSurfaceDelegate, Cylinder, Light, Luminophore, Material, Mesh, Node,
     NullSurfaceDelegate, Reactor, Scatterer, Scene, Sphere, Surface, cone, isotropic, lambertian,
     rectangular_mask,
 )
@@ -329,6 +329,44 @@ def hist_slab():
     return Scene(world)
 
 
+def mesh_lsc():
+    """lsc_equivalent with the slab given as a 12-triangle mesh: must behave like the analytic
+    box (same events; positions to ~1e-13 cm)."""
+    scene = lsc_equivalent()
+    slab = [n for n in scene.root.children if n.name == "LSC"][0]
+    slab.geometry = Mesh.box((5.0, 5.0, 1.0), material=slab.geometry.material)
+    return scene
+
+
+def mesh_gem():
+    """Faceted glass ball (320-face icosphere, rotated and off-centre) holding a scatterer and an
+    analytic sphere of denser glass, in a mesh world (80-face icosphere): mesh root EXIT,
+    mesh <-> analytic nesting, facet recorder on one triangle, heatmaps in the mesh frame."""
+    world = Node(name="world", geometry=Mesh.icosphere(1, 10.0, material=Material(refractive_index=1.0)))
+    gem = Node(name="gem", parent=world, geometry=Mesh.icosphere(2, 1.0, material=Material(
+        refractive_index=1.5,
+        components=[Scatterer(0.7, phase_function=HenyeyGreenstein(0.3), name="haze"),
+                    Absorber(0.05, name="tint")])))
+    gem.location = (0.2, -0.1, 2.0)
+    gem.rotate(0.4, (0.3, 1.0, 0.2))
+    core = Node(name="core", parent=gem, geometry=Sphere(0.35, material=Material(
+        refractive_index=1.9, components=[Absorber(0.8, name="core-abs")])))
+    core.location = (0.1, 0.0, -0.2)
+    light = Node(name="lamp", parent=world, light=Light(
+        position=CircularMask(0.6), direction=Cone(0.25), name="lamp"))
+    light.location = (0.0, 0.0, -4.0)
+    world_normals = gem.geometry.face_normals @ np.asarray(gem.transformation_to(world))[:3, :3].T
+    gem.recorders = [
+        Recorder("gem-in", event="entering", histograms=[Heatmap("x", "y", (-1, 1, 8), (-1, 1, 8))]),
+        Recorder("gem-out", event="escaping", histograms=[Histogram("angle", 0, np.pi / 2, 12)]),
+        Recorder("gem-facet", event="entering", facet=tuple(world_normals[int(np.argmin(world_normals[:, 2]))])),
+        Recorder("gem-lost", event="lost"), Recorder("gem-reflected", event="reflected"),
+    ]
+    core.recorders = [Recorder("core-in", event="entering"), Recorder("core-lost", event="lost")]
+    world.recorders = [Recorder("exit", event="exit", histograms=[Histogram("angle", 0, np.pi / 2, 9)])]
+    return Scene(world)
+
+
 REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
     "hello_world": hello_world,
     "lsc_equivalent": lsc_equivalent,
@@ -339,10 +377,12 @@ REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
     "touching_boxes": touching_boxes,
     "trapped_light": trapped_light,
 }
-EXTENSION_SCENES = {   # need the coating extension
+EXTENSION_SCENES = {   # need an extension: coatings, hist spectra, meshes
     "coated_slab": coated_slab,
     "lambertian_sheet": lambertian_sheet,
     "hist_slab": hist_slab,
+    "mesh_lsc": mesh_lsc,
+    "mesh_gem": mesh_gem,
 }
 ALL_SCENES = dict(REFERENCE_SCENES, **EXTENSION_SCENES)
 

@@ -115,9 +115,15 @@ def test_dict_spec_masks_phase_functions_and_errors(tmp_path):
     assert c.comp_abs_n.tolist() == [1, 31] and np.isclose(c.abs_y.max(), 2.0)
     lamp = scene.light_nodes[0].light
     assert isinstance(lamp.position, RectangularMask) and isinstance(lamp.direction, HenyeyGreenstein)
-    bad = dict(base, nodes=dict(base["nodes"], blob={"mesh": {"file": "x.stl", "material": {"refractive-index": 1.5}}}))
+    bad = dict(base, nodes=dict(base["nodes"], blob={"mesh": {"file": "x.obj", "material": {"refractive-index": 1.5}}}))
     with pytest.raises(UnsupportedSceneError):
         spec.load(bad)
+    from pvtrace_amd import mesh as M
+    M.save_stl(str(tmp_path / "gem.stl"), *M.icosphere(1, 0.4))
+    meshed = spec.load(dict(base, nodes=dict(base["nodes"], gem={"mesh": {
+        "file": str(tmp_path / "gem.stl"), "material": {"refractive-index": 1.5}}, "location": [0, 0, 3]})))
+    cm = compile_scene(meshed)
+    assert cm.geom_type.tolist() == [0, 2, 3] and cm.n_mesh_faces == 80 and cm.mesh_face_count.tolist() == [0, 0, 80]
     with pytest.raises(spec.SpecError):
         spec.load({"version": "9.9", "nodes": {}})
     with pytest.raises(spec.SpecError):

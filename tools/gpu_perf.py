@@ -28,6 +28,16 @@ if __name__ == "__main__":
     if which == "lsc":
         for n in (1_000_000, 4_000_000):
             probe("lsc_equivalent", scenes.lsc_equivalent(), n)
+    elif which == "mesh":
+        import pvtrace_amd as pv
+        probe("mesh_lsc (12 tri)", scenes.mesh_lsc(), 1_000_000)
+        probe("mesh_gem (400 tri)", scenes.mesh_gem(), 1_000_000)
+        for sub in (3, 5, 7):   # 1280, 20480, 327680 faces
+            sc = scenes.hello_world()
+            ball = [n for n in sc.root.children if n.geometry is not None][0]
+            ball.geometry = pv.Mesh.icosphere(sub, 1.0, material=ball.geometry.material)
+            probe(f"hello_world ico{sub}", sc, 1_000_000)
+        probe("hello_world", scenes.hello_world(), 1_000_000)
     else:
         probe("lsc_equivalent", scenes.lsc_equivalent(), 1_000_000)
         probe("lsc_equivalent", scenes.lsc_equivalent(), 10_000_000, reps=3, device_emit=True)

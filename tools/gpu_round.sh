@@ -4,7 +4,7 @@ set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -5 | tee gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 timeout 600 python bench.py 2>gpurun_out/bench.err | tee gpurun_out/bench.json
 timeout 600 python bench.py --streams 1 --no-cpu-baseline 2>>gpurun_out/bench.err | tee gpurun_out/bench_serial.json

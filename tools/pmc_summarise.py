@@ -1,0 +1,53 @@
+"""Summarise the PMC passes of tools/gpu_pmc.sh into profiles/<tag>_pmc_summary.json (+ the copy
+bench.py reads, profiles/pmc_summary.json).  Usage: python tools/pmc_summarise.py r01_c "stage text"
+
+Units/corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): rocprofv3 reports
+FETCH_SIZE / WRITE_SIZE in KiB, and on gfx950 FETCH_SIZE is half the bytes of a wide coalesced
+read stream, so it is doubled; WRITE_SIZE is uncalibrated and taken as is."""
+import csv, glob, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+stage = sys.argv[2] if len(sys.argv) > 2 else ""
+photons = 1_000_000
+sums = collections.defaultdict(list)
+kernel = None
+for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*", "pmc_counter_collection.csv"))):
+    rows = [r for r in csv.DictReader(open(path)) if "trace_kernel" in r["Kernel_Name"]]
+    per = collections.defaultdict(list)
+    for r in rows:
+        per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        kernel = r["Kernel_Name"]
+    for name, vals in per.items():
+        vals = vals[1:] if len(vals) > 1 else vals           # drop the warm-up launch
+        sums[name] = sum(vals) / len(vals)
+c = dict(sums)
+read_b = c["FETCH_SIZE"] * 1024 * 2
+write_b = c["WRITE_SIZE"] * 1024
+out = {
+    "round": 1, "stage": stage,
+    "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --gpus 1 --steps 5 "
+               "--warmup 1 --streams 1 --no-cpu-baseline (one counter set per run; tools/gpu_pmc.sh)",
+    "kernel": kernel, "photons_per_launch": photons, "counters_mean_per_launch": c,
+    "hbm_read_bytes_per_launch_corrected": read_b, "hbm_write_bytes_per_launch": write_b,
+    "hbm_bytes_per_launch": read_b + write_b,
+    "correction": "FETCH_SIZE doubled: gfx950 rocprofv3 reports 1/2 of a wide coalesced read stream "
+                  "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is",
+    "algorithmic_bytes_per_launch": 56 * photons,
+    "derived": {
+        "valu_lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) if "SQ_ACTIVE_INST_VALU" in c else None,
+        "valu_wave_instructions_per_photon": c.get("SQ_INSTS_VALU", 0) / photons,
+        "salu_instructions_per_photon": c.get("SQ_INSTS_SALU", 0) / photons,
+        "lds_instructions_per_photon": c.get("SQ_INSTS_LDS", 0) / photons,
+        "wait_any_fraction_of_wave_cycles": c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"],
+        "wait_inst_any_fraction": c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"],
+        "active_inst_any_fraction": c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"],
+        "lds_bank_conflict_fraction": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+        "smem_instructions_per_wave": c.get("SQ_INSTS_SMEM", 0) / c["SQ_WAVES"],
+        "vmem_instructions_per_wave": c.get("SQ_INSTS_VMEM", 0) / c["SQ_WAVES"],
+    },
+}
+for name in (f"{tag}_pmc_summary.json", "pmc_summary.json"):
+    with open(os.path.join(ROOT, "profiles", name), "w") as fp:
+        json.dump(out, fp, indent=1)
+print(json.dumps(out["derived"], indent=1), out["hbm_bytes_per_launch"])
