@@ -196,13 +196,13 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "trace_kernel<RECORD=0,TAB_LDS=1,SEENW=1,COATED=0>",
+                "kernel": "trace_kernel<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=0,MESH=0>",
                 "kernel_ms_mean": mean_kernel_ms,
                 "kernel_photons_per_s": n / (mean_kernel_ms * 1e-3),
                 "achieved_at_step_rate": ALGORITHMIC_BYTES_PER_PHOTON * n * args.steps / elapsed / 1e9,
                 "note": "not HBM-bound: 56 algorithmic B/photon; the loop is FP64-VALU/latency/"
                         "divergence-bound (DESIGN.md). kernel_ms_mean is per launch (HIP events on the "
-                        "launch's own stream); with 2 bundles in flight launches overlap, so "
+                        "launch's own stream); with several bundles in flight launches overlap, so "
                         "ms_per_step < kernel_ms_mean",
             },
             "launch": dscene.launch_info(),

@@ -464,8 +464,11 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     unsigned long long st_iters = 0, st_lane_steps = 0, st_drain_iters = 0, st_drain_lane_steps = 0;
     unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_mark = 0;
 #define PVT_MARK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); if (solo) st_t[k] += now_ - st_mark; st_mark = now_; } while (0)
+    unsigned long long st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bulk-phase lane counts per section
+#define PVT_COUNT(k, pred) do { unsigned long long b_ = __ballot(pred); if (!exhausted) st_c[k] += __popcll(b_); } while (0)
 #else
 #define PVT_MARK(k) do {} while (0)
+#define PVT_COUNT(k, pred) do {} while (0)
 #endif
     // wave-uniform ray window claimed from the global cursor
     unsigned int w_next = 0, w_end = 0;
@@ -624,6 +627,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
 #endif
 
         PVT_MARK(0);  // refill + drain bookkeeping
+        PVT_COUNT(0, alive);
         // ================= one step for every live lane ==================
         // deferred event of this step
         int ev_kind = -1, ev_hit = -1, ev_container = -1, ev_adjacent = -1, ev_component = -1;
@@ -959,6 +963,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         }
 
         PVT_MARK(2);  // classification + absorption + emission draws
+        PVT_COUNT(1, alive && ev_component >= 0);            // absorbed
+        PVT_COUNT(2, em);                                    // re-emitted
+        PVT_COUNT(3, alive && t_normal && ev_kind != PVT_EV_EXIT);   // surface
+        PVT_COUNT(4, alive && ev_kind == PVT_EV_EXIT);       // exit
+        PVT_COUNT(5, alive && t_sel >= 0);                   // has a tally selector already (terminal kinds)
+        PVT_COUNT(6, alive && terminal);
         // ---- local point + outward world normal of the node the event refers to.
         // Shared by EXIT and surface events (re-converged: one copy of the code).
         const bool need_frame = alive && (t_normal || (t_sel >= 0 && t_node >= 0));
@@ -1244,6 +1254,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         atomicAdd(c + 4, 1ull);
         for (int k = 0; k < 7; k++) atomicAdd(c + 8 + k, st_t[k]);
         atomicAdd(c + 15, solo ? 1ull : 0ull);
+        for (int k = 0; k < 8; k++) atomicAdd(c + 16 + k, st_c[k]);
     }
 #endif
     // ---- flush workgroup accumulators: done by the LAST wave to leave -------
@@ -1510,7 +1521,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->lds_limit = prop.sharedMemPerBlock;
     HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
     HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
-    HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots));
+    HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
     if (!bvh_nodes.empty()) {
         HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
         HIP_TRY(hipMalloc(&s->d_tris, bvh_tris.size() * sizeof(pvt::MeshTri)));
@@ -1650,7 +1661,7 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
         HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
     }
     a.cursor = s->d_cursor + 16 * (s->launches.fetch_add(1) % kCursorSlots);
-    HIP_TRY(hipMemsetAsync(a.cursor, 0, PVT_STATS ? 64 : 4, st));
+    HIP_TRY(hipMemsetAsync(a.cursor, 0, PVT_STATS ? 256 : 4, st));
 #if PVT_STATS
     static unsigned long long* g_stats = nullptr;
     if (!g_stats) (void)hipMalloc(&g_stats, 256);
@@ -1711,6 +1722,9 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
                 (double)c[4] / (c[3] + 1e-9), (double)c[1] / c[5], (double)c[3] / c[5]);
         fprintf(stderr, "[pvt stats] solo-wave cycles: refill %llu nodes %llu absorb %llu frame %llu trig %llu surface %llu tally %llu (solo waves %llu)\n",
                 c[9], c[10], c[11], c[12], c[13], c[14], c[15], c[16]);
+        const double bi = (double)(c[1] - c[3]) + 1e-9;
+        fprintf(stderr, "[pvt stats] bulk lanes/iteration: live %.1f absorbed %.1f re-emitted %.1f surface %.1f exit %.1f terminal-selector %.1f terminal %.1f\n",
+                c[17] / bi, c[18] / bi, c[19] / bi, c[20] / bi, c[21] / bi, c[22] / bi, c[23] / bi);
     }
 #endif
     return PVT_OK;
