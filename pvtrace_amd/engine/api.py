@@ -7,7 +7,7 @@ scene is flattened to SoA tables, uploaded once to HBM, and the whole per-photon
 loop runs in the HIP kernel of csrc/pvt_trace.hip; tallies come back as a few
 KB.  Keyword-only extras: `device` (GPU index), `emission` ("host" = numpy
 sampling like the reference, "device" = sampled on the GPU from per-ray
-streams) and `emit_seed`.  `workers` is accepted for compatibility and ignored
+streams, "auto" = device when the lights allow it) and `emit_seed`.  `workers` is accepted for compatibility and ignored
 (there are no CPU tracing threads; there is no CPU path at all).
 """
 import collections
@@ -182,14 +182,19 @@ def download(compiled, tallies, log, n_rays, record_every, max_events):
     nrec = int(compiled.rec_node.shape[0])
     n_recorded = native.num_recorded(n_rays, record_every)
     rows = n_recorded * max_events
-    data = {
-        "counts": (log["counts"][:n_recorded].cpu().numpy() if log is not None
-                   else np.zeros(0, dtype=np.int32)),
-        "rec_distinct": tallies["rec_distinct"][:nrec].cpu().numpy(),
-        "rec_crossings": tallies["rec_crossings"][:nrec].cpu().numpy(),
-        "rec_sums": tallies["rec_sums"][: nrec * 8].cpu().numpy().reshape(nrec, 4, 2),
-        "rec_bins": tallies["rec_bins"][: int(compiled.total_bins)].cpu().numpy(),
-    }
+    data = {"counts": (log["counts"][:n_recorded].cpu().numpy() if log is not None
+                       else np.zeros(0, dtype=np.int32))}
+    if "_ints" in tallies:   # DeviceScene.new_tallies(): distinct | crossings | bins share one buffer
+        ints = tallies["_ints"].cpu().numpy()
+        pad = max(nrec, 1)
+        data["rec_distinct"] = ints[:nrec]
+        data["rec_crossings"] = ints[pad:pad + nrec]
+        data["rec_bins"] = ints[2 * pad: 2 * pad + int(compiled.total_bins)]
+    else:
+        data["rec_distinct"] = tallies["rec_distinct"][:nrec].cpu().numpy()
+        data["rec_crossings"] = tallies["rec_crossings"][:nrec].cpu().numpy()
+        data["rec_bins"] = tallies["rec_bins"][: int(compiled.total_bins)].cpu().numpy()
+    data["rec_sums"] = tallies["rec_sums"][: nrec * 8].cpu().numpy().reshape(nrec, 4, 2)
     for name, dtype, width in native.EVENT_LOG_COLUMNS:
         if log is not None and rows > 0:
             col = log[name][: rows * width].cpu().numpy()
@@ -197,6 +202,118 @@ def download(compiled, tallies, log, n_rays, record_every, max_events):
             col = np.zeros(0, dtype=dtype)
         data[name] = col.reshape(rows, 3) if width == 3 else col
     return data
+
+
+class Session:
+    """A scene compiled and resident on one GPU, ready to trace any number of bundles.
+
+    `simulate` opens one per call; `simulate_stream` keeps one for the whole stream, so the
+    flattening, the table upload and the buffer allocations happen once, not once per bundle
+    (the reference re-flattens per `simulate` call, api.py:222, which costs it nothing next to
+    its trace time; here a 50 000-ray bundle traces in well under a millisecond)."""
+
+    def __init__(self, scene, device=None, emission="auto"):
+        if emission not in ("auto", "host", "device"):
+            raise ValueError("emission must be 'auto', 'host' or 'device'")
+        from pvtrace_amd.engine import emit as emit_mod
+        from pvtrace_amd.engine.compiler import UnsupportedSceneError
+
+        self.scene = scene
+        self.compiled = compile_scene(scene)
+        self.device = _default_device() if device is None else device
+        self.emitter = None
+        if emission in ("auto", "device"):
+            try:
+                self.emitter = emit_mod.EmitterTables(scene, strict=True)
+            except UnsupportedSceneError:
+                if emission == "device":
+                    raise
+        self.emission = "device" if self.emitter is not None else "host"
+        self.dscene = native.DeviceScene(self.compiled, device=self.device, emitter=self.emitter)
+        self._slots = []
+        self._submitted = 0
+
+    def close(self):
+        if self.dscene is not None:
+            self.dscene.close()
+            self.dscene = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def submit(self, num_rays, seed, maxsteps=1000, max_events=128, emit_method="kT", record_every=1,
+               emit_seed=None, ray_offset=0):
+        """Enqueue one bundle on one of two HIP streams and return a handle for `collect`.
+        Two bundles may be in flight: the next one is traced while the caller consumes the
+        previous result."""
+        import torch
+
+        from pvtrace_amd.engine import emit as emit_mod
+
+        if emit_method not in EMIT_METHODS:
+            raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
+        device, dscene = self.device, self.dscene
+        with torch.cuda.device(device):
+            if self.emission == "device":
+                if emit_seed is None:
+                    emit_seed = np.random.randint(0, 2 ** 31 - 1)
+                sources = emit_mod.sources_for(self.scene, num_rays, offset=ray_offset)
+                rays = None
+            else:
+                pos, direc, wl, sources = emit_mod.emit_bundle(self.scene, num_rays, seed=emit_seed)
+                dev = torch.device("cuda", device)
+                rays = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                             for a in (pos, direc, wl))
+            if not self._slots:
+                self._slots = [{"stream": torch.cuda.Stream(device=device), "tallies": dscene.new_tallies()}
+                               for _ in range(2)]
+            slot = self._slots[self._submitted % 2]
+            self._submitted += 1
+            stream, tallies = slot["stream"], slot["tallies"]
+            stream.wait_stream(torch.cuda.current_stream(device))   # ray upload, earlier downloads
+            with torch.cuda.stream(stream):
+                tallies["_ints"].zero_()
+                tallies["_sums"].zero_()
+                log = (dscene.new_event_log(num_rays, record_every, max_events)
+                       if record_every > 0 else None)
+                start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record(stream)
+                tic = time.perf_counter()
+                dscene.trace(rays, num_rays, int(seed), tallies, log=log, ray_offset=ray_offset,
+                             emit_seed=int(emit_seed or 0), record_every=int(record_every),
+                             maxsteps=int(maxsteps), max_events=int(max_events),
+                             emit_method=EMIT_METHODS[emit_method], stream=stream.cuda_stream)
+                stop.record(stream)
+        return {"stream": stream, "tallies": tallies, "log": log, "events": (start, stop), "tic": tic,
+                "rays": rays, "sources": sources, "num_rays": num_rays, "record_every": record_every,
+                "max_events": max_events}
+
+    def collect(self, pending, wall_clock=False):
+        """Wait for a submitted bundle and bring its results to the host -> `EngineResult`.
+        `elapsed` is the trace alone, like the reference's (api.py:232-245): HIP-event time, or
+        host wall time around launch + completion when `wall_clock`."""
+        import torch
+
+        with torch.cuda.device(self.device):
+            pending["stream"].synchronize()
+            wall = time.perf_counter() - pending["tic"]
+            kernel_ms = pending["events"][0].elapsed_time(pending["events"][1])
+            with torch.cuda.stream(pending["stream"]):
+                data = download(self.compiled, pending["tallies"], pending["log"], pending["num_rays"],
+                                pending["record_every"], pending["max_events"])
+        return EngineResult(self.compiled, data, pending["sources"], pending["max_events"],
+                            pending["record_every"], wall if wall_clock else kernel_ms * 1e-3,
+                            kernel_ms=kernel_ms)
+
+    def run(self, num_rays, seed, **kwargs):
+        """Trace one bundle -> `EngineResult` (submit + collect)."""
+        import torch
+
+        torch.cuda.synchronize(self.device)
+        return self.collect(self.submit(num_rays, seed, **kwargs), wall_clock=True)
 
 
 def simulate(
@@ -210,7 +327,7 @@ def simulate(
     record_every=1,
     *,
     device=None,
-    emission="host",
+    emission="auto",
     emit_seed=None,
     ray_offset=0,
 ):
@@ -220,56 +337,20 @@ def simulate(
     for every `record_every`-th ray (all when 1, none when 0).  Raises
     `UnsupportedSceneError` for scenes that cannot be flattened, `ValueError`
     for a bad `emit_method`, `EngineUnavailableError` without a GPU.
+
+    `emission`: "device" samples the lights on the GPU from per-ray streams (seeded by
+    `emit_seed`), "host" samples them with numpy like the reference's `emit_bundle`
+    (emit.py:92-134) and uploads the rays; "auto" (default) uses the device whenever every
+    light is built from the library's masks and falls back to the host for custom delegates.
     """
     if emit_method not in EMIT_METHODS:
         raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
-    if emission not in ("host", "device"):
-        raise ValueError("emission must be 'host' or 'device'")
-    compiled = compile_scene(scene)
     if seed is None:
         seed = np.random.randint(0, 2 ** 31 - 1)
-    if device is None:
-        device = _default_device()
-
-    import torch
-
-    from pvtrace_amd.engine import emit as emit_mod
-
-    emitter = None
-    if emission == "device":
-        emitter = emit_mod.EmitterTables(scene, strict=True)
-        if emit_seed is None:
-            emit_seed = np.random.randint(0, 2 ** 31 - 1)
-        sources = emit_mod.sources_for(scene, num_rays)
-        rays = None
-    dscene = native.DeviceScene(compiled, device=device, emitter=emitter)
-    try:
-        with torch.cuda.device(device):
-            if emission == "host":
-                pos, direc, wl, sources = emit_mod.emit_bundle(scene, num_rays, seed=emit_seed)
-                dev = torch.device("cuda", device)
-                rays = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-                             for a in (pos, direc, wl))
-            tallies = dscene.new_tallies()
-            log = (dscene.new_event_log(num_rays, record_every, max_events)
-                   if record_every > 0 else None)
-            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize(device)
-            tic = time.perf_counter()
-            start.record()
-            dscene.trace(rays, num_rays, int(seed), tallies, log=log, ray_offset=ray_offset,
-                         emit_seed=int(emit_seed or 0), record_every=int(record_every),
-                         maxsteps=int(maxsteps), max_events=int(max_events),
-                         emit_method=EMIT_METHODS[emit_method])
-            stop.record()
-            torch.cuda.synchronize(device)
-            elapsed = time.perf_counter() - tic
-            kernel_ms = start.elapsed_time(stop)
-            data = download(compiled, tallies, log, num_rays, record_every, max_events)
-    finally:
-        dscene.close()
-    return EngineResult(compiled, data, sources, max_events, record_every, elapsed,
-                        kernel_ms=kernel_ms)
+    with Session(scene, device=device, emission=emission) as session:
+        return session.run(num_rays, seed, maxsteps=maxsteps, max_events=max_events,
+                           emit_method=emit_method, record_every=record_every,
+                           emit_seed=emit_seed, ray_offset=ray_offset)
 
 
 def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
@@ -277,20 +358,34 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
 
     Bundle b uses per-ray seeds ``seed + traced + i`` (reference api.py:249-264),
     so the union of the streamed results equals one `simulate` call; sum the
-    `rec_*` arrays to accumulate."""
+    `rec_*` arrays to accumulate.  The scene is flattened and uploaded once for the
+    whole stream."""
     if seed is None:
         seed = np.random.randint(0, 2 ** 31 - 1)
     emit_seed = kwargs.pop("emit_seed", None)
-    traced = 0
-    while traced < num_rays:
+    kwargs.pop("workers", None)
+    session = Session(scene, device=kwargs.pop("device", None), emission=kwargs.pop("emission", "auto"))
+    if session.emission == "device" and emit_seed is None:
+        emit_seed = np.random.randint(0, 2 ** 31 - 1)
+    def submit(traced):
         n = min(bundle, num_rays - traced)
-        extra = {}
-        if kwargs.get("emission") == "device":
-            extra = {"emit_seed": emit_seed, "ray_offset": traced}
-            result = simulate(scene, n, seed=int(seed), **kwargs, **extra)
-        else:
-            bundle_emit_seed = None if emit_seed is None else int(emit_seed) + traced
-            result = simulate(scene, n, seed=int(seed) + traced, emit_seed=bundle_emit_seed,
-                              **kwargs)
-        traced += n
-        yield result, traced
+        if session.emission == "device":
+            # one emission stream for the whole job: ray i of the job is the same photon
+            # whatever the bundle size
+            return session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=traced, **kwargs), n
+        bundle_emit_seed = None if emit_seed is None else int(emit_seed) + traced
+        return session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, **kwargs), n
+
+    traced = 0
+    try:
+        pending = submit(0) if num_rays > 0 else None
+        while pending is not None:
+            handle, n = pending
+            following = traced + n
+            # bundle k+1 is traced while the consumer works on bundle k
+            pending = submit(following) if following < num_rays else None
+            result = session.collect(handle)
+            traced = following
+            yield result, traced
+    finally:
+        session.close()

@@ -17,6 +17,8 @@ Unrecognised delegates keep working through the per-ray Python fallback
 """
 import functools
 
+import collections.abc
+
 import numpy as np
 
 from pvtrace_amd import light as Lm
@@ -196,30 +198,71 @@ def emit_bundle(scene, num_rays, seed=None):
     positions = np.zeros((num_rays, 3))
     directions = np.zeros((num_rays, 3))
     wavelengths = np.zeros(num_rays)
-    sources = np.empty(num_rays, dtype=object)
+    sources = None if all(tab.builtin) else np.empty(num_rays, dtype=object)
     for i, node in enumerate(tab.nodes):
-        rows = np.arange(i, num_rays, tab.n_lights)
-        if rows.size == 0:
+        rows = slice(i, num_rays, tab.n_lights)
+        count = len(range(i, num_rays, tab.n_lights))
+        if count == 0:
             continue
         if not tab.builtin[i]:
             # unknown delegate: one Python call per ray (uses global np.random)
-            for row, ray in zip(rows, node.emit(rows.size)):
+            for row, ray in zip(range(i, num_rays, tab.n_lights), node.emit(count)):
                 world = ray.representation(node, scene.root)
                 positions[row] = world.position
                 directions[row] = world.direction
                 wavelengths[row] = world.wavelength
                 sources[row] = world.source
             continue
-        pos, direc, wl = _sample_light(tab, i, rows.size, uniform)
+        pos, direc, wl = _sample_light(tab, i, count, uniform)
         m = tab.light_to_world[i]
         positions[rows] = pos @ m[:3, :3].T + m[:3, 3]
         directions[rows] = direc @ m[:3, :3].T
         wavelengths[rows] = wl
-        sources[rows] = tab.names[i]
+        if sources is not None:
+            sources[rows] = tab.names[i]
+    if sources is None:
+        return positions, directions, wavelengths, RoundRobinSources(tab.names, num_rays)
     return positions, directions, wavelengths, sources.tolist()
 
 
-def sources_for(scene, num_rays):
+class RoundRobinSources(collections.abc.Sequence):
+    """The `sources` list of a bundle -- ray i comes from light ``(offset + i) % n_lights``
+    (reference emit.py:112-116 builds the list eagerly; 10^6 Python strings cost more than
+    tracing 10^6 photons here, so this is the same sequence, computed on demand).  Compares
+    equal to the equivalent list."""
+
+    def __init__(self, names, length, offset=0):
+        self.names = list(names)
+        self.length = int(length)
+        self.offset = int(offset)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            start, stop, step = index.indices(self.length)
+            if step == 1:
+                return RoundRobinSources(self.names, max(stop - start, 0), self.offset + start)
+            return [self[i] for i in range(start, stop, step)]
+        if index < 0:
+            index += self.length
+        if not 0 <= index < self.length:
+            raise IndexError("ray index out of range")
+        return self.names[(self.offset + index) % len(self.names)]
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, RoundRobinSources)):
+            return len(other) == self.length and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    def tolist(self):
+        return list(self)
+
+    def __repr__(self):
+        return f"RoundRobinSources({self.names!r}, {self.length})"
+
+
+def sources_for(scene, num_rays, offset=0):
     """Light name of each ray index (round-robin), without sampling anything."""
-    names = [node.light.name for node in scene.light_nodes]
-    return [names[i % len(names)] for i in range(num_rays)]
+    return RoundRobinSources([node.light.name for node in scene.light_nodes], num_rays, offset)

@@ -25,7 +25,7 @@ def test_engine_is_available_and_native_library_is_loaded():
 
 def test_simulate_equals_oracle_on_the_same_emitted_rays():
     scene = scenes.bench_slab(recorders=True)
-    result = engine.simulate(scene, 4000, seed=11, emit_seed=3, max_events=96)
+    result = engine.simulate(scene, 4000, seed=11, emit_seed=3, max_events=96, emission="host")
     pos, dirs, wl, src = emit_bundle(scene, 4000, seed=3)
     cpu = O.trace_bundle(result.compiled, pos, dirs, wl, 11, 1000, 96, 0, 1, 1, math_mode=O.MATH_PORTABLE)
     assert_bundles_identical(result.data, cpu, sums_rtol=1e-12)
