@@ -1505,7 +1505,12 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     for (int i = 0; i < t->n_abs; i++) { gd[abs_x0 + i] = t->abs_x[i]; gd[abs_y0 + i] = t->abs_y[i]; }
     for (int i = 0; i < t->n_ems; i++) { gd[ems_x0 + i] = t->ems_x[i]; gd[ems_c0 + i] = t->ems_cdf[i]; }
 
-    PvtScene* s = new PvtScene();
+    // owned until every upload has succeeded: a failing HIP call must not leak the scene
+    struct Owner {
+        PvtScene* p;
+        ~Owner() { if (p) pvt_scene_destroy(p); }
+    } owner{new PvtScene()};
+    PvtScene* s = owner.p;
     s->device = device;
     s->lay = lay;
     s->nd = (int)gd.size();
@@ -1530,6 +1535,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     }
     HIP_TRY(hipMemcpy(s->d_gd, gd.data(), gd.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_gi, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice));
+    owner.p = nullptr;
     *out = s;
     return PVT_OK;
 }
