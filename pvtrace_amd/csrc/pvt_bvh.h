@@ -5,8 +5,8 @@
 // the traversal is `i = hit ? i + 1 : skip[i]` with no per-lane stack in scratch or LDS.  A
 // photon needs EVERY forward crossing of a mesh (the container rule counts them,
 // _kernel.pyx:684-714), so front-to-back ordering buys nothing and a fixed order is free.
-// Leaves hold up to kLeafTris triangles, pre-gathered (vertices + face normal + face id) so a
-// leaf is one contiguous run of 104-byte records.
+// Leaves hold one triangle (up to 8 for tiny meshes), pre-gathered (vertices + face normal +
+// face id) so a leaf is one contiguous run of 104-byte records.
 //
 // The boxes are padded by 1e-7 of the mesh diagonal: culling must be conservative with respect
 // to the (differently rounded) watertight triangle test, so that the set of crossings found
@@ -25,7 +25,7 @@ struct BvhNode {      // 64 bytes
     double lo[3], hi[3];
     int skip;         // next node when this subtree is culled or finished
     int tri_start;    // leaves: first triangle record; inner nodes: -1
-    int tri_count;    // leaves: 1..kLeafTris; inner nodes: 0
+    int tri_count;    // leaves: 1..8; inner nodes: 0
     int pad;
 };
 struct MeshTri {      // 104 bytes
@@ -34,7 +34,10 @@ struct MeshTri {      // 104 bytes
     long long face;   // index in the scene's pooled face table (tie-break key, diagnostics)
 };
 
-constexpr int kLeafTris = 4;
+// Leaf size: the watertight triangle test costs several box tests, so large meshes get one
+// triangle per leaf (measured on MI355X: 20 480-face ball 3.2 ms vs 4.5 ms with 4 per leaf);
+// for a handful of faces the tree is not worth walking and leaves hold up to 8.
+constexpr int kSmallMesh = 32, kSmallLeaf = 8, kLargeLeaf = 1;
 
 class BvhBuilder {
 public:
@@ -65,6 +68,7 @@ public:
                                 (hi[2] - lo[2]) * (hi[2] - lo[2]));
         pad_ = 1e-7 * diag + 1e-300;
         f0_ = f0;
+        leaf_ = count <= kSmallMesh ? kSmallLeaf : kLargeLeaf;
         const int root = (int)nodes_.size();
         build(0, count);
         return root;
@@ -89,7 +93,7 @@ private:
         double lo[3], hi[3];
         bounds(begin, end, lo, hi);
         for (int a = 0; a < 3; a++) { nodes_[me].lo[a] = lo[a] - pad_; nodes_[me].hi[a] = hi[a] + pad_; }
-        if (end - begin <= kLeafTris) {
+        if (end - begin <= leaf_) {
             nodes_[me].tri_start = (int)tris_.size();
             nodes_[me].tri_count = end - begin;
             std::sort(order_.begin() + begin, order_.begin() + end);   // face order inside a leaf
@@ -138,6 +142,7 @@ private:
     std::vector<double> cx_;
     double pad_ = 0.0;
     int f0_ = 0;
+    int leaf_ = kLargeLeaf;
 };
 
 }  // namespace pvt
