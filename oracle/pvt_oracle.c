@@ -854,7 +854,12 @@ void pvt_oracle_math(int fn, int math_mode, const double* x, double* y, long n) 
             case 6: y[i] = 1.0 / x[i]; break;
             case 7: y[i] = m_sin(&M, x[i]) * m_cos(&M, x[i]); break;
             case 8: { Rng g; rng_seed(&g, (uint64_t)x[i]); rng_uniform(&g); y[i] = rng_uniform(&g); break; }
-            default: y[i] = x[i] / (x[i] + 3.0); break;
+            case 9: y[i] = x[i] / (x[i] + 3.0); break;
+            /* plain IEEE divisions the device replaces by its known-divisor sequence */
+            case 10: y[i] = x[i] / C_CM_PER_S; break;
+            case 11: y[i] = x[i] / 1.5; break;
+            case 12: y[i] = x[i] / (800.0 - 400.0); break;
+            default: { double d = x[i] * 0.7310585786300049 + 0.25; y[i] = x[i] / d; break; }
         }
     }
 }

@@ -66,14 +66,15 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // Scene blobs are arrays of fixed-stride RECORDS (one double blob, one int32 blob), so a
 // table element is addressed as base + index*stride + field with compile-time strides
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
-enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND = 26 };           // node doubles
+enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND_RN = 26, ND = 27 };  // node doubles (RN: RN(1/n))
 enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI };  // node ints (NI_MESH: BVH root, -1 = none)
-enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C, CD };                         // component doubles
+enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C,
+       CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN)
 enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N,
        CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI_ABS_HIST, CI_EMS_HIST, CI };  // *_G*: guide tables; *_HIST: step tables
 enum { RD_FACET = 0, RD_ATOL = 3, RD = 4 };                                     // recorder
 enum { RI_NODE = 0, RI_EVENT, RI_HAS_FACET, RI_HSTART, RI_HN, RI_SRC_MODE, RI_SRC_ID, RI };
-enum { HD_LO_A = 0, HD_HI_A, HD_LO_B, HD_HI_B, HD };                             // histogram
+enum { HD_LO_A = 0, HD_HI_A, HD_LO_B, HD_HI_B, HD_RA, HD_RB, HD };               // histogram (RA/RB: RN(1/(hi-lo)), NaN = divide)
 enum { HI_PA = 0, HI_PB, HI_NA, HI_NB, HI_OFF, HI };
 enum { KD_FACET = 0, KD_LO = 3, KD_HI = 6, KD_REFL = 9, KD = 10 };              // coating
 enum { KI_RMODE = 0, KI_TMODE, KI };
@@ -85,6 +86,8 @@ struct Lay {  // record bases (elements) inside the blobs; spectra follow the re
     int cand_i;     // (n_nodes*7) x {start, count, bin[6]}: recorders that can fire for a
                     // (node, selector): a list to walk + facet recorders found by normal bin
     int cand_list;  // recorder ids, ascending within each (node, selector)
+    int crit_d;     // (n_nodes x n_nodes) critical angles asin(n[a]/n[c]) (+inf where n[a] >= n[c]),
+                    // or -1 when the scene has too many nodes for the table
 };
 
 struct EmitOff {  // emitter blobs (global only; read once per photon)
@@ -183,6 +186,25 @@ struct V3 {
 };
 __device__ __forceinline__ double dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
+// RN(x / y) for a divisor known in advance, given z = RN(1/y) computed once on the host:
+// five multiply-adds instead of the ~25-instruction IEEE division expansion.  q1 = RN(x z) is
+// within 1.5 ulp of x/y; one residual correction (r = x - q y, exact up to a rounding that
+// cannot matter at that magnitude) makes q2 the rounding of a value within 2^-52 ulp of x/y, hence
+// a faithful quotient; Markstein's theorem (z correctly rounded, q faithful, residual by FMA)
+// then makes the second correction EXACTLY RN(x/y).  Preconditions: y, z finite non-zero
+// normal, x finite, no underflow of the quotient (durations, indices and bin coordinates are
+// many orders of magnitude inside the normal range).  A zero x may come back with the other
+// sign (every use adds it or truncates it).  `tests/test_gpu_parity.py` checks the sequence
+// against the host's division on random and adversarial operands.
+__device__ __forceinline__ double div_known(double x, double y, double z) {
+    double q = x * z;
+    double r = __builtin_fma(-q, y, x);
+    q = __builtin_fma(r, z, q);
+    r = __builtin_fma(-q, y, x);
+    return __builtin_fma(r, z, q);
+}
+constexpr double kRcpCcm = 1.0 / kCcm;   // correctly rounded by the compiler
+
 // np.interp-like clamped interpolation (_kernel.pyx:219-238).  The reference bisects the
 // whole table for `lo` = the largest index with xs[lo] <= x; that index is unique, so any
 // search that finds it gives identical results.  Here a host-built guide table (n buckets of
@@ -192,7 +214,7 @@ __device__ __forceinline__ double dot3(const V3& a, const V3& b) { return a.x * 
 // runs inside the bracket: typically 0-1 steps instead of ~log2(n) dependent LDS reads.
 template <bool TAB_LDS>
 __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n,
-                                                 int guide, double scale, int hist) {
+                                                 int guide, double scale, int hist, double rcp) {
     if (n == 1) return T.dv(ys);
     const double x0 = T.dv(xs), xl = T.dv(xs + n - 1);
     if (x <= x0) return T.dv(ys);
@@ -223,7 +245,10 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
     }
     const double ylo = T.dv(ys + lo), yhi = T.dv(ys + hi);
     if (xhi == xlo) return ylo;
-    return ylo + (yhi - ylo) * (x - xlo) / (xhi - xlo);
+    // evenly spaced abscissae (every interval has the same bits, checked by the host): the
+    // divisor is known in advance, see div_known
+    const double num = (yhi - ylo) * (x - xlo), width = xhi - xlo;
+    return ylo + (rcp == rcp ? div_known(num, width, rcp) : num / width);
 }
 // same, tables in global memory (emitter spectra)
 __device__ __forceinline__ double interp_global(const double* xs, const double* ys, int n, double x) {
@@ -364,7 +389,11 @@ __global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, d
         case 6: r = 1.0 / v; break;
         case 7: { double s, c; pvt_sincos(v, &s, &c); r = s * c; break; }
         case 8: { Rng g; rng_seed(g, (unsigned long long)v); rng_uniform(g); r = rng_uniform(g); break; }
-        default: r = v / (v + 3.0); break;
+        case 9: r = v / (v + 3.0); break;
+        case 10: r = div_known(v, kCcm, kRcpCcm); break;
+        case 11: r = div_known(v, 1.5, 1.0 / 1.5); break;
+        case 12: r = div_known(v, 800.0 - 400.0, 1.0 / (800.0 - 400.0)); break;
+        default: { double d = v * 0.7310585786300049 + 0.25; r = div_known(v, d, 1.0 / d); break; }
     }
     y[i] = r;
 }
@@ -836,7 +865,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         if (hit == A.root) {  // leaves the scene (:728-744)
                             pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
                             travelled += t0;
-                            duration += t0 * n_container / kCcm;
+                            duration += div_known(t0 * n_container, kCcm, kRcpCcm);
                             ev_kind = PVT_EV_EXIT; ev_hit = hit; ev_adjacent = adjacent;
                             terminal = true;
                             t_sel = PVT_REC_EXIT; t_node = hit; t_normal = true;
@@ -851,7 +880,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                             for (int k = 0; k < ccount; k++) {
                                 const int ci = L.comp_i + (cbase + k) * CI;
                                 alpha += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
-                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST));
+                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
+                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_RCP));
                                 if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
                                 else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
                             }
@@ -861,7 +891,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                             if (depth < t0) {  // absorbed (:762-832)
                                 pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
                                 travelled += depth;
-                                duration += depth * n_container / kCcm;
+                                duration += div_known(depth * n_container, kCcm, kRcpCcm);
                                 const double target = rng_uniform(rng) * alpha;
                                 int comp = cbase;
                                 if (ccount <= 4) {
@@ -874,7 +904,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                     for (int k = 0; k < ccount; k++) {
                                         const int ci = L.comp_i + (cbase + k) * CI;
                                         running += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
-                                                                  T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST));
+                                                                  T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
+                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_RCP));
                                         if (target <= running) { comp = cbase + k; break; }
                                     }
                                 }
@@ -924,10 +955,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                                 double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
                                                 e_nm = 1240.0 / e_ev;
                                             }
-                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_X), T.iv(ci + CI_EMS_HIST));
+                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_X), T.iv(ci + CI_EMS_HIST), T.dv(L.comp_d + comp * CD + CD_EMS_RCP_X));
                                         }
                                         double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
-                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_C), T.iv(ci + CI_EMS_HIST));
+                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_C), T.iv(ci + CI_EMS_HIST), T.dv(L.comp_d + comp * CD + CD_EMS_RCP_C));
                                         tau = T.dv(L.comp_d + comp * CD + CD_TAU_RAD);
                                         ev_kind = PVT_EV_EMIT;
                                     } else {
@@ -946,7 +977,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                 // ---- surface interaction (:834-895) ---------
                                 pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
                                 travelled += t0;
-                                duration += t0 * n_container / kCcm;
+                                duration += div_known(t0 * n_container, kCcm, kRcpCcm);
                                 ev_hit = hit;
                                 if (adjacent < 0) {  // malformed scene (:840-845)
                                     ev_kind = PVT_EV_KILL;
@@ -1059,14 +1090,20 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             // ---- Fresnel / coating decision at the surface (:865-895) ------------
             const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
             const double angle = ac;
-            double r = 0.0, n1 = 0.0, n2 = 0.0;
+            double r = 0.0, n1 = 0.0, n2 = 0.0, rn2 = 0.0;
             if (fres) {  // unpolarised Fresnel, 1.0 beyond the critical angle (:406-419)
                 n1 = T.dv(container * ND + ND_N);
                 n2 = T.dv(adjacent * ND + ND_N);
-                if (n2 < n1 && angle > pvt_asin(n2 / n1)) {
+                rn2 = T.dv(adjacent * ND + ND_RN);
+                // critical angle asin(n2/n1): a function of the node pair, tabulated by the host
+                // with the same pvt_asin (small scenes), else computed here
+                bool tir;
+                if (L.crit_d >= 0) tir = angle > T.dv(L.crit_d + container * A.n_nodes + adjacent);
+                else tir = n2 < n1 && angle > pvt_asin(div_known(n2, n1, T.dv(container * ND + ND_RN)));
+                if (tir) {
                     r = 1.0;
                 } else {
-                    double q = n1 / n2 * s1;
+                    double q = div_known(n1, n2, rn2) * s1;
                     double k = pvt_sqrt(1.0 - q * q);
                     double rs1 = n1 * c1 - n2 * k, rs2 = n1 * c1 + n2 * k;
                     double rs = (rs1 / rs2) * (rs1 / rs2);
@@ -1126,7 +1163,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 bool matched = false;
                 if (coat >= 0) matched = T.iv(L.coat_i + coat * KI + KI_TMODE) == 1;
                 if (fres && !matched) {  // Snell, vector form (:436-446)
-                    double n = n1 / n2;
+                    double n = div_known(n1, n2, rn2);
                     double dd = dot3(dir, nf);
                     double c = pvt_sqrt(1.0 - n * n * (1.0 - dd * dd));
                     double sign = dd < 0.0 ? -1.0 : 1.0;
@@ -1219,12 +1256,16 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                          : pr == 4 ? lpos.x : pr == 5 ? lpos.y : lpos.z;
                                 };
                                 const double la = T.dv(hd_ + HD_LO_A), ha = T.dv(hd_ + HD_HI_A);
-                                const int ia = (int)((prop(pa) - la) / (ha - la) * na);
+                                const double ra = T.dv(hd_ + HD_RA);
+                                const double qa = ra == ra ? div_known(prop(pa) - la, ha - la, ra) : (prop(pa) - la) / (ha - la);
+                                const int ia = (int)(qa * na);
                                 if (ia < 0 || ia >= na) continue;
                                 int slot = T.iv(hi_ + HI_OFF) + ia;
                                 if (pb >= 0) {
                                     const double lb = T.dv(hd_ + HD_LO_B), hb = T.dv(hd_ + HD_HI_B);
-                                    const int ib = (int)((prop(pb) - lb) / (hb - lb) * nb);
+                                    const double rb = T.dv(hd_ + HD_RB);
+                                    const double qb = rb == rb ? div_known(prop(pb) - lb, hb - lb, rb) : (prop(pb) - lb) / (hb - lb);
+                                    const int ib = (int)(qb * nb);
                                     if (ib < 0 || ib >= nb) continue;
                                     slot = T.iv(hi_ + HI_OFF) + ia * nb + ib;
                                 }
@@ -1367,7 +1408,21 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.coat_d = lay.hist_d + H * HD;
     const int spec_d = lay.coat_d + K * KD;
     const int abs_x0 = spec_d, abs_y0 = abs_x0 + t->n_abs, ems_x0 = abs_y0 + t->n_abs, ems_c0 = ems_x0 + t->n_ems;
-    std::vector<double> gd((size_t)ems_c0 + t->n_ems + 1, 0.0);
+    bool index_ok = true;   // refractive indices the known-divisor division is proven for
+    for (int n = 0; n < N; n++) {
+        const double v = t->refractive_index[n];
+        if (!(std::isfinite(v) && v > 1e-100 && v < 1e100)) index_ok = false;
+    }
+    if (!index_ok) return fail(PVT_ERR_INVALID, "refractive indices must be finite and positive");
+    constexpr int kCritNodes = 16;
+    lay.crit_d = N <= kCritNodes ? ems_c0 + t->n_ems : -1;
+    std::vector<double> gd((size_t)ems_c0 + t->n_ems + (lay.crit_d >= 0 ? (size_t)N * N : 0) + 1, 0.0);
+    if (lay.crit_d >= 0)
+        for (int c = 0; c < N; c++)
+            for (int a = 0; a < N; a++) {
+                const double n1 = t->refractive_index[c], n2 = t->refractive_index[a];
+                gd[lay.crit_d + c * N + a] = n2 < n1 ? pvt_asin(n2 / n1) : INFINITY;   // same pvt_asin as the device
+            }
     lay.comp_i = N * NI;
     lay.rec_i = lay.comp_i + C * CI;
     lay.hist_i = lay.rec_i + R * RI;
@@ -1431,6 +1486,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             for (int c = 0; c < 3; c++) d[ND_L2W + r * 3 + c] = t->local_to_world[n * 16 + r * 4 + c];
         for (int c = 0; c < 4; c++) d[ND_PARAMS + c] = t->geom_params[n * 4 + c];
         d[ND_N] = t->refractive_index[n];
+        d[ND_RN] = 1.0 / t->refractive_index[n];
         int* q = gi.data() + n * NI;
         q[NI_GEOM] = t->geom_type[n];
         q[NI_SURF] = t->surface_type[n];
@@ -1468,6 +1524,23 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         build_guide(t->abs_x + t->comp_abs_start[c], t->comp_abs_n[c], q[CI_ABS_G], &d[CD_ABS_SCALE]);
         build_guide(t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GX], &d[CD_EMS_SCALE_X]);
         build_guide(t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GC], &d[CD_EMS_SCALE_C]);
+        // RN(1/spacing) when EVERY interval of the abscissae has the same bits and the ordinates
+        // keep the quotient inside div_known's domain (no -0.0, no extreme magnitudes)
+        auto even_rcp = [](const double* xs, const double* ys, int n) -> double {
+            if (n < 2) return NAN;
+            const double w = xs[1] - xs[0];
+            if (!(w > 1e-100 && w < 1e100)) return NAN;
+            for (int i = 1; i + 1 < n; i++) if (xs[i + 1] - xs[i] != w) return NAN;
+            for (int i = 0; i < n; i++) {
+                if (ys[i] == 0.0 && std::signbit(ys[i])) return NAN;
+                if (!(std::fabs(ys[i]) < 1e100)) return NAN;
+                if (i > 0 && ys[i] != ys[i - 1] && std::fabs(ys[i] - ys[i - 1]) < 1e-100) return NAN;
+            }
+            return 1.0 / w;
+        };
+        d[CD_ABS_RCP] = even_rcp(t->abs_x + t->comp_abs_start[c], t->abs_y + t->comp_abs_start[c], t->comp_abs_n[c]);
+        d[CD_EMS_RCP_X] = even_rcp(t->ems_x + t->comp_ems_start[c], t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c]);
+        d[CD_EMS_RCP_C] = even_rcp(t->ems_cdf + t->comp_ems_start[c], t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c]);
     }
     for (int r = 0; r < R; r++) {
         double* d = gd.data() + lay.rec_d + r * RD;
@@ -1486,6 +1559,11 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         double* d = gd.data() + lay.hist_d + h * HD;
         d[HD_LO_A] = t->hist_lo_a[h]; d[HD_HI_A] = t->hist_hi_a[h];
         d[HD_LO_B] = t->hist_lo_b[h]; d[HD_HI_B] = t->hist_hi_b[h];
+        auto rcp_or_nan = [](double width) {   // NaN: the kernel divides for real
+            return (std::isfinite(width) && std::fabs(width) > 1e-290 && std::fabs(width) < 1e290) ? 1.0 / width : NAN;
+        };
+        d[HD_RA] = rcp_or_nan(t->hist_hi_a[h] - t->hist_lo_a[h]);
+        d[HD_RB] = rcp_or_nan(t->hist_hi_b[h] - t->hist_lo_b[h]);
         int* q = gi.data() + lay.hist_i + h * HI;
         q[HI_PA] = t->hist_prop_a[h]; q[HI_PB] = t->hist_prop_b[h];
         q[HI_NA] = t->hist_na[h]; q[HI_NB] = t->hist_nb[h]; q[HI_OFF] = t->hist_offset[h];

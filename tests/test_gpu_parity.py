@@ -28,8 +28,19 @@ def gpu_and_oracle(scene, n, mode, seed=42, emit_seed=123, **kw):
     return gpu, cpu
 
 
+def _division_operands(rng, n, divisor):
+    """Random operands over many binades plus the hard cases of a division: numerators whose
+    quotient by `divisor(x)` lands on, or half an ulp away from, a representable number."""
+    x = np.concatenate((rng.random(n // 2) * 10.0 ** rng.uniform(-30, 30, n // 2), rng.normal(size=n // 2) * 1e-9))
+    q = rng.random(n // 2) * 10.0 ** rng.uniform(-12, 12, n // 2)
+    d = divisor(q) if callable(divisor) else np.full_like(q, divisor)
+    exact = (q.astype(np.longdouble) * d.astype(np.longdouble)).astype(np.float64)
+    half = ((q.astype(np.longdouble) + np.spacing(q).astype(np.longdouble) / 2) * d.astype(np.longdouble)).astype(np.float64)
+    return np.concatenate((x, exact, half, [0.0, 1.0, 2.99792458e10, 1.5, 400.0]))
+
+
 @pytest.mark.parametrize("fn", ["log", "sin", "cos", "asin", "acos", "sqrt", "rcp",
-                                "sincos_product", "uniform2", "ratio"])
+                                "sincos_product", "uniform2", "ratio", "div_c", "div_n", "div_hist", "div_any"])
 def test_device_arithmetic_is_bit_identical_to_host(fn):
     """The premise of everything below: IEEE divide/sqrt, u64->f64 and pvt_math.h give the
     same bits on gfx950 (hipcc, -ffp-contract=off) as on the host (gcc)."""
@@ -40,8 +51,13 @@ def test_device_arithmetic_is_bit_identical_to_host(fn):
         "asin": rng.random(n) * 2 - 1, "acos": rng.random(n) * 2 - 1, "sqrt": rng.random(n) * 1e6,
         "rcp": rng.normal(size=n) * 1e3, "sincos_product": rng.random(n) * 2 * np.pi,
         "uniform2": np.floor(rng.random(n) * 2 ** 52), "ratio": rng.random(n) * 100,
+        # the kernel's known-divisor division (5 multiply-adds) must equal the host's IEEE division
+        "div_c": _division_operands(rng, n, 2.99792458e10), "div_n": _division_operands(rng, n, 1.5),
+        "div_hist": _division_operands(rng, n, 400.0),
+        "div_any": _division_operands(rng, n, lambda q: q * 0.7310585786300049 + 0.25),
     }[fn]
-    x = np.concatenate((x, [1.0, 0.5, 1e-300, 0.9999999999999999]))
+    if not fn.startswith("div_"):   # (a subnormal quotient is outside div_known's stated domain)
+        x = np.concatenate((x, [1.0, 0.5, 1e-300, 0.9999999999999999]))
     dev = native.selftest_math(O.MATH_FN[fn], x)
     host = O.math(fn, x, math_mode=O.MATH_PORTABLE)
     assert np.array_equal(dev, host, equal_nan=True), int(np.sum(dev != host))
