@@ -719,10 +719,14 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         const double dz = pick(dd, kz);
                         if (dz < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
                         const double shx = pick(dd, kx) / dz, shy = pick(dd, ky) / dz, shz = 1.0 / dz;
+                        // Box culling only has to be conservative (a false hit costs a triangle test, a
+                        // false miss would lose a crossing).  A ray parallel to a slab gets a huge finite
+                        // reciprocal instead of inf: inside the slab the two plane distances then have
+                        // opposite signs (interval covers everything), outside the same sign (pushed out
+                        // of range, or a harmless false hit), and 0 * inf = NaN can never arise.
                         double inv[3];
-                        bool par[3];
 #pragma unroll
-                        for (int a = 0; a < 3; a++) { par[a] = pvt_fabs(dd[a]) < 1e-300; inv[a] = 1.0 / dd[a]; }
+                        for (int a = 0; a < 3; a++) inv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
                         long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
                         int i = T.iu(node * NI + NI_MESH);
                         const int end = A.bvh[i].skip;
@@ -731,15 +735,9 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                             double tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
                             for (int a = 0; a < 3; a++) {
-                                double ta = (b->lo[a] - oo[a]) * inv[a], tb = (b->hi[a] - oo[a]) * inv[a];
-                                if (par[a]) {
-                                    const bool outside = oo[a] < b->lo[a] || oo[a] > b->hi[a];
-                                    ta = outside ? INFINITY : -INFINITY;
-                                    tb = outside ? -INFINITY : INFINITY;
-                                }
-                                if (ta > tb) { double tmp = ta; ta = tb; tb = tmp; }
-                                if (ta > tmin) tmin = ta;
-                                if (tb < tmax) tmax = tb;
+                                const double ta = (b->lo[a] - oo[a]) * inv[a], tb = (b->hi[a] - oo[a]) * inv[a];
+                                tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                                tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
                             }
                             if (tmax < tmin || tmax < 0.0) { i = b->skip; continue; }
                             const int tn = b->tri_count;
