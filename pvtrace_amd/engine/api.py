@@ -195,13 +195,43 @@ def download(compiled, tallies, log, n_rays, record_every, max_events):
         data["rec_crossings"] = tallies["rec_crossings"][:nrec].cpu().numpy()
         data["rec_bins"] = tallies["rec_bins"][: int(compiled.total_bins)].cpu().numpy()
     data["rec_sums"] = tallies["rec_sums"][: nrec * 8].cpu().numpy().reshape(nrec, 4, 2)
-    for name, dtype, width in native.EVENT_LOG_COLUMNS:
-        if log is not None and rows > 0:
-            col = log[name][: rows * width].cpu().numpy()
-        else:
+    if log is None or rows == 0:
+        for name, dtype, width in native.EVENT_LOG_COLUMNS:
             col = np.zeros(0, dtype=dtype)
-        data[name] = col.reshape(rows, 3) if width == 3 else col
+            data[name] = col.reshape(0, 3) if width == 3 else col
+        return data
+    # The log is `max_events` rows per recorded ray but a ray writes only `counts[j]` of them
+    # (10 of 128 on the LSC): gather the written rows on the GPU, move those, and scatter them into
+    # host arrays pre-filled like the reference's (`np.zeros` / `np.full(-1)`, _kernel.pyx:1035-1047).
+    # Untouched pages of the zero-filled columns are never committed, as in the reference.
+    import torch
+
+    counts = log["counts"][:n_recorded]
+    used = int(counts.sum().item())
+    sparse = used < 0.6 * rows
+    if sparse:
+        written = (torch.arange(max_events, device=counts.device, dtype=torch.int32)[None, :]
+                   < counts[:, None]).reshape(-1)
+        index = written.nonzero().squeeze(1)
+        index_host = index.cpu().numpy()
+    for name, dtype, width in native.EVENT_LOG_COLUMNS:
+        col = log[name][: rows * width]
+        if sparse:
+            fill = -1 if name in ("hit", "container", "adjacent", "component", "source") else 0
+            shape = (rows, 3) if width == 3 else (rows,)
+            # zero columns stay uncommitted (calloc); the -1 fill is the reference's eager cost too
+            host = np.zeros(shape, dtype=dtype) if fill == 0 else np.full(shape, fill, dtype=dtype)
+            if used:
+                packed = (col.view(rows, 3) if width == 3 else col)[index].cpu().numpy()
+                host[index_host] = packed
+            data[name] = host
+        else:
+            host = col.cpu().numpy()
+            data[name] = host.reshape(rows, 3) if width == 3 else host
     return data
+
+
+_SIDE_STREAMS = {}   # device index -> [torch.cuda.Stream, torch.cuda.Stream]
 
 
 class Session:
@@ -268,8 +298,13 @@ class Session:
                 rays = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev)
                              for a in (pos, direc, wl))
             if not self._slots:
-                self._slots = [{"stream": torch.cuda.Stream(device=device), "tallies": dscene.new_tallies()}
-                               for _ in range(2)]
+                # the two side streams are shared by every Session on this device: torch's caching
+                # allocator pools memory per stream, so fresh streams per call would re-malloc
+                # (and later free) every buffer, multi-GB event logs included
+                streams = _SIDE_STREAMS.setdefault(device, [])
+                while len(streams) < 2:
+                    streams.append(torch.cuda.Stream(device=device))
+                self._slots = [{"stream": st, "tallies": dscene.new_tallies()} for st in streams]
             slot = self._slots[self._submitted % 2]
             self._submitted += 1
             stream, tallies = slot["stream"], slot["tallies"]
