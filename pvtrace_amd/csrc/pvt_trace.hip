@@ -33,6 +33,7 @@
 #include <atomic>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/pvtrace_hip.h"
@@ -53,7 +54,7 @@ namespace {
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
 constexpr int kWaves = kBlock / 64;
-constexpr int kCursorSlots = 16;
+constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
 constexpr int kXSlots = 128;         // LDS photon-state slots used to repack a draining workgroup
 // workgroup control words in LDS
 enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_WORDS = 16 };
@@ -1356,9 +1357,10 @@ struct PvtScene {
     int* d_ei = nullptr;
     pvt::BvhNode* d_bvh = nullptr;      // triangle meshes: BVH nodes + gathered triangles
     pvt::MeshTri* d_tris = nullptr;
-    unsigned int* d_cursor = nullptr;   // ring of kCursorSlots cursors (64 B apart): launches on
+    unsigned int* d_cursor = nullptr;   // kCursorSlots cursors (64 B apart), one per stream: launches on
                                         // different streams may overlap, each needs its own
-    std::atomic<unsigned int> launches{0};
+    std::mutex slot_mutex;              // launches on one stream are ordered and may share a cursor;
+    std::vector<hipStream_t> slot_of;   // index = cursor slot owned by that stream
     int num_cu = 0;
     int last_grid = 0, last_lds = 0;
     size_t lds_limit = 0;
@@ -1742,7 +1744,17 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
         HIP_TRY(hipMemsetAsync(log->travelled, 0, rows * 8, st));
         HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
     }
-    a.cursor = s->d_cursor + 16 * (s->launches.fetch_add(1) % kCursorSlots);
+    {   // the cursor belongs to the stream: two launches can only overlap on different streams
+        std::lock_guard<std::mutex> lock(s->slot_mutex);
+        size_t slot = 0;
+        while (slot < s->slot_of.size() && s->slot_of[slot] != st) slot++;
+        if (slot == s->slot_of.size()) {
+            if (slot >= (size_t)kCursorSlots)
+                return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
+            s->slot_of.push_back(st);
+        }
+        a.cursor = s->d_cursor + 16 * slot;
+    }
     HIP_TRY(hipMemsetAsync(a.cursor, 0, PVT_STATS ? 256 : 4, st));
 #if PVT_STATS
     static unsigned long long* g_stats = nullptr;
