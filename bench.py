@@ -159,11 +159,19 @@ def main():
         total_photons = n * world * args.steps
         value = total_photons / elapsed
         achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, instruction_side = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc):   # last committed PMC passes of this same command (tools/gpu_pmc.sh)
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                summary = json.load(open(pmc))
+                traffic = summary.get("hbm_bytes_per_launch")
+                derived = summary.get("derived", {})
+                instruction_side = {
+                    "source": "profiles/pmc_summary.json (" + str(summary.get("stage", "")) + ")",
+                    "valu_wave_instructions_per_photon": derived.get("valu_wave_instructions_per_photon"),
+                    "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
+                    "wait_fraction_of_wave_cycles": derived.get("wait_any_fraction_of_wave_cycles"),
+                }
             except Exception:
                 traffic = None
         nrec = compiled.rec_node.shape[0]
@@ -198,6 +206,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "trace_kernel<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=0,MESH=0>",
                 "kernel_ms_mean": mean_kernel_ms,
+                "instruction_side": instruction_side,
                 "kernel_photons_per_s": n / (mean_kernel_ms * 1e-3),
                 "achieved_at_step_rate": ALGORITHMIC_BYTES_PER_PHOTON * n * args.steps / elapsed / 1e9,
                 "note": "not HBM-bound: 56 algorithmic B/photon; the loop is FP64-VALU/latency/"
