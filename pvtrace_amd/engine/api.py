@@ -4,7 +4,7 @@ Same call signature, result object and `data` dictionary as the reference's
 pvtrace/engine/api.py:197-264 (`simulate`, `simulate_stream`, `EngineResult`,
 `RecorderResult`, `is_available`).  What differs is everything underneath: the
 scene is flattened to SoA tables, uploaded once to HBM, and the whole per-photon
-loop runs in the HIP kernel of csrc/pvt_trace.hip; tallies come back as a few
+loop runs in the HIP kernel of csrc/pvt_trace_kernel.h; tallies come back as a few
 KB.  Keyword-only extras: `device` (GPU index), `emission` ("host" = numpy
 sampling like the reference, "device" = sampled on the GPU from per-ray
 streams, "auto" = device when the lights allow it) and `emit_seed`.  `workers` is accepted for compatibility and ignored

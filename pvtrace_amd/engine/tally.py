@@ -1,6 +1,6 @@
 """Recorder tallies computed in pure Python from (ray, event, metadata) histories.
 
-Host-side mirror of the device tally (csrc/pvt_trace.hip `tally_event`), with
+Host-side mirror of the device tally (the tally block of csrc/pvt_trace_kernel.h), with
 the semantics of the reference's pvtrace/engine/tally.py:26-156: it re-derives
 what every recorder should hold from `EngineResult.histories()` (or any list of
 histories) and is used by the tests to prove the kernel's accumulators exact.

@@ -6,7 +6,7 @@ transformable.py:12-96).  Only analytic primitives the device tracer supports
 exist here; every shape is centred on its node's origin, cylinders run along z.
 
 The per-ray queries (`intersections`, `normal`) are numpy restatements of the
-device functions in csrc/pvt_trace.hip and follow the *kernel* semantics
+device functions in csrc/pvt_trace_kernel.h and follow the *kernel* semantics
 (reference pvtrace/engine/_kernel.pyx:245-400), i.e. Box is analytic f64 rather
 than a triangle mesh.  They exist for host-side plumbing and unit tests; the
 hot path never calls them.

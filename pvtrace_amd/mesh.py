@@ -160,8 +160,8 @@ def is_watertight(faces):
 
 
 # ---------------------------------------------------------------------------
-# host restatement of the device ray/triangle test (csrc/pvt_trace.hip `tri_hit`,
-# oracle/pvt_oracle.c `tri_hit`): watertight shear + edge functions + half-plane tie rule
+# host restatement of the device ray/triangle test (csrc/pvt_trace_kernel.h, mesh branch of the
+# node loop; oracle/pvt_oracle.c `tri_hit`): watertight shear + edge functions + half-plane tie rule
 
 def ray_triangle_distances(vertices, faces, origin, direction):
     """(t, face index) of every crossing with t > EPS_ZERO, sorted by (t, face)."""

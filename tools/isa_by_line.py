@@ -9,7 +9,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                       stderr=subprocess.DEVNULL)
 s = open(os.path.join(tmp, "k.s")).read()
 files = dict(re.findall(r'\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', s)) or dict(re.findall(r'\.file\s+(\d+)\s+"([^"]+)"', s))
-srclines = open(src).read().split("\n")
+srclines = open(os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace_kernel.h")).read().split("\n")
 mathlines = open(os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_math.h")).read().split("\n")
 for f in re.split(r"\n\s*\.globl\s+", s)[1:]:
     name = f.split("\n", 1)[0].strip()
@@ -38,6 +38,6 @@ for f in re.split(r"\n\s*\.globl\s+", s)[1:]:
     top = sorted(counts.items(), key=lambda kv: -kv[1])[:70]
     for (fn, ln), c in top:
         text = ""
-        if fn == "pvt_trace.hip" and 0 < ln <= len(srclines): text = srclines[ln - 1].strip()[:90]
+        if fn == "pvt_trace_kernel.h" and 0 < ln <= len(srclines): text = srclines[ln - 1].strip()[:90]
         if fn == "pvt_math.h" and 0 < ln <= len(mathlines): text = mathlines[ln - 1].strip()[:90]
         print(f"{c:5d} (valu {valu[(fn, ln)]:4d}) {fn}:{ln}: {text}")

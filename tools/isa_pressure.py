@@ -11,7 +11,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                       stderr=subprocess.DEVNULL)
 s = open(os.path.join(tmp, "k.s")).read()
 files = dict(re.findall(r'\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', s)) or dict(re.findall(r'\.file\s+(\d+)\s+"([^"]+)"', s))
-lines = {"pvt_trace.hip": open(src).read().split("\n"),
+lines = {"pvt_trace_kernel.h": open(os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace_kernel.h")).read().split("\n"),
          "pvt_math.h": open(os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_math.h")).read().split("\n")}
 for f in re.split(r"\n\s*\.globl\s+", s)[1:]:
     name = f.split("\n", 1)[0].strip()
