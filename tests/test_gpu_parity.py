@@ -271,3 +271,38 @@ def test_bvh_walk_finds_exactly_the_crossings_of_the_brute_force_oracle():
     cpu = O.trace_bundle(compiled, pos, dirs, wl, 5, 1000, 48, 0, 8, 1, math_mode=O.MATH_PORTABLE)
     assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what="icosphere-4")
     assert cpu["rec_distinct"][0] > 0.6 * n
+
+
+def test_every_kernel_variant_at_once():
+    """The template axes together: mesh geometry (MESH), 6000-point spectra that do not fit LDS
+    (TAB_LDS=false), 150 recorders (wide seen mask), sampled event log (RECORD) and device-side
+    emission (EMIT) — against the oracle's emitter + tracer on the same seeds."""
+    from pvtrace_amd import Absorber, Light, Luminophore, Material, Mesh, Node, Scene, Sphere
+    from pvtrace_amd.engine import Histogram, Recorder
+    from pvtrace_amd.light import ConstantWavelengthMask
+    from pvtrace_amd.material import gaussian
+
+    x = np.linspace(300.0, 1000.0, 6000)
+    world = Node(name="world", geometry=Sphere(10.0, material=Material(1.0)))
+    gem = Node(name="gem", parent=world, geometry=Mesh.icosphere(2, 1.2, material=Material(1.5, components=[
+        Luminophore(np.column_stack((x, 3.0 * gaussian(x, 1.0, 480.0, 40.0))),
+                    emission=np.column_stack((x, gaussian(x, 1.0, 600.0, 40.0))), quantum_yield=0.9, name="dye"),
+        Absorber(0.2, name="host")])))
+    gem.location = (0.0, 0.0, 2.5)
+    gem.rotate(0.5, (1.0, 0.2, 0.0))
+    events = ["entering", "escaping", "reflected", "lost"]
+    gem.recorders = [Recorder(f"r{i}", event=events[i % 4],
+                              histograms=[Histogram("wavelength", 300, 1000, 9)] if i % 7 == 0 else [])
+                     for i in range(150)]
+    Node(name="lamp", parent=world, light=Light(wavelength=ConstantWavelengthMask(470.0), name="lamp"))
+    scene = Scene(world)
+    compiled = compile_scene(scene)
+    emitter = EmitterTables(scene)
+    n, seed, emit_seed, record_every, max_events = 5000, 21, 8, 3, 40
+    gpu = _kernel.trace_bundle(compiled, None, None, n, seed, 1000, max_events, 0, 1, record_every,
+                               emitter=emitter, emit_seed=emit_seed)
+    pos, dirs, wl = O.emit(emitter, n, emit_seed=emit_seed)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, seed, 1000, max_events, 0, 4, record_every,
+                         math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what="all-variants")
+    assert cpu["rec_distinct"][64:].sum() > 0 and cpu["counts"].max() > 4
