@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="bundles kept in flight (HIP streams); 1 = strictly serial launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reduce", choices=("end", "bundle"), default="end",
+                    help="multi-GPU: all-reduce the tallies once per job, inside the timed region "
+                         "(default), or after every bundle")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,9 +126,9 @@ def main():
     dscene = native.DeviceScene(compiled, device=local_rank)
     # Steps are independent bundles; like any streaming consumer of the engine they go
     # through the product's BundlePipeline (engine/pipeline.py): bundle k+1 is enqueued on a
-    # second HIP stream while bundle k drains, every bundle is fully traced, (all-)reduced and
-    # accumulated.  --streams 1 gives the strictly serial schedule.
-    pipe = BundlePipeline(dscene, depth=args.streams, distributed=distributed)
+    # second HIP stream while bundle k drains, every bundle is fully traced and accumulated; the
+    # totals are summed over the ranks before the closing fence.  --streams 1 gives the strictly serial schedule.
+    pipe = BundlePipeline(dscene, depth=args.streams, distributed=distributed, reduce=args.reduce)
     pipe.wait_for_inputs()
 
     def step(k, timed):
@@ -139,12 +142,14 @@ def main():
         torch.cuda.synchronize(dev)
 
     for k in range(args.warmup):
-        step(k, False)
+        step(k, True)      # same path as the timed steps (events included); reset below
+    pipe.reduce_totals()   # also warms the RCCL communicator up (its first collective is slow)
     pipe.reset_totals()
     fence()
     tic = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, True)
+    pipe.reduce_totals()   # fold the streams' totals; RCCL all-reduce over the ranks (reduce="end")
     fence()
     elapsed = time.perf_counter() - tic
     if distributed:
@@ -196,7 +201,8 @@ def main():
                             "(10 cm^-1 peak, qy 1) + 0.1 cm^-1 background, 20-degree cone @555 nm, "
                             "10 recorders, record_every=0, emit_method=kT, maxsteps=1000",
                 "photons_per_gpu_per_step": n,
-                "sharding": f"index-range x{world}, tallies RCCL all-reduce per step" if distributed
+                "sharding": (f"index-range x{world}, tallies RCCL all-reduce "
+                             + ("once per job, inside the timed region" if args.reduce == "end" else "per step")) if distributed
                             else "single GPU",
                 "input": "rays resident in HBM (array-input mode, 56 B/photon)",
                 "bundles_in_flight": args.streams,

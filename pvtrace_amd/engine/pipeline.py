@@ -16,8 +16,18 @@ from pvtrace_amd.engine import native
 
 
 class BundlePipeline:
-    def __init__(self, dscene, depth=2, distributed=False, group=None):
+    def __init__(self, dscene, depth=2, distributed=False, group=None, reduce="end"):
+        """`distributed`: the bundles of this pipeline are one rank's shard of a multi-GPU job.
+        `reduce="end"` sums the tallies over ranks ONCE, when the totals are asked for (the sum
+        over bundles commutes with the sum over ranks, so one RCCL all-reduce of a few KB serves
+        the whole job); `reduce="bundle"` all-reduces every bundle as it completes, for consumers
+        that show global running totals."""
         import torch
+
+        if reduce not in ("end", "bundle"):
+            raise ValueError("reduce must be 'end' or 'bundle'")
+        self.reduce = reduce
+        self._reduced = False
 
         self.torch = torch
         self.dscene = dscene
@@ -35,6 +45,9 @@ class BundlePipeline:
                emit_method=0, timed=True):
         """Enqueue one tally-mode bundle (record_every=0) on the next stream; returns its slot."""
         torch = self.torch
+        if self._reduced and self.distributed and self.reduce == "end":
+            raise RuntimeError("totals already reduced over the ranks; call reset_totals() before submitting more bundles")
+        self._reduced = False
         k = self.submitted % self.depth
         self.submitted += 1
         stream, tallies, total = self.streams[k], self.slots[k], self.totals[k]
@@ -52,7 +65,7 @@ class BundlePipeline:
             if timed:
                 ev[1].record(stream)
                 self.events.append(ev)
-            if self.distributed:
+            if self.distributed and self.reduce == "bundle":
                 from pvtrace_amd.engine.distributed import all_reduce_tallies
 
                 all_reduce_tallies(tallies, group=self.group)
@@ -77,12 +90,35 @@ class BundlePipeline:
             t["_ints"].zero_()
             t["_sums"].zero_()
         self.events = []
+        self._reduced = False
+
+    def reduce_totals(self):
+        """Fold the per-stream totals into one buffer and, for a distributed job in
+        `reduce="end"` mode, sum it over the ranks (two small RCCL all-reduces for the whole
+        job).  Enqueued on the first pipeline stream; idempotent until the next submit/reset."""
+        torch = self.torch
+        if self._reduced:
+            return
+        first = self.streams[0]
+        for s in self.streams[1:]:
+            first.wait_stream(s)
+        with torch.cuda.stream(first):
+            for t in self.totals[1:]:
+                self.totals[0]["_ints"] += t["_ints"]
+                self.totals[0]["_sums"] += t["_sums"]
+                t["_ints"].zero_()
+                t["_sums"].zero_()
+            if self.distributed and self.reduce == "end":
+                from pvtrace_amd.engine.distributed import all_reduce_tallies
+
+                all_reduce_tallies(self.totals[0], group=self.group)
+        self._reduced = True
 
     def totals_host(self):
         """Sum of every bundle submitted since the last reset -> host numpy dict."""
+        self.reduce_totals()
         self.synchronize()
-        ints = sum(t["_ints"] for t in self.totals)
-        sums = sum(t["_sums"] for t in self.totals)
+        ints, sums = self.totals[0]["_ints"], self.totals[0]["_sums"]
         c = self.dscene.compiled
         nrec = max(int(c.rec_node.shape[0]), 1)
         ints, sums = ints.cpu().numpy(), sums.cpu().numpy()
