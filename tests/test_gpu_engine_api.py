@@ -199,6 +199,24 @@ def test_sharded_simulate_over_rccl_world_size_one():
         for key in ("rec_distinct", "rec_crossings", "rec_bins"):
             assert np.array_equal(sharded.data[key], whole.data[key]), key
         assert sharded.shard == (0, 300000)
+        # the pipelined job: tallies summed over the ranks once at the end, or per bundle
+        from pvtrace_amd.engine import BundlePipeline, compile_scene, native
+        from pvtrace_amd.engine.emit import EmitterTables
+
+        dscene = native.DeviceScene(compile_scene(scene), device=0, emitter=EmitterTables(scene))
+        try:
+            for mode in ("end", "bundle"):
+                pipe = BundlePipeline(dscene, depth=3, distributed=True, reduce=mode)
+                for k in range(5):
+                    pipe.submit(None, 60000, seed=8, ray_offset=60000 * k, emit_seed=2, emit_method=0)
+                totals = pipe.totals_host()
+                for key in ("rec_distinct", "rec_crossings", "rec_bins"):
+                    assert np.array_equal(totals[key], whole.data[key]), (mode, key)
+                if mode == "end":
+                    with pytest.raises(RuntimeError):
+                        pipe.submit(None, 10, seed=1)
+        finally:
+            dscene.close()
     finally:
         dist.destroy_process_group()
 
