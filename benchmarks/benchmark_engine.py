@@ -12,30 +12,19 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from pvtrace_amd import Absorber, Box, Light, Luminophore, Material, Node, Scene, Sphere   # noqa: E402
-from pvtrace_amd import engine                                                             # noqa: E402
-from pvtrace_amd.engine import Heatmap, Histogram, Recorder                                # noqa: E402
-from pvtrace_amd.material import gaussian                                                  # noqa: E402
+from pvtrace_amd import engine                                   # noqa: E402
+from pvtrace_amd.engine import Heatmap, Histogram, Recorder      # noqa: E402
 
 
 def make_lsc_scene():
-    """Same scene as the reference harness (benchmark_engine.py:26-55)."""
-    x = np.linspace(300.0, 1000.0, 200)
-    absorption = np.column_stack((x, 5.0 * gaussian(x, 1.0, 480.0, 40.0)))
-    emission = np.column_stack((x, gaussian(x, 1.0, 600.0, 40.0)))
-    world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
-    Node(name="slab", parent=world, geometry=Box((5.0, 5.0, 1.0), material=Material(
-        refractive_index=1.5,
-        components=[Luminophore(coefficient=absorption, emission=emission, quantum_yield=0.9, name="dye"),
-                    Absorber(coefficient=0.3, name="background")])))
-    light = Node(name="light", light=Light(), parent=world)
-    light.location = (0.0, 0.0, -3.0)
-    return Scene(world)
+    """The reference harness's scene (benchmark_engine.py:26-55): Gaussian dye slab in a sphere,
+    collimated light from below -- kept once, in the shared scene library."""
+    from tests import scenes
+
+    return scenes.bench_slab(recorders=False)
 
 
 def best_of(fn, repeats=3):

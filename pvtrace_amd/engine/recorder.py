@@ -40,73 +40,85 @@ VOLUME_EVENTS = frozenset(("lost", "reacted", "killed"))
 SOURCE_ANY, SOURCE_LIGHTS, SOURCE_COMPONENTS, SOURCE_COMPONENT = 0, 1, 2, 3
 
 
+def _require(condition, message):
+    if not condition:
+        raise ValueError(message)
+
+
 class Histogram:
-    """`bins` equal-width bins of `prop` over [start, stop)."""
+    """Equal-width binning of one ray property: `bins` bins over [start, stop).
+
+    Same constructor and attributes (`prop`, `start`, `stop`, `bins`) as the reference's
+    Histogram (pvtrace/engine/recorder.py:56-72); the flattener turns it into one row of the
+    `hist_*` tables."""
+
+    __slots__ = ("prop", "start", "stop", "bins")
 
     def __init__(self, prop, start, stop, bins):
-        if prop not in PROPERTIES:
-            raise ValueError(
-                f"Unknown property {prop!r}; use one of {sorted(PROPERTIES)}"
-            )
-        if not stop > start:
-            raise ValueError("Histogram range requires stop > start.")
-        if bins < 1:
-            raise ValueError("Histogram requires at least one bin.")
-        self.prop = prop
-        self.start = float(start)
-        self.stop = float(stop)
-        self.bins = int(bins)
+        _require(prop in PROPERTIES, f"Unknown property {prop!r}; use one of {sorted(PROPERTIES)}")
+        lo, hi, count = float(start), float(stop), int(bins)
+        _require(hi > lo, "Histogram range requires stop > start.")
+        _require(count >= 1, "Histogram requires at least one bin.")
+        self.prop, self.start, self.stop, self.bins = prop, lo, hi, count
+
+    @property
+    def size(self):
+        """Number of accumulator slots."""
+        return self.bins
 
     def __repr__(self):
-        return f"Histogram({self.prop!r}, {self.start}, {self.stop}, {self.bins})"
+        return "Histogram(%r, %s, %s, %d)" % (self.prop, self.start, self.stop, self.bins)
 
 
 class Heatmap:
-    """2-D histogram over (prop_a, prop_b); ranges are (start, stop, bins)."""
+    """Two properties binned jointly; each range is `(start, stop, bins)`.  Slot of a sample is
+    `ia * b.bins + ib` (reference recorder.py:75-83, kernel _kernel.pyx:540-553)."""
+
+    __slots__ = ("a", "b")
 
     def __init__(self, prop_a, prop_b, range_a, range_b):
-        self.a = Histogram(prop_a, *range_a)
-        self.b = Histogram(prop_b, *range_b)
+        self.a, self.b = Histogram(prop_a, *range_a), Histogram(prop_b, *range_b)
+
+    @property
+    def size(self):
+        return self.a.bins * self.b.bins
 
     def __repr__(self):
-        return f"Heatmap({self.a!r}, {self.b!r})"
+        return "Heatmap(%r, %r)" % (self.a, self.b)
 
 
 class Recorder:
-    """Tally of rays interacting with a node.
+    """What to count at a node (reference recorder.py:86-117, plus `source`).
 
-    Parameters
-    ----------
-    name : str
-        Key under which results are returned.
-    event : str
-        One of `EVENTS`.
-    facet : 3-tuple, optional
-        Restrict a surface recorder to interactions whose outward world normal
-        equals this vector within `atol` per component.
-    atol : float
-    histograms : list of Histogram / Heatmap, optional
-    source : None | "lights" | "components" | component name, optional
-        Only tally photons last emitted by a light / by any luminophore or scatterer / by
-        the named component (extension; splits e.g. "solar" from "luminescent" counts).
+    name        key of the result in `EngineResult.recorders`
+    event       one of `EVENTS`: "entering" / "escaping" / "reflected" at the node's surface,
+                "lost" / "reacted" / "killed" inside it, "exit" on the root
+    facet       optional outward world normal a surface interaction must have (each component
+                within `atol`) -- one recorder per face of a box, say
+    histograms  `Histogram` / `Heatmap` specs filled by the first matching interaction of a ray
+    source      None, "lights", "components" or a component name: only photons whose current
+                incarnation was emitted there (extension; splits "solar" from "luminescent")
 
-    Counts, moments and histograms are per *distinct* ray (first matching
-    interaction); every matching interaction also increments `crossings`.
+    A ray is counted once per recorder (`rays`, moments, histograms) however often it
+    matches; `crossings` counts every match.
     """
 
     def __init__(self, name, event="entering", facet=None, atol=1e-6, histograms=None,
                  source=None):
-        if event not in EVENTS:
-            raise ValueError(f"Unknown event {event!r}; use one of {sorted(EVENTS)}")
+        _require(event in EVENTS, f"Unknown event {event!r}; use one of {sorted(EVENTS)}")
+        specs = list(histograms or ())
+        _require(all(isinstance(spec, (Histogram, Heatmap)) for spec in specs),
+                 "histograms must contain Histogram or Heatmap objects.")
         self.name = name
         self.event = event
-        self.facet = None if facet is None else tuple(float(v) for v in facet)
+        self.facet = tuple(map(float, facet)) if facet is not None else None
         self.atol = float(atol)
-        self.histograms = [] if histograms is None else list(histograms)
+        self.histograms = specs
         self.source = source
-        for hist in self.histograms:
-            if not isinstance(hist, (Histogram, Heatmap)):
-                raise ValueError("histograms must contain Histogram or Heatmap objects.")
+
+    @property
+    def is_volume(self):
+        return self.event in VOLUME_EVENTS
 
     def __repr__(self):
-        return f"Recorder({self.name!r}, event={self.event!r})"
+        return "Recorder(%r, event=%r)" % (self.name, self.event)
