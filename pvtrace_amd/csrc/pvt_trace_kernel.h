@@ -464,8 +464,13 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
 #define PVT_COUNT(k, pred) do {} while (0)
 #endif
     // wave-uniform ray window claimed from the global cursor
-    unsigned int w_next = 0, w_end = 0;
+    unsigned int w_next = 0, w_end = 0, w_base = 0;
     bool exhausted = false;
+    // Per-wave pool of ready-made RNG states for the claimed chunk (4 x 64 u64 = 2 KB).  It lives
+    // in the photon-exchange buffer: that buffer is first used when ALL waves of the workgroup
+    // have run the cursor dry, i.e. after every pool has been consumed.
+    const bool seed_pool = A.xslots * (14 + SEENW) >= kWaves * 4 * 64;
+    const int pool_at = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 4 * 64;   // wave-uniform
     // drain-phase consolidation state (all wave-uniform)
     const int wave = threadIdx.x >> 6;
     bool counted = false, in_regime = false, solo = false;
@@ -483,6 +488,18 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 if (b >= A.n_rays) { exhausted = true; break; }
                 w_next = b;
                 w_end = (A.n_rays - b < (unsigned int)kChunk) ? A.n_rays : b + kChunk;
+                if (seed_pool) {
+                    // Seed the whole chunk NOW, with every lane busy, instead of inside each later
+                    // refill with only the dead lanes active (8 64-bit multiplies per seed): lane l
+                    // prepares the stream of ray b + l and parks it in this wave's slice of LDS.
+                    unsigned long long st = A.seed + (unsigned long long)b + (unsigned long long)lane;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {   // one word at a time: keeps the live range short
+                        xbuf[pool_at + k * 64 + lane] = splitmix64(st);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    w_base = b;
+                }
             }
             unsigned int avail = w_end - w_next;
             unsigned int rank = __popcll(need & lane_lt);
@@ -496,7 +513,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     dir = V3{A.dir[i * 3ull], A.dir[i * 3ull + 1], A.dir[i * 3ull + 2]};
                     wl = A.wl[i];
                 }
-                rng_seed(rng, A.seed + (unsigned long long)i);
+                if (seed_pool) {
+                    const int k = pool_at + (int)(i - w_base);
+                    rng.s0 = xbuf[k]; rng.s1 = xbuf[k + 64]; rng.s2 = xbuf[k + 128]; rng.s3 = xbuf[k + 192];
+                } else {
+                    rng_seed(rng, A.seed + (unsigned long long)i);
+                }
                 travelled = 0.0;
                 duration = 0.0;
                 count = 0;
@@ -628,7 +650,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         int t_sel = -1, t_node = -1;
         bool t_normal = false;
         double t_angle = 0.0;
-        V3 nrm{0, 0, 0}, lpos{0, 0, 0};
+        V3 nrm{0, 0, 0};
         int tri1 = -1;   // triangle record of the nearest crossing when it lies on a mesh
         bool em = false, em_acos = false;   // re-emission pending: acos argument (or theta) and phi
         double em_x = 0.0, em_phi = 0.0;
@@ -964,53 +986,54 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         PVT_COUNT(6, alive && terminal);
         // ---- local point + outward world normal of the node the event refers to.
         // Shared by EXIT and surface events (re-converged: one copy of the code).
-        const bool need_frame = alive && (t_normal || (t_sel >= 0 && t_node >= 0));
-        V3 nloc{0, 0, 0};
-        if (need_frame) {
+        // Both are pure functions of (t_node, pos, tri1), so the coating / Lambertian code and the
+        // x,y,z histogram axes RECOMPUTE them where needed (same arithmetic, same bits) instead of
+        // keeping 12 VGPRs alive across the transcendental sites, the register-pressure peak.
+        auto local_point = [&]() -> V3 {
             const int m = t_node * ND + ND_W2L;
-            lpos.x = T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(m + 3);
-            lpos.y = T.dv(m + 4) * pos.x + T.dv(m + 5) * pos.y + T.dv(m + 6) * pos.z + T.dv(m + 7);
-            lpos.z = T.dv(m + 8) * pos.x + T.dv(m + 9) * pos.y + T.dv(m + 10) * pos.z + T.dv(m + 11);
-            if (t_normal) {  // outward normal (_kernel.pyx:359-400)
-                const int gp = t_node * ND + ND_PARAMS;
-                const int gt = T.iv(t_node * NI + NI_GEOM);
-                if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
-                    const pvt::MeshTri* tr = A.tris + tri1;
-                    nloc = V3{tr->n[0], tr->n[1], tr->n[2]};
-                } else if (gt == PVT_GEOM_BOX) {
-                    double best = INFINITY;
-                    int baxis = 0;
-                    double bsign = 1.0;
-                    const double pp[3] = {lpos.x, lpos.y, lpos.z};
-#pragma unroll
-                    for (int a = 0; a < 3; a++) {
-                        double hs = 0.5 * T.dv(gp + a);
-                        double dm = pvt_fabs(pp[a] - (-1.0) * hs);
-                        if (dm < best) { best = dm; baxis = a; bsign = -1.0; }
-                        double dp = pvt_fabs(pp[a] - hs);
-                        if (dp < best) { best = dp; baxis = a; bsign = 1.0; }
-                    }
-                    nloc.x = (baxis == 0) ? bsign : 0.0;
-                    nloc.y = (baxis == 1) ? bsign : 0.0;
-                    nloc.z = (baxis == 2) ? bsign : 0.0;
-                } else if (gt == PVT_GEOM_SPHERE) {
-                    double mag = pvt_sqrt(dot3(lpos, lpos));
-                    nloc = V3{lpos.x / mag, lpos.y / mag, lpos.z / mag};
-                } else {
-                    double half = 0.5 * T.dv(gp);
-                    double tol = 1e-8 + 1e-5 * pvt_fabs(half);
-                    if (pvt_fabs(lpos.z + half) <= tol) nloc = V3{0.0, 0.0, -1.0};
-                    else if (pvt_fabs(lpos.z - half) <= tol) nloc = V3{0.0, 0.0, 1.0};
-                    else {
-                        double r = pvt_sqrt(lpos.x * lpos.x + lpos.y * lpos.y);
-                        nloc = V3{lpos.x / r, lpos.y / r, 0.0};
-                    }
-                }
-                const int q = t_node * ND + ND_L2W;
-                nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
-                nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
-                nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
+            return V3{T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(m + 3),
+                      T.dv(m + 4) * pos.x + T.dv(m + 5) * pos.y + T.dv(m + 6) * pos.z + T.dv(m + 7),
+                      T.dv(m + 8) * pos.x + T.dv(m + 9) * pos.y + T.dv(m + 10) * pos.z + T.dv(m + 11)};
+        };
+        auto local_normal = [&](const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
+            const int gp = t_node * ND + ND_PARAMS;
+            const int gt = T.iv(t_node * NI + NI_GEOM);
+            if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
+                const pvt::MeshTri* tr = A.tris + tri1;
+                return V3{tr->n[0], tr->n[1], tr->n[2]};
             }
+            if (gt == PVT_GEOM_BOX) {
+                double best = INFINITY;
+                int baxis = 0;
+                double bsign = 1.0;
+                const double pp[3] = {lp.x, lp.y, lp.z};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    double hs = 0.5 * T.dv(gp + a);
+                    double dm = pvt_fabs(pp[a] - (-1.0) * hs);
+                    if (dm < best) { best = dm; baxis = a; bsign = -1.0; }
+                    double dp = pvt_fabs(pp[a] - hs);
+                    if (dp < best) { best = dp; baxis = a; bsign = 1.0; }
+                }
+                return V3{(baxis == 0) ? bsign : 0.0, (baxis == 1) ? bsign : 0.0, (baxis == 2) ? bsign : 0.0};
+            }
+            if (gt == PVT_GEOM_SPHERE) {
+                double mag = pvt_sqrt(dot3(lp, lp));
+                return V3{lp.x / mag, lp.y / mag, lp.z / mag};
+            }
+            double half = 0.5 * T.dv(gp);
+            double tol = 1e-8 + 1e-5 * pvt_fabs(half);
+            if (pvt_fabs(lp.z + half) <= tol) return V3{0.0, 0.0, -1.0};
+            if (pvt_fabs(lp.z - half) <= tol) return V3{0.0, 0.0, 1.0};
+            double r = pvt_sqrt(lp.x * lp.x + lp.y * lp.y);
+            return V3{lp.x / r, lp.y / r, 0.0};
+        };
+        if (alive && t_normal) {
+            const V3 nloc = local_normal(local_point());
+            const int q = t_node * ND + ND_L2W;
+            nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
+            nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
+            nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
         }
 
         PVT_MARK(3);  // frame + normal
@@ -1077,6 +1100,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             int coat = -1;
             if (coated && fres) {
                 const int cs = T.iv(hit * NI + NI_KSTART), ce = cs + T.iv(hit * NI + NI_KCOUNT);
+                const V3 lpos = local_point(), nloc = local_normal(lpos);
                 const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
                 for (int c = cs; c < ce && coat < 0; c++) {
                     bool ok = true;
@@ -1101,6 +1125,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 if (lamb) {
                     // cosine-weighted about the incoming side's normal, in the node frame
                     double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
+                    const V3 nloc = local_normal(local_point());
                     V3 mm{side * nloc.x, side * nloc.y, side * nloc.z};
                     double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
                     V3 sd = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
@@ -1214,8 +1239,9 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                 const int pa = T.iv(hi_ + HI_PA), pb = T.iv(hi_ + HI_PB);
                                 const int na = T.iv(hi_ + HI_NA), nb = T.iv(hi_ + HI_NB);
                                 auto prop = [&](int pr) -> double {
-                                    return pr == 0 ? wl : pr == 1 ? t_angle : pr == 2 ? duration : pr == 3 ? travelled
-                                         : pr == 4 ? lpos.x : pr == 5 ? lpos.y : lpos.z;
+                                    if (pr < 4) return pr == 0 ? wl : pr == 1 ? t_angle : pr == 2 ? duration : travelled;
+                                    const V3 lpos = local_point();   // position in the recorder node's frame
+                                    return pr == 4 ? lpos.x : pr == 5 ? lpos.y : lpos.z;
                                 };
                                 const double la = T.dv(hd_ + HD_LO_A), ha = T.dv(hd_ + HD_HI_A);
                                 const double ra = T.dv(hd_ + HD_RA);
