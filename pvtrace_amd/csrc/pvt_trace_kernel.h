@@ -1179,7 +1179,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             // Facet recorders whose facets have distinct dominant axes (the usual "one recorder
             // per box face") are found in O(1): the host files each under the bin (dominant axis,
             // sign) of its facet, the lane looks up the bin of ITS normal and verifies that one
-            // recorder with the full tolerance test (trip j = -1).  Everything else is walked.
+            // recorder with the full tolerance test (its first trip).  Everything else is walked.
             int cs = 0, cn = 0, rbin = -1;
             if (alive && t_sel >= 0) {
                 const int key = L.cand_i + (t_node * 7 + t_sel) * 8;
@@ -1193,9 +1193,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     rbin = T.iv(key + 2 + b);
                 }
             }
-            for (int j = -1; __ballot(j < 0 ? (rbin >= 0 || cn > 0) : j < cn) != 0ull; j++) {
-                if (j < 0 ? rbin >= 0 : j < cn) {
-                    const int r = j < 0 ? rbin : T.iv(L.cand_list + cs + j);
+            // trip t of a lane: its bin recorder first (if any), then its list -- so lanes served by
+            // the bin table and lanes served by a list share the same trips
+            const int nb = rbin >= 0 ? 1 : 0, ntrips = nb + cn;
+            for (int j = 0; __ballot(j < ntrips) != 0ull; j++) {
+                if (j < ntrips) {
+                    const int r = j < nb ? rbin : T.iv(L.cand_list + cs + j - nb);
                     const int ri = L.rec_i + r * RI;
                     bool match = true;
                     const int smode = T.iv(ri + RI_SRC_MODE);  // source filter (extension)
