@@ -251,6 +251,13 @@ int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, i
 /* Launch geometry actually used by the last trace on this scene (diagnostics). */
 int pvt_scene_launch_info(PvtScene* scene, int32_t* grid, int32_t* block, int32_t* lds_bytes);
 
+/* Host-only check of the triangle BVH the library builds for mesh node `node` (no GPU needed):
+ * every face appears in exactly one leaf, lies inside the boxes of its leaf and of all its
+ * ancestors, and the skip links describe a proper depth-first layout.  Returns PVT_OK and the
+ * node / leaf counts and the tree depth, or PVT_ERR_INVALID with pvt_last_error(). */
+int pvt_mesh_bvh_check(const PvtSceneTables* tables, int32_t node, int32_t* n_bvh_nodes,
+                       int32_t* n_leaves, int32_t* depth);
+
 #ifdef __cplusplus
 }
 #endif

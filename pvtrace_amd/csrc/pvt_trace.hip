@@ -586,6 +586,59 @@ int pvt_scene_launch_info(PvtScene* s, int32_t* grid, int32_t* block, int32_t* l
     return PVT_OK;
 }
 
+int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nodes, int32_t* n_leaves,
+                       int32_t* depth_out) {
+    if (!t || node < 0 || node >= t->n_nodes || t->geom_type[node] != PVT_GEOM_MESH)
+        return fail(PVT_ERR_INVALID, "not a mesh node");
+    const int f0 = t->mesh_face_start[node], fc = t->mesh_face_count[node];
+    if (fc <= 0 || f0 < 0 || f0 + fc > t->n_mesh_faces) return fail(PVT_ERR_INVALID, "mesh face range out of bounds");
+    std::vector<pvt::BvhNode> nodes;
+    std::vector<pvt::MeshTri> tris;
+    const int root = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, nodes, tris).add_mesh(f0, fc);
+    if (root != 0 || nodes.empty() || nodes[0].skip != (int)nodes.size()) return fail(PVT_ERR_INVALID, "root skip link");
+    std::vector<int> seen(fc, 0);
+    int leaves = 0, max_depth = 0;
+    // walk the depth-first layout with an explicit ancestor stack (end index of each open subtree)
+    std::vector<int> open_end, open_id;
+    for (int i = 0; i < (int)nodes.size(); i++) {
+        while (!open_end.empty() && open_end.back() <= i) { open_end.pop_back(); open_id.pop_back(); }
+        const pvt::BvhNode& b = nodes[i];
+        if (b.skip <= i || b.skip > (int)nodes.size()) return fail(PVT_ERR_INVALID, "skip link does not move forward");
+        if (!open_end.empty() && b.skip > open_end.back()) return fail(PVT_ERR_INVALID, "subtree leaves its parent");
+        for (int a = 0; a < 3; a++) {
+            if (!(b.lo[a] <= b.hi[a])) return fail(PVT_ERR_INVALID, "empty box");
+            if (!open_id.empty() && (b.lo[a] < nodes[open_id.back()].lo[a] || b.hi[a] > nodes[open_id.back()].hi[a]))
+                return fail(PVT_ERR_INVALID, "child box not inside its parent");
+        }
+        max_depth = std::max(max_depth, (int)open_end.size() + 1);
+        if (b.tri_count > 0) {
+            if (b.skip != i + 1) return fail(PVT_ERR_INVALID, "leaf with a subtree");
+            leaves += 1;
+            for (int k = 0; k < b.tri_count; k++) {
+                const pvt::MeshTri& tr = tris[b.tri_start + k];
+                const long long local = tr.face - f0;
+                if (local < 0 || local >= fc || seen[local]++) return fail(PVT_ERR_INVALID, "face missing or duplicated");
+                for (int c = 0; c < 3; c++)
+                    for (int a = 0; a < 3; a++) {
+                        if (tr.v[3 * c + a] != t->mesh_vertices[3 * (size_t)t->mesh_faces[3 * (size_t)tr.face + c] + a])
+                            return fail(PVT_ERR_INVALID, "gathered vertex differs from the table");
+                        if (tr.v[3 * c + a] < b.lo[a] || tr.v[3 * c + a] > b.hi[a])
+                            return fail(PVT_ERR_INVALID, "triangle outside its leaf box");
+                    }
+            }
+        } else {
+            if (b.skip == i + 1) return fail(PVT_ERR_INVALID, "inner node without children");
+            open_end.push_back(b.skip);
+            open_id.push_back(i);
+        }
+    }
+    for (int k = 0; k < fc; k++) if (seen[k] != 1) return fail(PVT_ERR_INVALID, "face missing from the tree");
+    if (n_bvh_nodes) *n_bvh_nodes = (int32_t)nodes.size();
+    if (n_leaves) *n_leaves = leaves;
+    if (depth_out) *depth_out = max_depth;
+    return PVT_OK;
+}
+
 // Host-buffer entry: the literal stand-in for _kernel.trace_bundle.
 int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitter, const PvtRays* rays,
                      const PvtTraceParams* p, const PvtTallies* tl, const PvtEventLog* log, int device,

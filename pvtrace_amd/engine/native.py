@@ -209,6 +209,9 @@ def declare_signatures(lib, names):
              C.POINTER(C.c_double)], C.c_int),
         "pvt_emit_device": ([vp, C.POINTER(PvtTraceParams), vp, vp, vp, vp], C.c_int),
         "pvt_selftest_math": ([C.c_int, vp, vp, C.c_int64, C.c_int], C.c_int),
+        "pvt_mesh_bvh_check": (
+            [C.POINTER(PvtSceneTables), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+             C.POINTER(C.c_int32)], C.c_int),
         "pvt_scene_launch_info": (
             [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
     }
@@ -223,7 +226,7 @@ def declare_signatures(lib, names):
 ABI_SYMBOLS = (
     "pvt_abi_version", "pvt_last_error", "pvt_device_count", "pvt_scene_create",
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
-    "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info",
+    "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
 )
 
 _lib = None
@@ -315,6 +318,17 @@ def selftest_math(fn, x, device=0):
     check(lib.pvt_selftest_math(int(fn), x.ctypes.data, y.ctypes.data, x.size, int(device)),
           "pvt_selftest_math")
     return y
+
+
+def mesh_bvh_check(compiled, node):
+    """Build the BVH of mesh node `node` on the host and verify its invariants (no GPU needed)
+    -> (bvh nodes, leaves, depth)."""
+    lib = load_library()
+    st, keep = scene_tables_struct(compiled)
+    out = [C.c_int32(0) for _ in range(3)]
+    check(lib.pvt_mesh_bvh_check(C.byref(st), int(node), *(C.byref(v) for v in out)), "pvt_mesh_bvh_check")
+    del keep
+    return tuple(int(v.value) for v in out)
 
 
 class DeviceScene:

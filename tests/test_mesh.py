@@ -157,3 +157,25 @@ def test_fine_icosphere_approaches_the_analytic_sphere():
         out.append(r["rec_distinct"][:2] / n)
     (in_s, refl_s), (in_m, refl_m) = out
     assert abs(in_s - in_m) < 0.01 and abs(refl_s - refl_m) < 0.01, out
+
+
+def test_host_built_bvh_is_a_proper_depth_first_tree():
+    """The library's BVH builder (csrc/pvt_bvh.h) checked on the host: every face in exactly one
+    leaf and inside all enclosing boxes, skip links nest properly.  One triangle per leaf for
+    big meshes, up to 8 for tiny ones."""
+    from pvtrace_amd.engine import native
+
+    scene = scenes.mesh_gem()
+    compiled = compile_scene(scene)
+    nodes, leaves, depth = native.mesh_bvh_check(compiled, 1)          # 320-face gem
+    assert leaves == 320 and nodes == 2 * 320 - 1 and 9 <= depth <= 11
+    nodes, leaves, depth = native.mesh_bvh_check(compiled, 0)          # 80-face world
+    assert leaves == 80 and nodes == 159
+    small = compile_scene(scenes.mesh_lsc())
+    nodes, leaves, depth = native.mesh_bvh_check(small, 1)             # 12 faces: leaves of <= 8
+    assert (nodes, leaves, depth) == (3, 2, 2)
+    big = Node(name="w", geometry=Mesh.icosphere(5, 3.0, material=Material(1.0)))
+    nodes, leaves, depth = native.mesh_bvh_check(compile_scene(Scene(big)), 0)
+    assert leaves == 20480 and depth == 16
+    with pytest.raises(Exception):
+        native.mesh_bvh_check(compiled, 2)                              # the analytic sphere
