@@ -258,20 +258,6 @@ __device__ __forceinline__ V3 sample_phase(int type, double param, Rng& rng) {
     return sphere_direction(theta, phi);
 }
 
-// Fresnel (_kernel.pyx:406-419)
-__device__ __forceinline__ double fresnel_reflectivity(double angle, double n1, double n2) {
-    if (n2 < n1 && angle > pvt_asin(n2 / n1)) return 1.0;
-    double s, c;
-    pvt_sincos(angle, &s, &c);
-    double q = n1 / n2 * s;
-    double k = pvt_sqrt(1.0 - q * q);
-    double rs1 = n1 * c - n2 * k, rs2 = n1 * c + n2 * k;
-    double rs = (rs1 / rs2) * (rs1 / rs2);
-    double rp1 = n1 * k - n2 * c, rp2 = n1 * k + n2 * c;
-    double rp = (rp1 / rp2) * (rp1 / rp2);
-    return 0.5 * (rs + rp);
-}
-
 // ----------------------------------------------------------- emission
 // One ray from its own stream (mirrors oracle pvt_oracle_emit; distributions of
 // reference pvtrace/engine/emit.py:22-89).
@@ -422,9 +408,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     unsigned int* acc_cross = reinterpret_cast<unsigned int*>(acc_sums + A.n_rec * 8);
     unsigned int* acc_distinct = acc_cross + A.n_rec;
     unsigned int* acc_bins = acc_distinct + A.n_rec;
-    constexpr int XW = 14 + SEENW + (RECORD ? 3 : 0);  // u64 words of one photon's state
     int* ctl = reinterpret_cast<int*>(acc_bins + ((A.bins_in_lds ? A.total_bins : 0) + 1 & ~1));
-    unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [XW][xslots]
+    unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [14 + SEENW (+3 when RECORD)][xslots] u64 words
     if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
     if constexpr (TAB_LDS) {
         for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
