@@ -18,13 +18,11 @@ import numpy as np
 from pvtrace_amd.engine.recorder import (
     EVENTS,
     PROPERTIES,
-    SOURCE_ANY,
     SOURCE_COMPONENT,
     SOURCE_COMPONENTS,
     SOURCE_LIGHTS,
     VOLUME_EVENTS,
     Heatmap,
-    Histogram,
     Recorder,
 )
 from pvtrace_amd.geometry import Box, Cylinder, Mesh, Sphere

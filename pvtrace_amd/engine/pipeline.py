@@ -10,8 +10,6 @@ finished, so the next bundle's bulk phase fills the CUs the draining bundle vaca
 Every bundle is still traced completely and tallied into its own buffers; results are
 identical to running the bundles one after another (per-ray RNG streams).
 """
-import numpy as np
-
 from pvtrace_amd.engine import native
 
 

@@ -10,7 +10,7 @@ graph into SoA tables and runs the HIP kernel.
 import numpy as np
 
 from pvtrace_amd.common import AppError
-from pvtrace_amd.geometry import Transformable, rotation_matrix
+from pvtrace_amd.geometry import Transformable
 
 
 class Node(Transformable):
