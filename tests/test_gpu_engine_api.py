@@ -283,3 +283,22 @@ def test_pipelined_bundles_equal_serial_bundles():
     whole = engine.simulate(scene, 500_000, seed=5, record_every=0, emission="device", emit_seed=9)
     for key in ("rec_distinct", "rec_crossings", "rec_bins"):
         assert np.array_equal(data[key], whole.data[key]), key
+
+
+def test_empty_and_tiny_jobs_through_the_public_api():
+    scene = scenes.lsc_equivalent()
+    for emission in ("device", "host"):
+        none = engine.simulate(scene, 0, seed=1, emission=emission)
+        assert none.num_rays == 0 and none.num_recorded == 0 and list(none.histories()) == []
+        assert none.data["rec_distinct"].sum() == 0 and none.data["kind"].shape == (0,)
+        one = engine.simulate(scene, 1, seed=1, emission=emission, record_every=0)
+        assert one.num_rays == 1 and one.data["counts"].shape == (0,) and one.data["rec_distinct"].sum() >= 1
+        assert list(engine.simulate_stream(scene, 0, seed=1, emission=emission)) == []
+        sizes = [r.num_rays for r, _ in engine.simulate_stream(scene, 1001, bundle=250, seed=1,
+                                                               emission=emission, record_every=7)]
+        assert sizes == [250, 250, 250, 250, 1]
+    assert engine.simulate(scene, 5, seed=2, max_events=2).data["counts"].tolist() == [2] * 5
+    with pytest.raises(ValueError):
+        engine.simulate(scene, 5, seed=2, max_events=1)
+    with pytest.raises(ValueError):
+        engine.simulate(scene, -3, seed=2)
