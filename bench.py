@@ -177,6 +177,14 @@ def main():
                     "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
                     "wait_fraction_of_wave_cycles": derived.get("wait_any_fraction_of_wave_cycles"),
                 }
+                per_photon = derived.get("valu_wave_instructions_per_photon")
+                if per_photon:
+                    # the operative ceiling: one wave64 VALU instruction per SIMD every 4 cycles
+                    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+                    peak = cus * 4 * 2.4e9 / 4.0
+                    instruction_side["valu_issue_peak_per_s"] = peak
+                    instruction_side["valu_issue_rate_per_s"] = per_photon * value / world
+                    instruction_side["valu_issue_frac"] = per_photon * value / world / peak
             except Exception:
                 traffic = None
         nrec = compiled.rec_node.shape[0]
