@@ -107,6 +107,8 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     distributed = world > 1 or os.environ.get("PVT_BENCH_FORCE_DIST") == "1"  # (1-rank RCCL self-test)
     if not native.library_built():
+        if world > 1:
+            sys.exit("libpvtrace_hip.so is not built; run __graft_entry__.build() once before a multi-rank launch")
         entry.build()
     if not native.is_available():
         sys.exit("no MI355X visible: the engine has no CPU path (build ok, nothing to measure)")
@@ -231,7 +233,7 @@ def main():
             "launch": dscene.launch_info(),
             "tallies": fractions,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU referee is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(compiled, pos, dirs, wl)
         print(json.dumps(out))
     if distributed:
