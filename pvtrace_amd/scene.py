@@ -13,6 +13,29 @@ from pvtrace_amd.common import AppError
 from pvtrace_amd.geometry import Transformable
 
 
+class Intersection(object):
+    """A crossing of a query ray with one node's surface (reference geometry/intersection.py:16-49):
+    `point` in the frame of `coordsys`, `hit` the node that owns the surface, `distance` from the
+    ray origin."""
+
+    __slots__ = ("coordsys", "point", "hit", "distance")
+
+    def __init__(self, coordsys, point, hit, distance):
+        self.coordsys, self.hit, self.distance = coordsys, hit, float(distance)
+        self.point = tuple(float(v) for v in point)
+
+    def to(self, node):
+        """The same crossing with its point expressed in `node`'s frame."""
+        return Intersection(node, self.coordsys.point_to_node(self.point, node), self.hit, self.distance)
+
+    def __eq__(self, other):
+        return (isinstance(other, Intersection) and self.coordsys is other.coordsys and self.hit is other.hit
+                and np.allclose(self.point, other.point) and abs(self.distance - other.distance) < 1e-9)
+
+    def __repr__(self):
+        return f"Intersection(hit={self.hit.name!r}, point={self.point}, distance={self.distance:.6g})"
+
+
 class Node(Transformable):
     """A frame positioned relative to its parent node."""
 
@@ -164,6 +187,21 @@ class Node(Transformable):
         m = self.transformation_to(node)[:3, :3]
         return tuple(m @ np.asarray(tuple(vector), dtype=np.float64))
 
+    # -- host-side ray queries (debugging / plumbing; the engine never calls these) -----------
+    def intersections(self, ray_origin, ray_direction):
+        """Crossings of a ray, given in THIS node's frame, with this node's geometry and every
+        geometry below it, each in the frame of the node it hits (reference node.py:137-174).
+        Geometry queries follow the kernel: only crossings further than EPS_ZERO count."""
+        found = []
+        for node in self.preorder():
+            if node.geometry is None:
+                continue
+            origin = self.point_to_node(ray_origin, node) if node is not self else tuple(ray_origin)
+            direction = self.vector_to_node(ray_direction, node) if node is not self else tuple(ray_direction)
+            for point in node.geometry.intersections(origin, direction):
+                found.append(Intersection(node, point, node, float(np.linalg.norm(np.subtract(point, origin)))))
+        return tuple(found)
+
     # -- light -----------------------------------------------------------
     def emit(self, num_rays=None):
         if self.light is None:
@@ -203,6 +241,14 @@ class Scene(object):
             node = lights[idx % len(lights)]
             for ray in node.emit(1):
                 yield ray.representation(node, self.root)
+
+    def intersections(self, ray_origin, ray_direction):
+        """Forward crossings of a root-frame ray with every geometry of the scene, nearest first,
+        points in the root frame (reference scene.py:153-195)."""
+        if self.root is None:
+            return tuple()
+        crossings = [x.to(self.root) for x in self.root.intersections(ray_origin, ray_direction)]
+        return tuple(sorted(crossings, key=lambda x: x.distance))
 
     def simulate(self, num_rays, seed=None, **kwargs):
         """Trace on the MI355X engine; returns an `EngineResult`.

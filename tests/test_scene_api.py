@@ -278,3 +278,18 @@ def test_auto_recorders_match_the_reference_shorthand():
     assert len(names) == 7 and len(set(names)) == 7
     assert len([r for r in slab.recorders if r.name == "slab-top"][0].histograms) == 0   # explicit wins
     compile_scene(scene)
+
+
+def test_host_side_scene_intersections():
+    """Scene.intersections / Node.intersections (reference scene.py:153-195, node.py:137-174):
+    every forward crossing, nearest first, in the root frame -- nested_cylinders along +z crosses
+    A, the protruding child B twice, A again and the world (examples/nested_cylinders.py)."""
+    scene = scenes.nested_cylinders()
+    found = scene.intersections((0.0, 0.0, -1.0), (0.0, 0.0, 1.0))
+    assert [x.hit.name for x in found] == ["A", "B", "B", "A", "World"]
+    assert np.allclose([x.distance for x in found], [2.149349, 2.6, 3.4, 3.850651, 11.0], atol=1e-6)
+    assert all(x.coordsys is scene.root for x in found) and np.allclose(found[-1].point, (0, 0, 10))
+    a = [n for n in scene.root.children if n.name == "A"][0]
+    local = a.intersections((0.0, 0.0, -5.0), (0.0, 0.0, 1.0))     # a ray along A's own axis
+    assert [x.hit.name for x in local][:2] == ["A", "A"] and local[0].coordsys is a
+    assert local[0].to(scene.root) == local[0].to(scene.root)
