@@ -1,0 +1,122 @@
+"""The pure-Python per-ray tracer (oracle/py_tracer.py, a restatement of the reference's
+pvtrace/algorithm/photon_tracer.py over the host scene API) against the table-driven path.
+
+This is the reference's own validation scheme for its engine (tests/test_engine.py:95-167,
+:321-350): per-ray event-count means of a few hundred Python-traced rays must agree with the
+kernel's within Monte-Carlo error (Welch, 5 sigma).  On CPU the kernel is played by the C referee;
+the GPU test does the same against the HIP engine.  BASELINE configs[0] is the first case."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import py_tracer as P
+from pvtrace_amd.engine import compile_scene, tally_histories
+from pvtrace_amd.engine.api import EngineResult
+from pvtrace_amd.engine.emit import emit_bundle
+from pvtrace_amd.light import Event
+from tests import scenes
+
+KINDS = (Event.GENERATE, Event.ABSORB, Event.EMIT, Event.SCATTER, Event.REFLECT, Event.TRANSMIT,
+         Event.NONRADIATIVE, Event.REACT, Event.EXIT, Event.KILL)
+
+
+def python_counts(scene, n, seed):
+    """(n, kinds) per-ray event counts from the Python tracer, and the histories."""
+    np.random.seed(seed)
+    histories = [list(P.step_forward(scene, ray)) for ray in scene.emit(n)]
+    table = np.zeros((n, len(KINDS)))
+    for j, history in enumerate(histories):
+        for _, event, _ in history:
+            table[j, KINDS.index(event)] += 1
+    return table, histories
+
+
+def table_counts(data, max_events):
+    """Same table from a `data` dict of the kernel / referee (all rays recorded)."""
+    n = len(data["counts"])
+    kinds = data["kind"].reshape(n, max_events)
+    valid = np.arange(max_events)[None, :] < data["counts"][:, None]
+    return np.stack([((kinds == k.value) & valid).sum(axis=1) for k in KINDS], axis=1).astype(float)
+
+
+def assert_means_close(a, b, nsigma=5.0):
+    """Welch comparison of per-ray event-count means (reference tests/test_engine.py:126-136)."""
+    for k, kind in enumerate(KINDS):
+        se = math.sqrt(a[:, k].var(ddof=1) / len(a) + b[:, k].var(ddof=1) / len(b))
+        assert abs(a[:, k].mean() - b[:, k].mean()) <= nsigma * se + 1e-9, (
+            kind.name, a[:, k].mean(), b[:, k].mean(), nsigma * se)
+
+
+def referee_counts(scene, n, seed, max_events=256):
+    compiled = compile_scene(scene)
+    pos, dirs, wl, src = emit_bundle(scene, n, seed=seed)
+    data = O.trace_bundle(compiled, pos, dirs, wl, seed, 1000, max_events, 0, 8, 1)
+    assert data["counts"].max() < max_events - 1
+    return table_counts(data, max_events), EngineResult(compiled, data, src, max_events, 1, 0.0)
+
+
+def test_config1_hello_world_one_thousand_rays_in_pure_python():
+    """BASELINE configs[0]: glass sphere in the world sphere, 1 000 rays, Python per-ray path on
+    the CPU.  Expected per-ray means from SURVEY.md §8(d): GENERATE 1, TRANSMIT ~1.91,
+    REFLECT ~0.087, EXIT 1."""
+    py, histories = python_counts(scenes.hello_world(), 1000, seed=1)
+    mean = dict(zip(KINDS, py.mean(axis=0)))
+    assert mean[Event.GENERATE] == 1.0 and mean[Event.EXIT] == 1.0 and mean[Event.KILL] == 0.0
+    assert mean[Event.TRANSMIT] == pytest.approx(1.91, abs=0.03)
+    assert mean[Event.REFLECT] == pytest.approx(0.087, abs=0.03)
+    ref, _ = referee_counts(scenes.hello_world(), 20000, seed=7, max_events=64)
+    assert_means_close(py, ref)
+    # every history is a connected polyline that ends on the world sphere
+    for history in histories[:50]:
+        assert history[-1][1] == Event.EXIT
+        assert np.isclose(np.linalg.norm(history[-1][0].position), 10.0)
+
+
+@pytest.mark.parametrize("name,n_python", [("fresnel_box", 800), ("bench_slab", 400), ("lsc_equivalent", 400),
+                                           ("nested_cylinders", 600)])
+def test_python_tracer_and_table_driven_path_agree(name, n_python):
+    """reference tests/test_engine.py:139-167 (Fresnel scene, dye slab) plus the headline LSC and the
+    nested rotated cylinders: two implementations that share no code below the scene objects."""
+    scene = scenes.REFERENCE_SCENES[name]() if name != "bench_slab" else scenes.bench_slab(recorders=False)
+    py, _ = python_counts(scene, n_python, seed=42)
+    ref, _ = referee_counts(scene, 20000, seed=7)
+    assert_means_close(py, ref)
+
+
+def test_python_tracer_tallies_match_statistically():
+    """reference tests/test_engine.py:321-350: recorders tallied from Python histories vs the
+    kernel-side accumulators, within 5 sigma."""
+    scene = scenes.lsc_equivalent()
+    n_python, n_table = 400, 20000
+    _, histories = python_counts(scene, n_python, seed=5)
+    python_tallies = tally_histories(scene, histories)
+    _, result = referee_counts(scene, n_table, seed=13)
+    for name in ("top", "bottom", "lost", "entering", "reflected"):
+        a, b = python_tallies[name].rays, result.recorders[name].rays
+        p = (a + b) / (n_python + n_table)
+        se = math.sqrt(max(p * (1 - p), 1e-12) * (1 / n_python + 1 / n_table))
+        assert abs(a / n_python - b / n_table) <= 5 * se, (name, a / n_python, b / n_table)
+
+
+def test_coatings_python_delegates_against_the_coating_tables():
+    """Config 5 (Coatings notebook scene + scatterer): the host `CoatedSurfaceDelegate` is CALLED by
+    the Python tracer, the flattener lowers the same coatings to tables for the kernel.  The
+    reference engine cannot express this scene, so this statistical agreement is its check."""
+    scene = scenes.coated_slab()
+    py, _ = python_counts(scene, 800, seed=3)
+    ref, _ = referee_counts(scene, 20000, seed=9)
+    assert_means_close(py, ref)
+
+
+@pytest.mark.gpu
+def test_python_tracer_against_the_gpu_engine():
+    from pvtrace_amd import engine
+
+    for name, n_python in (("hello_world", 1000), ("lsc_equivalent", 400)):
+        scene = scenes.REFERENCE_SCENES[name]()
+        py, _ = python_counts(scene, n_python, seed=11)
+        result = engine.simulate(scene, 20000, seed=7, max_events=256)
+        assert result.data["counts"].max() < 255
+        assert_means_close(py, table_counts(result.data, 256))
