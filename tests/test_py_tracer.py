@@ -121,3 +121,79 @@ def test_python_tracer_against_the_gpu_engine():
         result = engine.simulate(scene, 20000, seed=7, max_events=256)
         assert result.data["counts"].max() < 255
         assert_means_close(py, table_counts(result.data, 256))
+
+
+# -- the reference's seeded known answers for its Python tracer ------------------------------
+# (tests/test_refractored_tracer.py:116-377: numpy seed 0, ray from (0,0,-1) along +z; the
+# expected positions/events below are that file's constants, so they pin oracle/py_tracer.py --
+# draw order included -- to the reference's photon_tracer.follow)
+
+def _embedded(n1=1.5, components=None):
+    from pvtrace_amd import Box, Material, Node, Scene, Sphere
+
+    world = Node(name="world (air)", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    box = Node(name="box", parent=world,
+               geometry=Box((1.0, 1.0, 1.0), material=Material(refractive_index=n1, components=components)))
+    return Scene(world), world, box
+
+
+def _touching():
+    from pvtrace_amd import Box, Material, Node, Scene, Sphere
+
+    world = Node(name="world (air)", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    boxes = []
+    for k in range(3):
+        b = Node(name=f"box {k + 1}", parent=world, geometry=Box((1.0, 1.0, 1.0), material=Material(refractive_index=1.5)))
+        b.translate((0.0, 0.0, float(k)))
+        boxes.append(b)
+    return Scene(world), world, boxes
+
+
+def _follow_seed0(scene):
+    from pvtrace_amd.light import Ray
+
+    np.random.seed(0)
+    path = P.follow(scene, Ray(position=(0.0, 0.0, -1.0), direction=(0.0, 0.0, 1.0), wavelength=555.0))
+    return [r.position for r, _ in path], [e for _, e in path]
+
+
+@pytest.mark.parametrize("case", ["glass", "mirror-like", "absorber", "reactor", "touching"])
+def test_reference_known_answers_of_the_python_tracer(case):
+    from pvtrace_amd import Absorber, Reactor
+
+    if case == "glass":            # :116-139
+        scene = _embedded()[0]
+        want_p = [(0, 0, -1.0), (0, 0, -0.5), (0, 0, 0.5), (0, 0, 10.0)]
+        want_e = [Event.GENERATE, Event.TRANSMIT, Event.TRANSMIT, Event.EXIT]
+    elif case == "mirror-like":    # :142-165, n = 100: the first draw (0.5488) is below R = 0.96
+        scene = _embedded(n1=100.0)[0]
+        want_p = [(0, 0, -1.0), (0, 0, -0.5), (0, 0, -10.0)]
+        want_e = [Event.GENERATE, Event.REFLECT, Event.EXIT]
+    elif case == "absorber":       # :168-195, depth = -ln(1 - 0.7151893...) / 10
+        scene = _embedded(components=[Absorber(coefficient=10.0)])[0]
+        want_p = [(0, 0, -1.0), (0, 0, -0.5), (0, 0, -0.3744069237034118)]
+        want_e = [Event.GENERATE, Event.TRANSMIT, Event.ABSORB]
+    elif case == "reactor":        # :198-224
+        scene = _embedded(components=[Reactor(coefficient=10.0)])[0]
+        want_p = [(0, 0, -1.0), (0, 0, -0.5), (0, 0, -0.3744069237034118), (0, 0, -0.3744069237034118)]
+        want_e = [Event.GENERATE, Event.TRANSMIT, Event.ABSORB, Event.REACT]
+    else:                          # :262-293, three touching glass cubes
+        scene = _touching()[0]
+        want_p = [(0, 0, -1.0), (0, 0, -0.5), (0, 0, 0.5), (0, 0, 1.5), (0, 0, 2.5), (0, 0, 10.0)]
+        want_e = [Event.GENERATE] + [Event.TRANSMIT] * 4 + [Event.EXIT]
+    positions, events = _follow_seed0(scene)
+    assert events[:len(want_e)] == want_e
+    for got, want in zip(positions, want_p):
+        assert np.allclose(got, want, atol=2.3e-13), (got, want)
+
+
+def test_find_container_known_answers():
+    """tests/test_refractored_tracer.py:247-260, :296-377."""
+    scene, world, boxes = _touching()
+    assert tuple(x.hit for x in scene.intersections((0, 0, -1.0), (0, 0, 1.0))) == (
+        boxes[0], boxes[0], boxes[1], boxes[1], boxes[2], boxes[2], world)
+    for z, want in ((-1.0, world), (-0.4, boxes[0]), (0.6, boxes[1]), (1.6, boxes[2]), (2.6, world)):
+        assert P.find_container(scene.intersections((0.0, 0.0, z), (0.0, 0.0, 1.0))) is want
+    scene, world, box = _embedded()
+    for z, want in ((-1.0, world), (-0.4, box), (0.6, world)):
+        assert P.find_container(scene.intersections((0.0, 0.0, z), (0.0, 0.0, 1.0))) is want
