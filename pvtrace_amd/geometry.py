@@ -131,6 +131,11 @@ class Geometry(object):
     def normal(self, point):
         raise NotImplementedError
 
+    def is_entering(self, surface_point, direction):
+        """A ray at `surface_point` travelling along `direction` goes INTO the shape
+        (reference geometry protocol, e.g. sphere.py:78-86)."""
+        return bool(np.dot(self.normal(surface_point), np.asarray(direction, dtype=np.float64)) < 0.0)
+
 
 class Box(Geometry):
     """Axis-aligned box of side lengths `size`, centred on the origin."""
@@ -254,6 +259,13 @@ class Cylinder(Geometry):
             self.radius - (r + EPS_ZERO) > 0.0
             and 0.5 * self.length - (abs(p[2]) + EPS_ZERO) > 0.0
         )
+
+    def is_on_surface(self, point):
+        p = np.asarray(point, dtype=np.float64)
+        r, half = math.hypot(p[0], p[1]), 0.5 * self.length
+        on_cap = abs(abs(p[2]) - half) < EPS_ZERO and r <= self.radius + EPS_ZERO
+        on_side = abs(r - self.radius) < EPS_ZERO and abs(p[2]) <= half + EPS_ZERO
+        return bool(on_cap or on_side)
 
     def normal(self, point):
         p = np.asarray(point, dtype=np.float64)

@@ -59,6 +59,19 @@ def bandgap(x, cutoff, alpha):
     return (1 - np.heaviside(x - cutoff, 0.5)) * alpha
 
 
+def thermodynamic_emission(abs_spec, T=300, mu=0.5):
+    """Emission line shape in detailed balance with an absorption spectrum (generalised Planck
+    law): `abs_spec` is an (n, 2) array of (nm, absorptance); returns (nm, emission) normalised to
+    a peak of 1.  `T` in kelvin, `mu` the chemical potential in eV.  (Counterpart of the
+    reference's pvtrace/material/utils.py:72-85, used to build test spectra.)"""
+    planck, light, charge, boltzmann = 6.62607015e-34, 299792458.0, 1.60217662e-19, 1.38064852e-23
+    spec = np.asarray(abs_spec, dtype=np.float64)
+    ev = planck * light / charge * 1e9 / spec[:, 0]                  # photon energy of each row
+    occupation = np.expm1((ev - mu) / (boltzmann / charge * T))
+    emission = spec[:, 1] * ev * ev / occupation
+    return np.column_stack((spec[:, 0], emission / np.max(emission)))
+
+
 def spherical_to_cart(theta, phi, r=1.0):
     st = np.sin(theta)
     cart = np.column_stack((r * st * np.cos(phi), r * st * np.sin(phi), r * np.cos(theta)))
