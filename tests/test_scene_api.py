@@ -293,3 +293,35 @@ def test_host_side_scene_intersections():
     local = a.intersections((0.0, 0.0, -5.0), (0.0, 0.0, 1.0))     # a ray along A's own axis
     assert [x.hit.name for x in local][:2] == ["A", "A"] and local[0].coordsys is a
     assert local[0].to(scene.root) == local[0].to(scene.root)
+
+
+def test_node_frames_known_answers_of_the_reference():
+    """reference tests/test_node.py:47-74 (frame conversions up and down the tree), :108-125
+    (intersections through a translated child), :141-152 (look_at)."""
+    from pvtrace_amd.geometry import rotation_matrix
+
+    a = Node(name="a"); b = Node(name="b", parent=a); c = Node(name="c", parent=b); d = Node(name="d", parent=a)
+    b.translate((1, 1, 1)); c.translate((0, 1, 1)); d.translate((-1, -1, -1))
+    theta = 0.5 * np.pi
+    b.rotate(theta, (0, 0, 1)); c.rotate(theta, (1, 0, 0)); d.rotate(theta, (0, 1, 0))
+    assert np.allclose(d.point_to_node((0, 0, 0), a), (-1, -1, -1))
+    assert np.allclose(d.point_to_node((1, 1, 1), a), (0, 0, -2))
+    assert np.allclose(d.vector_to_node((1, 0, 0), a), (0, 0, -1))
+    assert np.allclose(d.vector_to_node((0, 1, 0), a), (0, 1, 0))
+    assert np.allclose(d.vector_to_node((0, 0, 1), a), (1, 0, 0))
+    assert np.allclose(c.point_to_node((0, 0, 0), d), (-3, 2, 1))
+    assert np.allclose(c.point_to_node((1, 1, 1), d), (-4, 3, 2))
+    assert np.allclose(c.vector_to_node((1, 0, 0), d), (0, 1, 0))
+    assert np.allclose(c.vector_to_node((0, 1, 0), d), (-1, 0, 0))
+    assert np.allclose(c.vector_to_node((0, 0, 1), d), (0, 0, 1))
+
+    top = Node(name="A"); ball = Node(name="B", parent=top, geometry=Sphere(radius=1.0))
+    ball.translate((1.0, 0.0, 0.0))
+    found = top.intersections((-2.0, 0.0, 0.0), (1.0, 0.0, 0.0))
+    assert np.allclose([x.point for x in found], ((-1, 0, 0), (1, 0, 0)))          # in B's frame
+    assert np.allclose([x.to(top).point for x in found], ((0, 0, 0), (2, 0, 0)))   # shifted 1 along x in A
+
+    n = Node(name="n"); n.look_at([1, 0, 0])
+    assert np.allclose(n.pose, rotation_matrix(np.pi / 2, [0, 1, 0]))
+    n = Node(name="n"); n.look_at([0, 0, -1])
+    assert np.allclose(n.pose, rotation_matrix(np.pi, [0, 1, 0]))
