@@ -15,7 +15,8 @@ traces rays with seeds seed + traced + i" (api.py:249-264).  Both map directly:
   sums are all-reduced (sum).  Payload is O(recorders + bins) — tens of KB —
   so the collective is latency-bound (~tens of microseconds), independent of
   the photon count;
-* sampled event logs stay on the rank that traced them.
+* sampled event logs stay on the rank that traced them; shard boundaries are multiples of
+  `record_every`, so together they are the single-process log.
 
 `backend="nccl"` is RCCL on ROCm.  The CPU tests run the same code path with
 gloo and an injected tracer.
@@ -28,9 +29,22 @@ from pvtrace_amd.engine import native
 from pvtrace_amd.engine.compiler import EMIT_METHODS, compile_scene
 
 
-def shard_range(num_rays, rank, world_size):
-    """[start, stop) of the global ray indices owned by `rank`."""
-    return (num_rays * rank) // world_size, (num_rays * (rank + 1)) // world_size
+def shard_range(num_rays, rank, world_size, align=1):
+    """[start, stop) of the global ray indices owned by `rank`.  With `align` > 1 the inner
+    boundaries are multiples of it: a job that keeps the history of every `record_every`-th ray
+    shards on those multiples, so each rank samples exactly the rays a single process would
+    (the kernel samples by index within its bundle, `_kernel.pyx:1085-1089`) and the union of
+    the shards' event logs IS the single-process log."""
+    align = max(int(align), 1)
+
+    def edge(r):
+        if r <= 0:
+            return 0
+        if r >= world_size:
+            return num_rays
+        return min(((num_rays * r) // world_size) // align * align, num_rays)
+
+    return edge(rank), edge(rank + 1)
 
 
 def all_reduce_tallies(tallies, group=None):
@@ -78,7 +92,7 @@ def simulate_sharded(scene, num_rays, seed, emit_seed=0, maxsteps=1000, max_even
     if emit_method not in EMIT_METHODS:
         raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    start, stop = shard_range(num_rays, rank, world)
+    start, stop = shard_range(num_rays, rank, world, align=record_every)
     n_local = stop - start
     compiled = compile_scene(scene)
     sources = emit_mod.sources_for(scene, num_rays)[start:stop]

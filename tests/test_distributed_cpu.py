@@ -39,7 +39,7 @@ def _worker(rank, world, port, n, out_dir):
     pos, dirs, wl, _ = emit_bundle(scene, n, seed=55)
     result = simulate_sharded(scene, n, seed=77, record_every=10, max_events=64,
                               tracer=_oracle_tracer, rays=(pos, dirs, wl))
-    assert result.shard == shard_range(n, rank, world)
+    assert result.shard == shard_range(n, rank, world, align=10)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), counts=result.data["counts"],
              **{k: result.data[k] for k in ("rec_distinct", "rec_crossings", "rec_sums", "rec_bins")})
     dist.barrier()
@@ -56,6 +56,10 @@ def test_shard_ranges_partition_the_job():
             assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+            for align in (7, 1000):
+                edges = [shard_range(n, r, world, align=align) for r in range(world)]
+                assert edges[0][0] == 0 and edges[-1][1] == n
+                assert all(a[1] == b[0] and a[1] % align == 0 for a, b in zip(edges, edges[1:]))
 
 
 @pytest.mark.timeout(300)

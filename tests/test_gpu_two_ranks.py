@@ -1,0 +1,79 @@
+"""The N>1 device path with two real processes on the one GPU of the test box: each rank builds
+its own scene on cuda:0, traces its index-range shard with the HIP kernel, and the tallies are
+summed with a gloo all-reduce of the device tensors (RCCL refuses two ranks on one GPU, so the
+collective backend is the only thing that differs from an 8-GPU run).  Both ranks must end up
+with the single-process result, exactly for the integer tallies."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from pvtrace_amd.engine import BundlePipeline, compile_scene, native
+    from pvtrace_amd.engine.distributed import shard_range, simulate_sharded
+    from pvtrace_amd.engine.emit import EmitterTables
+    from tests import scenes
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    scene = scenes.lsc_equivalent()
+    sharded = simulate_sharded(scene, n, seed=8, emit_seed=2, record_every=70, max_events=64, device=0)
+    assert sharded.shard == shard_range(n, rank, world, align=70) and sharded.shard[0] % 70 == 0
+    out = {f"sharded_{k}": sharded.data[k] for k in ("rec_distinct", "rec_crossings", "rec_bins", "rec_sums", "counts")}
+
+    # pipelined job: this rank's shard as 4 bundles, tallies reduced once at the end / per bundle
+    start, stop = shard_range(n, rank, world)
+    dscene = native.DeviceScene(compile_scene(scene), device=0, emitter=EmitterTables(scene))
+    try:
+        for mode in ("end", "bundle"):
+            pipe = BundlePipeline(dscene, depth=3, distributed=True, reduce=mode)
+            edges = np.linspace(start, stop, 5).astype(int)
+            for a, b in zip(edges[:-1], edges[1:]):
+                pipe.submit(None, int(b - a), seed=8, ray_offset=int(a), emit_seed=2, emit_method=0)
+            totals = pipe.totals_host()
+            for k in ("rec_distinct", "rec_crossings", "rec_bins", "rec_sums"):
+                out[f"pipe_{mode}_{k}"] = totals[k]
+    finally:
+        dscene.close()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_on_one_gpu_reproduce_the_single_process_job(tmp_path):
+    import torch.multiprocessing as mp
+
+    from pvtrace_amd import engine
+    from tests import scenes
+
+    n, world = 200_033, 2
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    whole = engine.simulate(scenes.lsc_equivalent(), n, seed=8, record_every=70, max_events=64,
+                            emission="device", emit_seed=2)
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in ranks:
+        for prefix in ("sharded", "pipe_end", "pipe_bundle"):
+            for k in ("rec_distinct", "rec_crossings", "rec_bins"):
+                assert np.array_equal(r[f"{prefix}_{k}"], whole.data[k]), (prefix, k)
+            assert np.allclose(r[f"{prefix}_rec_sums"], whole.data["rec_sums"], rtol=1e-12)
+    # sampled event logs are per shard; shards start on multiples of record_every (here 99 960,
+    # not the even split 100 016), so together they are the single-process log
+    counts = np.concatenate([r["sharded_counts"] for r in ranks])
+    assert np.array_equal(counts, whole.data["counts"])
