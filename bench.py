@@ -112,12 +112,17 @@ def main():
         entry.build()
     if not native.is_available():
         sys.exit("no MI355X visible: the engine has no CPU path (build ok, nothing to measure)")
+    local_rank %= torch.cuda.device_count()   # (self-test: several ranks on a 1-GPU box, gloo backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("PVT_BENCH_BACKEND", "nccl")   # nccl = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     n = args.photons
     scene = scenes.lsc_equivalent()
@@ -211,7 +216,7 @@ def main():
                             "(10 cm^-1 peak, qy 1) + 0.1 cm^-1 background, 20-degree cone @555 nm, "
                             "10 recorders, record_every=0, emit_method=kT, maxsteps=1000",
                 "photons_per_gpu_per_step": n,
-                "sharding": (f"index-range x{world}, tallies RCCL all-reduce "
+                "sharding": (f"index-range x{world}, tallies {'RCCL' if os.environ.get('PVT_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['PVT_BENCH_BACKEND']} all-reduce "
                              + ("once per job, inside the timed region" if args.reduce == "end" else "per step")) if distributed
                             else "single GPU",
                 "input": "rays resident in HBM (array-input mode, 56 B/photon)",
