@@ -6,7 +6,8 @@
 // photon needs EVERY forward crossing of a mesh (the container rule counts them,
 // _kernel.pyx:684-714), so front-to-back ordering buys nothing and a fixed order is free.
 // Leaves hold one triangle (up to 8 for tiny meshes), pre-gathered (vertices + face normal +
-// face id) so a leaf is one contiguous run of 104-byte records.
+// face id) so a leaf is one contiguous run of 104-byte records.  Nodes are 32 bytes (f32 boxes
+// rounded outwards): culling is only a filter, the triangle test itself stays f64.
 //
 // The boxes are padded by 1e-7 of the mesh diagonal: culling must be conservative with respect
 // to the (differently rounded) watertight triangle test, so that the set of crossings found
@@ -21,12 +22,10 @@
 
 namespace pvt {
 
-struct BvhNode {      // 64 bytes
-    double lo[3], hi[3];
-    int skip;         // next node when this subtree is culled or finished
-    int tri_start;    // leaves: first triangle record; inner nodes: -1
-    int tri_count;    // leaves: 1..8; inner nodes: 0
-    int pad;
+struct BvhNode {      // 32 bytes: two nodes per 64-byte line, half the traffic of f64 boxes
+    float lo[3], hi[3];   // box rounded OUTWARDS to f32 (after the padding below): still conservative
+    int skip;             // next node when this subtree is culled or finished
+    int leaf;             // leaves: (first triangle record << 4) | triangle count (1..8); inner: 0
 };
 struct MeshTri {      // 104 bytes
     double v[9];      // three vertices, node-local frame
@@ -92,10 +91,12 @@ private:
         nodes_.push_back(BvhNode{});
         double lo[3], hi[3];
         bounds(begin, end, lo, hi);
-        for (int a = 0; a < 3; a++) { nodes_[me].lo[a] = lo[a] - pad_; nodes_[me].hi[a] = hi[a] + pad_; }
+        for (int a = 0; a < 3; a++) {
+            nodes_[me].lo[a] = std::nextafter((float)(lo[a] - pad_), -INFINITY);   // (float) rounds to nearest:
+            nodes_[me].hi[a] = std::nextafter((float)(hi[a] + pad_), INFINITY);    // one more step outwards
+        }
         if (end - begin <= leaf_) {
-            nodes_[me].tri_start = (int)tris_.size();
-            nodes_[me].tri_count = end - begin;
+            nodes_[me].leaf = ((int)tris_.size() << 4) | (end - begin);
             std::sort(order_.begin() + begin, order_.begin() + end);   // face order inside a leaf
             for (int k = begin; k < end; k++) {
                 const int face = order_[k];
@@ -125,8 +126,7 @@ private:
                                  double ca = cx_[3 * (size_t)(a - f0_) + axis], cb = cx_[3 * (size_t)(b - f0_) + axis];
                                  return ca < cb || (ca == cb && a < b);
                              });
-            nodes_[me].tri_start = -1;
-            nodes_[me].tri_count = 0;
+            nodes_[me].leaf = 0;
             build(begin, mid);
             build(mid, end);
         }

@@ -118,6 +118,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             return fail(PVT_ERR_INVALID, "mesh node without mesh tables");
         const long long f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
         if (fc <= 0 || f0 < 0 || f0 + fc > t->n_mesh_faces) return fail(PVT_ERR_INVALID, "mesh face range out of bounds");
+        if (t->n_mesh_faces >= (1 << 27)) return fail(PVT_ERR_INVALID, "more than 2^27 mesh faces in one scene");
         for (long long k = 3 * f0; k < 3 * (f0 + fc); k++)
             if (t->mesh_faces[k] < 0 || t->mesh_faces[k] >= t->n_mesh_vertices)
                 return fail(PVT_ERR_INVALID, "mesh face indexes a missing vertex");
@@ -611,11 +612,11 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
                 return fail(PVT_ERR_INVALID, "child box not inside its parent");
         }
         max_depth = std::max(max_depth, (int)open_end.size() + 1);
-        if (b.tri_count > 0) {
+        if ((b.leaf & 15) > 0) {
             if (b.skip != i + 1) return fail(PVT_ERR_INVALID, "leaf with a subtree");
             leaves += 1;
-            for (int k = 0; k < b.tri_count; k++) {
-                const pvt::MeshTri& tr = tris[b.tri_start + k];
+            for (int k = 0; k < (b.leaf & 15); k++) {
+                const pvt::MeshTri& tr = tris[(b.leaf >> 4) + k];
                 const long long local = tr.face - f0;
                 if (local < 0 || local >= fc || seen[local]++) return fail(PVT_ERR_INVALID, "face missing or duplicated");
                 for (int c = 0; c < 3; c++)

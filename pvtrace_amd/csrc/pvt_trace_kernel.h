@@ -702,17 +702,17 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         int i = T.iu(node * NI + NI_MESH);
                         const int end = A.bvh[i].skip;
                         while (i < end) {
-                            const pvt::BvhNode* b = A.bvh + i;
+                            const pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
                             double tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
                             for (int a = 0; a < 3; a++) {
-                                const double ta = (b->lo[a] - oo[a]) * inv[a], tb = (b->hi[a] - oo[a]) * inv[a];
+                                const double ta = ((double)b.lo[a] - oo[a]) * inv[a], tb = ((double)b.hi[a] - oo[a]) * inv[a];
                                 tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
                                 tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
                             }
-                            if (tmax < tmin || tmax < 0.0) { i = b->skip; continue; }
-                            const int tn = b->tri_count;
-                            const pvt::MeshTri* tr = A.tris + b->tri_start;
+                            if (tmax < tmin || tmax < 0.0) { i = b.skip; continue; }
+                            const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
+                            const pvt::MeshTri* tr = A.tris + tri_start;
                             for (int k = 0; k < tn; k++, tr++) {
                                 double va[3], vb[3], vc[3];
 #pragma unroll
@@ -737,7 +737,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                 const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
                                 if (!(t > kEps)) continue;
                                 const long long face = tr->face;
-                                const int tri = b->tri_start + k;
+                                const int tri = tri_start + k;
                                 if (nl == 0 || t < tfirst) tfirst = t;
                                 nl += 1;
                                 if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
