@@ -302,3 +302,34 @@ def test_empty_and_tiny_jobs_through_the_public_api():
         engine.simulate(scene, 5, seed=2, max_events=1)
     with pytest.raises(ValueError):
         engine.simulate(scene, -3, seed=2)
+
+
+def test_the_binding_printed_in_INTEGRATION_md_works_as_documented():
+    """INTEGRATION.md shows the ctypes module a pvtrace maintainer would drop in as
+    `pvtrace/engine/_kernel_hip.py`.  Execute exactly that text (library path aside) against the
+    flattener's tables and compare with the package's own binding."""
+    import os
+    import re
+
+    from pvtrace_amd.engine import native
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, numpy as np\n.*?)```", text, flags=re.S).group(1)
+    native.load_library()                                   # HIP runtime of torch first (native.py)
+    code = code.replace('C.CDLL("libpvtrace_hip.so")', f"C.CDLL({native.LIB_PATH!r})")
+    module = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), module)
+    scene = scenes.bench_slab(recorders=True)
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, 3000, seed=4)
+    for record_every in (1, 0):
+        theirs = module["trace_bundle"](compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, record_every)
+        ours = _kernel_module().trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, record_every)
+        assert_bundles_identical(theirs, ours, sums_rtol=1e-12, what="INTEGRATION.md stub")
+
+
+def _kernel_module():
+    from pvtrace_amd.engine import _kernel
+
+    return _kernel
