@@ -138,8 +138,21 @@ class EmitterTables:
 
 
 def _sphere(theta, phi):
+    out = np.empty((theta.shape[0], 3))
     st = np.sin(theta)
-    return np.column_stack((st * np.cos(phi), st * np.sin(phi), np.cos(theta)))
+    np.multiply(st, np.cos(phi), out=out[:, 0])
+    np.multiply(st, np.sin(phi), out=out[:, 1])
+    np.cos(theta, out=out[:, 2])
+    return out
+
+
+def _to_world(local, matrix, translate):
+    """(n,3) local rows -> world rows; skips the matrix product for axis-aligned lights."""
+    rot = matrix[:3, :3]
+    out = local if np.array_equal(rot, np.eye(3)) else local @ rot.T
+    if translate and np.any(matrix[:3, 3] != 0.0):
+        out = out + matrix[:3, 3]
+    return out
 
 
 def _sample_light(tab, i, n, uniform):
@@ -215,8 +228,8 @@ def emit_bundle(scene, num_rays, seed=None):
             continue
         pos, direc, wl = _sample_light(tab, i, count, uniform)
         m = tab.light_to_world[i]
-        positions[rows] = pos @ m[:3, :3].T + m[:3, 3]
-        directions[rows] = direc @ m[:3, :3].T
+        positions[rows] = _to_world(pos, m, translate=True)
+        directions[rows] = _to_world(direc, m, translate=False)
         wavelengths[rows] = wl
         if sources is not None:
             sources[rows] = tab.names[i]
