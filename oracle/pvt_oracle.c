@@ -658,7 +658,10 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
             r = fresnel_reflectivity(M, angle, n1, n2);
         }
         int coat = fres ? find_coating(S, hit, nl, lp) : -1;          /* EXTENSION */
-        if (coat >= 0 && S->coat_reflectivity[coat] >= 0.0) r = S->coat_reflectivity[coat];
+        /* a coating sets the reflectivity -- except beyond the critical angle when it transmits by
+         * Fresnel refraction: no refracted ray exists there, the light stays totally reflected */
+        if (coat >= 0 && S->coat_reflectivity[coat] >= 0.0 && !(r == 1.0 && S->coat_transmit_mode[coat] != 1))
+            r = S->coat_reflectivity[coat];
 
         double u = 1.0;
         if (r > 0.0) u = rng_uniform(&rng);

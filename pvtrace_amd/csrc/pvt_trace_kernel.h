@@ -1098,8 +1098,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     if (ok) coat = c;
                 }
                 if (coat >= 0) {
+                    // a coating sets the reflectivity -- except beyond the critical angle when it
+                    // transmits by Fresnel refraction: no refracted ray exists there
                     double cr = T.dv(L.coat_d + coat * KD + KD_REFL);
-                    if (cr >= 0.0) r = cr;
+                    if (cr >= 0.0 && !(r == 1.0 && T.iv(L.coat_i + coat * KI + KI_TMODE) != 1)) r = cr;
                 }
             }
             double u = 1.0;

@@ -361,12 +361,15 @@ class CoatedSurfaceDelegate(FresnelSurfaceDelegate):
         return None
 
     def reflectivity(self, surface, ray, geometry, container, adjacent):
-        coating = self._match(ray, geometry)
-        if coating is not None and coating.reflectivity is not None:
-            return coating.reflectivity
-        return super(CoatedSurfaceDelegate, self).reflectivity(
+        fresnel = super(CoatedSurfaceDelegate, self).reflectivity(
             surface, ray, geometry, container, adjacent
         )
+        coating = self._match(ray, geometry)
+        if coating is None or coating.reflectivity is None:
+            return fresnel
+        if fresnel == 1.0 and coating.transmission != "matched":
+            return 1.0   # beyond the critical angle no refracted ray exists: stays totally reflected
+        return coating.reflectivity
 
     def transmitted_direction(self, surface, ray, geometry, container, adjacent):
         coating = self._match(ray, geometry)

@@ -306,3 +306,33 @@ def test_every_kernel_variant_at_once():
                          math_mode=O.MATH_PORTABLE)
     assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what="all-variants")
     assert cpu["rec_distinct"][64:].sum() > 0 and cpu["counts"].max() > 4
+
+
+@pytest.mark.parametrize("extensions", [False, True])
+@pytest.mark.parametrize("seed", range(30))
+def test_random_scenes_gpu_equals_oracle(seed, extensions):
+    """Differential fuzz (tests/fuzz.py): random scenes -- with `extensions` also meshes, coatings,
+    histogram-sampled spectra and source-filtered recorders -- traced on the GPU and by the oracle,
+    alternating host rays and device emission: every output array identical."""
+    from tests.fuzz import random_scene
+
+    scene = random_scene(1000 * int(extensions) + seed, extensions=extensions)
+    compiled = compile_scene(scene)
+    mode = [(1, 48, 300, 0), (3, 16, 40, 1), (0, 8, 300, 2)][seed % 3]
+    record_every, max_events, maxsteps, emit_method = mode
+    n = 1500
+    try:
+        emitter = EmitterTables(scene) if seed % 2 else None
+    except Exception:
+        emitter = None
+    if emitter is not None:
+        pos, dirs, wl = O.emit(emitter, n, emit_seed=seed)
+        gpu = _kernel.trace_bundle(compiled, None, None, n, 9 + seed, maxsteps, max_events, emit_method, 1,
+                                   record_every, emitter=emitter, emit_seed=seed)
+    else:
+        pos, dirs, wl, _ = emit_bundle(scene, n, seed=seed)
+        gpu = _kernel.trace_bundle(compiled, pos, dirs, wl, 9 + seed, maxsteps, max_events, emit_method, 1,
+                                   record_every)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, 9 + seed, maxsteps, max_events, emit_method, 4,
+                         record_every, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=f"fuzz scene {seed} ext={extensions}")

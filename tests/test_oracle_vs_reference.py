@@ -44,3 +44,23 @@ def test_reference_rejects_more_than_128_nodes_like_we_do():
         O.reference_trace_bundle(compiled, pos, dirs, wl, 1, 10, 8, 0, 1, 0)
     with pytest.raises(ValueError):
         O.trace_bundle(compiled, pos, dirs, wl, 1, 10, 8, 0, 1, 0)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_oracle_equals_reference_kernel(seed):
+    """Differential fuzz: random shapes / nesting / overlaps / components / phase functions /
+    lifetimes / Null surfaces / recorders with 1-D and 2-D histograms on every property
+    (tests/fuzz.py), traced by the reference's compiled kernel and by the oracle: every output array
+    identical."""
+    from tests.fuzz import random_scene
+
+    scene = random_scene(seed)
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, 600, seed=seed)
+    mode = [(1, 48, 300, 0), (3, 16, 40, 1), (0, 8, 300, 2)][seed % 3]
+    record_every, max_events, maxsteps, emit_method = mode
+    ref = O.reference_trace_bundle(compiled, pos, dirs, wl, 77 + seed, maxsteps, max_events, emit_method, 1,
+                                   record_every)
+    mine = O.trace_bundle(compiled, pos, dirs, wl, 77 + seed, maxsteps, max_events, emit_method, 1,
+                          record_every, math_mode=O.MATH_LIBM)
+    assert_bundles_identical(mine, ref, what=f"fuzz scene {seed}")
