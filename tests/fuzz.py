@@ -58,14 +58,14 @@ def _components(rng, extensions):
 def _geometry(rng, material, extensions):
     k = rng.integers(0, 4 if extensions else 3)
     if k == 0:
-        return Box(tuple(rng.uniform(0.4, 3.0, 3)), material=material)
+        return Box(tuple(rng.uniform(0.8, 5.0, 3)), material=material)
     if k == 1:
-        return Sphere(float(rng.uniform(0.3, 1.8)), material=material)
+        return Sphere(float(rng.uniform(0.5, 2.8)), material=material)
     if k == 2:
-        return Cylinder(float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.2, 1.2)), material=material)
+        return Cylinder(float(rng.uniform(0.8, 5.0)), float(rng.uniform(0.4, 2.0)), material=material)
     if rng.random() < 0.5:
-        return Mesh.icosphere(int(rng.integers(0, 3)), float(rng.uniform(0.4, 1.6)), material=material)
-    return Mesh.box(tuple(rng.uniform(0.4, 2.5, 3)), material=material)
+        return Mesh.icosphere(int(rng.integers(0, 3)), float(rng.uniform(0.6, 2.6)), material=material)
+    return Mesh.box(tuple(rng.uniform(0.8, 4.0, 3)), material=material)
 
 
 def _recorders(rng, node, is_root, component_names, extensions):
@@ -112,7 +112,7 @@ def random_scene(seed, extensions=False):
         material = Material(float(rng.uniform(1.0, 2.2)), surface=surface, components=_components(rng, extensions))
         parent = world if rng.random() < 0.6 else nodes[int(rng.integers(0, len(nodes)))]
         node = Node(name=f"n{k}", parent=parent, geometry=_geometry(rng, material, extensions))
-        node.translate(tuple(rng.uniform(-2.5, 2.5, 3)))
+        node.translate(tuple(rng.uniform(-1.5, 1.5, 3)))
         if rng.random() < 0.6:
             node.rotate(float(rng.uniform(0, np.pi)), tuple(rng.normal(size=3)))
         nodes.append(node)
@@ -126,9 +126,9 @@ def random_scene(seed, extensions=False):
         wl = ConstantWavelengthMask(float(rng.uniform(400, 800))) if rng.random() < 0.6 else SpectrumWavelengthMask(
             Distribution(*_spectrum(rng, True).T))
         pos = [None, RectangularMask(0.8, 0.5), CircularMask(0.7), CubeMask(0.3, 0.3, 0.3)][int(rng.integers(0, 4))]
-        direc = [None, isotropic, lambertian, Cone(float(rng.uniform(0.05, 1.2))),
-                 HenyeyGreenstein(float(rng.uniform(-0.8, 0.8)))][int(rng.integers(0, 5))]
+        direc = [None, None, Cone(float(rng.uniform(0.05, 0.6))), isotropic, lambertian, Cone(float(rng.uniform(0.05, 1.2))),
+                 HenyeyGreenstein(float(rng.uniform(-0.8, 0.8)))][int(rng.integers(0, 7))]
         light = Node(name=f"light{k}", parent=world, light=Light(wavelength=wl, position=pos, direction=direc, name=f"light{k}"))
-        light.translate(tuple(rng.uniform(-4.0, 4.0, 3)))
+        light.translate(tuple(rng.uniform(-3.0, 3.0, 3)))
         light.look_at(tuple(-np.asarray(light.location) + rng.normal(scale=0.3, size=3)))
     return Scene(world)
