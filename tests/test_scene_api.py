@@ -325,3 +325,24 @@ def test_node_frames_known_answers_of_the_reference():
     assert np.allclose(n.pose, rotation_matrix(np.pi / 2, [0, 1, 0]))
     n = Node(name="n"); n.look_at([0, 0, -1])
     assert np.allclose(n.pose, rotation_matrix(np.pi, [0, 1, 0]))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_python_tally_reproduces_kernel_tallies_on_random_scenes(seed):
+    """The host-side recorder semantics (engine/tally.py) against the kernel-side accumulators on
+    random scenes (tests/fuzz.py): rays, crossings and every histogram bin -- facets, source
+    filters, heatmaps in the recorder node's frame included."""
+    from tests.fuzz import random_scene
+
+    scene = random_scene(400 + seed, extensions=bool(seed % 2))
+    compiled = compile_scene(scene)
+    pos, dirs, wl, src = emit_bundle(scene, 200, seed=seed)
+    data = O.trace_bundle(compiled, pos, dirs, wl, 5 + seed, 300, 64, 0, 1, 1)
+    if data["counts"].max() >= 63 or np.isnan(data["direction"]).any() or not compiled.recorder_names:
+        pytest.skip("truncated or NaN histories cannot be re-tallied")
+    result = EngineResult(compiled, data, src, 64, 1, 0.0)
+    python_side = tally_histories(scene, result.histories())
+    for name, rec in result.recorders.items():
+        assert python_side[name].rays == rec.rays and python_side[name].crossings == rec.crossings, name
+        for i in range(len(rec.spec.histograms)):
+            assert np.array_equal(python_side[name]._bins[i], rec._bins[i]), (name, i)
