@@ -19,7 +19,7 @@ RANGES = {"wavelength": (350.0, 850.0), "angle": (0.0, 1.6), "duration": (0.0, 2
 
 
 def _spectrum(rng, even):
-    n = int(rng.integers(2, 40))
+    n = int(rng.integers(2, 40)) if rng.random() > 0.04 else int(rng.integers(3000, 7000))   # some too big for LDS
     x = np.linspace(360.0, 840.0, n) if even else np.sort(rng.uniform(360.0, 840.0, n))
     x[0], x[-1] = 360.0, 840.0
     y = rng.uniform(0.0, 1.0) * gaussian(x, 1.0, rng.uniform(420, 760), rng.uniform(15, 120)) + rng.uniform(0, 0.05)
@@ -119,6 +119,12 @@ def random_scene(seed, extensions=False):
     names = [c.name for n in nodes for c in n.geometry.material.components]
     for node in nodes:
         node.recorders = _recorders(rng, node, node is world, names, extensions)
+    if rng.random() < 0.08:   # sometimes more than 64 recorders: the wide per-ray "seen" mask
+        target = nodes[int(rng.integers(0, len(nodes)))]
+        target.recorders = list(target.recorders) + [
+            Recorder(f"extra{k}", event=str(rng.choice(["entering", "escaping", "reflected", "lost"])),
+                     histograms=[Histogram("wavelength", 350.0, 850.0, 5)] if k % 9 == 0 else [])
+            for k in range(int(rng.integers(65, 120)))]
     taken = set()
     for node in nodes:      # recorder names must be unique
         node.recorders = [r for r in node.recorders if not (r.name in taken or taken.add(r.name))]
