@@ -496,7 +496,7 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
     if (a.bins_in_lds) lds += (bins_bytes + 7) & ~(size_t)7;
     lds += CTL_WORDS * 4;
-    // drain-phase consolidation buffer: kXSlots photon states, if four workgroups still fit a CU
+    // drain-phase consolidation buffer: kXSlots photon states (also the seed pools), within 40 KB
     const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 3 : 0);
     const size_t xbytes = (size_t)kXSlots * xw * 8;
     a.xslots = 0;

@@ -18,7 +18,11 @@ constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
 constexpr int kWaves = kBlock / 64;
 constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
-constexpr int kXSlots = 128;         // LDS photon-state slots used to repack a draining workgroup
+constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a draining workgroup (>= 64: the
+                                     // last stage packs the survivors into one wave; >= 69 so that the 8 KB of
+                                     // per-wave seed pools fit in the same region); small enough that FIVE
+                                     // workgroups' LDS fit a CU, so a fresh workgroup of the next launch can
+                                     // start while draining ones still hold theirs (+6 % on pipelined bundles)
 // workgroup control words in LDS
 enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_WORDS = 16 };
 constexpr double kEps = 2.220446049250313e-13;       // _kernel.pyx:29
