@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 4
+#define PVT_ABI_VERSION 5
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -173,7 +173,10 @@ typedef struct PvtTraceParams {
     int32_t maxsteps;
     int32_t max_events;
     int32_t emit_method;    /* PVT_EMIT_*                                            */
-    int32_t reserved;
+    int32_t workgroups_per_cu; /* persistent workgroups launched per CU; 0 = default (4: one launch
+                                * fills the chip).  Launches that overlap on several streams run best
+                                * with fewer (2 with three in flight): each then holds fewer CU slots
+                                * while it drains, and a workgroup amortises its drain over more photons */
 } PvtTraceParams;
 
 /* initial rays, world frame (exactly trace_bundle's three array arguments) */

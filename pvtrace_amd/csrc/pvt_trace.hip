@@ -510,8 +510,8 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     // persistent grid: enough workgroups to fill every CU a few times over,
     // never more than the rays can feed
     long long blocks_for_rays = (p->n_rays + kBlock - 1) / kBlock;
-    double per_cu = 4.0;
-    if (const char* env = getenv("PVT_BLOCKS_PER_CU")) per_cu = atof(env) > 0 ? atof(env) : per_cu;
+    double per_cu = p->workgroups_per_cu > 0 ? (double)p->workgroups_per_cu : 4.0;
+    if (const char* env = getenv("PVT_BLOCKS_PER_CU")) per_cu = atof(env) > 0 ? atof(env) : per_cu;   // dev override
     long long grid = (long long)((double)s->num_cu * per_cu);
     if (grid > blocks_for_rays) grid = blocks_for_rays;
     if (grid < 1) grid = 1;

@@ -73,7 +73,7 @@ class PvtTraceParams(C.Structure):
     _fields_ = [
         ("n_rays", C.c_int64), ("seed", C.c_uint64), ("ray_offset", C.c_uint64),
         ("emit_seed", C.c_uint64), ("record_every", C.c_int64), ("maxsteps", C.c_int32),
-        ("max_events", C.c_int32), ("emit_method", C.c_int32), ("reserved", C.c_int32),
+        ("max_events", C.c_int32), ("emit_method", C.c_int32), ("workgroups_per_cu", C.c_int32),
     ]
 
 
@@ -169,11 +169,11 @@ def emitter_tables_struct(emitter):
 
 
 def trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps, max_events,
-                 emit_method):
+                 emit_method, workgroups_per_cu=0):
     mask = (1 << 64) - 1
     return PvtTraceParams(
         int(n_rays), int(seed) & mask, int(ray_offset) & mask, int(emit_seed) & mask,
-        int(record_every), int(maxsteps), int(max_events), int(emit_method), 0,
+        int(record_every), int(maxsteps), int(max_events), int(emit_method), int(workgroups_per_cu),
     )
 
 
@@ -230,7 +230,7 @@ ABI_SYMBOLS = (
 )
 
 _lib = None
-ABI_VERSION = 4   # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 5   # include/pvtrace_hip.h PVT_ABI_VERSION
 
 
 def library_built():
@@ -407,15 +407,17 @@ class DeviceScene:
         return log
 
     def trace(self, rays, n_rays, seed, tallies, log=None, ray_offset=0, emit_seed=0,
-              record_every=0, maxsteps=1000, max_events=128, emit_method=0, stream=None):
-        """Enqueue one bundle.  `rays` is None (device emission) or a tuple of
+              record_every=0, maxsteps=1000, max_events=128, emit_method=0, stream=None,
+              workgroups_per_cu=0):
+        """Enqueue one bundle (`workgroups_per_cu`: see PvtTraceParams; 0 = the library default).
+        `rays` is None (device emission) or a tuple of
         three float64 CUDA tensors (positions (n,3), directions (n,3), wavelengths (n))."""
         import torch
 
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         params = trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps,
-                              max_events, emit_method)
+                              max_events, emit_method, workgroups_per_cu)
         tl = PvtTallies(
             addr_ptr(tallies["rec_distinct"].data_ptr(), C.c_int64),
             addr_ptr(tallies["rec_crossings"].data_ptr(), C.c_int64),

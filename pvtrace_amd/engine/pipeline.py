@@ -33,6 +33,9 @@ class BundlePipeline:
         self.depth = max(1, int(depth))
         self.distributed = distributed
         self.group = group
+        # launches that overlap run best with fewer persistent workgroups each (measured on the
+        # LSC, 10^6-photon bundles: 2 per CU with three in flight, 3 with two, 4 alone)
+        self.workgroups_per_cu = {1: 4, 2: 3}.get(self.depth, 2)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.slots = [dscene.new_tallies() for _ in range(self.depth)]
         self.totals = [dscene.new_tallies() for _ in range(self.depth)]
@@ -59,7 +62,7 @@ class BundlePipeline:
             self.dscene.trace(rays, n_rays, seed=seed, tallies=tallies, ray_offset=ray_offset,
                               emit_seed=emit_seed, record_every=0, maxsteps=maxsteps,
                               max_events=max_events, emit_method=emit_method,
-                              stream=stream.cuda_stream)
+                              stream=stream.cuda_stream, workgroups_per_cu=self.workgroups_per_cu)
             if timed:
                 ev[1].record(stream)
                 self.events.append(ev)
