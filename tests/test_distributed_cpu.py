@@ -62,7 +62,7 @@ def test_shard_ranges_partition_the_job():
                 assert all(a[1] == b[0] and a[1] % align == 0 for a, b in zip(edges, edges[1:]))
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(1200)
 def test_two_rank_gloo_job_equals_single_process(tmp_path):
     import torch.multiprocessing as mp
 

@@ -56,7 +56,7 @@ def _worker(rank, world, port, n, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(1800)
 def test_two_processes_on_one_gpu_reproduce_the_single_process_job(tmp_path):
     import torch.multiprocessing as mp
 
