@@ -275,7 +275,7 @@ class Session:
         self.close()
 
     def submit(self, num_rays, seed, maxsteps=1000, max_events=128, emit_method="kT", record_every=1,
-               emit_seed=None, ray_offset=0):
+               emit_seed=None, ray_offset=0, workgroups_per_cu=0):
         """Enqueue one bundle on one of two HIP streams and return a handle for `collect`.
         Two bundles may be in flight: the next one is traced while the caller consumes the
         previous result."""
@@ -320,7 +320,8 @@ class Session:
                 dscene.trace(rays, num_rays, int(seed), tallies, log=log, ray_offset=ray_offset,
                              emit_seed=int(emit_seed or 0), record_every=int(record_every),
                              maxsteps=int(maxsteps), max_events=int(max_events),
-                             emit_method=EMIT_METHODS[emit_method], stream=stream.cuda_stream)
+                             emit_method=EMIT_METHODS[emit_method], stream=stream.cuda_stream,
+                             workgroups_per_cu=workgroups_per_cu)
                 stop.record(stream)
         return {"stream": stream, "tallies": tallies, "log": log, "events": (start, stop), "tic": tic,
                 "rays": rays, "sources": sources, "num_rays": num_rays, "record_every": record_every,
@@ -407,9 +408,10 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
         if session.emission == "device":
             # one emission stream for the whole job: ray i of the job is the same photon
             # whatever the bundle size
-            return session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=traced, **kwargs), n
+            return session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=traced,
+                                  workgroups_per_cu=3, **kwargs), n     # two bundles in flight
         bundle_emit_seed = None if emit_seed is None else int(emit_seed) + traced
-        return session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, **kwargs), n
+        return session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, workgroups_per_cu=3, **kwargs), n
 
     traced = 0
     try:
