@@ -218,6 +218,14 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[NI_KSTART] = K > 0 ? t->coat_start[n] : 0;
         q[NI_KCOUNT] = K > 0 ? t->coat_count[n] : 0;
         q[NI_MESH] = -1;
+        q[NI_ROT] = n;   // first node whose world->local rotation (the 3x3 block) has the same bits
+        for (int e = 0; e < n; e++) {
+            bool same = true;
+            for (int r = 0; r < 3 && same; r++)
+                for (int c = 0; c < 3 && same; c++)
+                    same = std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], &t->world_to_local[e * 16 + r * 4 + c], 8) == 0;
+            if (same) { q[NI_ROT] = e; break; }
+        }
         if (t->geom_type[n] == PVT_GEOM_MESH) {
             const int f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
             q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris)
@@ -261,9 +269,23 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             }
             return 1.0 / w;
         };
+        // the spacing itself when, additionally, xs[i] == xs[0] + i*w bit for bit (then the kernel finds the
+        // reference's bisection index by arithmetic): evaluated exactly as the device does
+        auto even_w = [](const double* xs, int n, double rcp) -> double {
+            if (!(rcp == rcp) || n < 2) return NAN;
+            const double w = xs[1] - xs[0];
+            for (int i = 0; i < n; i++) {
+                volatile double prod = (double)i * w;   // two roundings, never contracted
+                volatile double at = xs[0] + prod;
+                if (at != xs[i]) return NAN;
+            }
+            return w;
+        };
         d[CD_ABS_RCP] = even_rcp(t->abs_x + t->comp_abs_start[c], t->abs_y + t->comp_abs_start[c], t->comp_abs_n[c]);
         d[CD_EMS_RCP_X] = even_rcp(t->ems_x + t->comp_ems_start[c], t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c]);
         d[CD_EMS_RCP_C] = even_rcp(t->ems_cdf + t->comp_ems_start[c], t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c]);
+        d[CD_ABS_W] = even_w(t->abs_x + t->comp_abs_start[c], t->comp_abs_n[c], d[CD_ABS_RCP]);
+        d[CD_EMS_W] = even_w(t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c], d[CD_EMS_RCP_X]);
     }
     for (int r = 0; r < R; r++) {
         double* d = gd.data() + lay.rec_d + r * RD;
@@ -407,9 +429,17 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
     return a;
 }
 
+#ifndef PVT_DEV_VARIANTS
+#define PVT_DEV_VARIANTS 0   // developer builds: only the analytic, array-input, <=64-recorder variants (fast compile)
+#endif
 template <bool RECORD, bool TAB_LDS, int SEENW>
 hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
     const bool mesh = a.bvh != nullptr;
+#if PVT_DEV_VARIANTS
+    if (emit || mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
+    if constexpr (TAB_LDS && SEENW == 1)
+        hipLaunchKernelGGL((trace_kernel<RECORD, true, 1, false, false>), dim3(grid), dim3(kBlock), lds, st, a);
+#else
     if (emit) {
         if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, true>), dim3(grid), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, false>), dim3(grid), dim3(kBlock), lds, st, a);
@@ -417,6 +447,7 @@ hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const
         if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, false>), dim3(grid), dim3(kBlock), lds, st, a);
     }
+#endif
     return hipGetLastError();
 }
 

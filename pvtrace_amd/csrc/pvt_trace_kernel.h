@@ -3,6 +3,7 @@
 // and the trace kernel itself.  Included once, by pvt_trace.hip (which holds the design
 // overview, the host-side packing and the C ABI).
 #pragma once
+#include <type_traits>
 // Developer-only ablation switches (timing experiments; results are WRONG when set).
 #ifndef PVT_ABLATE
 #define PVT_ABLATE 0
@@ -35,9 +36,11 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // table element is addressed as base + index*stride + field with compile-time strides
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
 enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND_RN = 26, ND = 27 };  // node doubles (RN: RN(1/n))
-enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI };  // node ints (NI_MESH: BVH root, -1 = none)
+enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI_ROT, NI };  // node ints (NI_MESH: BVH root, -1 = none;
+                                                                                          // NI_ROT: first node whose world->local rotation has the same bits)
 enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C,
-       CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN)
+       CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD_ABS_W, CD_EMS_W, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN;
+                                                            // *_W: the spacing w when additionally xs[i] == xs[0] + i*w bit for bit, else NaN)
 enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N,
        CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI_ABS_HIST, CI_EMS_HIST, CI };  // *_G*: guide tables; *_HIST: step tables
 enum { RD_FACET = 0, RD_ATOL = 3, RD = 4 };                                     // recorder
@@ -180,13 +183,32 @@ constexpr double kRcpCcm = 1.0 / kCcm;   // correctly rounded by the compiler
 // brackets the answer to a bucket first, the bracket is VALIDATED against the table (falls
 // back to the full range if rounding put x in a neighbouring bucket), and the same bisection
 // runs inside the bracket: typically 0-1 steps instead of ~log2(n) dependent LDS reads.
-template <bool TAB_LDS>
+// UNI: the descriptor (xs, ys, n, ...) is wave-uniform, so the table ends come through the scalar
+// cache.  `w` (NaN = no): the abscissae are xs[0] + i*w bit for bit AND every interval has the bits
+// of w (both checked by the host), so the reference's index is found by arithmetic — no table
+// walk, no dependent LDS reads — and validated against the (computed) neighbours.  `yw` likewise for
+// the ordinates (the inverse-CDF lookup returns wavelengths of an evenly spaced grid).
+template <bool TAB_LDS, bool UNI>
 __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n,
-                                                 int guide, double scale, int hist, double rcp) {
-    if (n == 1) return T.dv(ys);
-    const double x0 = T.dv(xs), xl = T.dv(xs + n - 1);
-    if (x <= x0) return T.dv(ys);
-    if (hist ? x > xl : x >= xl) return T.dv(ys + n - 1);  // step tables search x == xl (plateaus)
+                                                 int guide, double scale, int hist, double rcp,
+                                                 double w = __builtin_nan(""), double yw = __builtin_nan("")) {
+    auto end = [&](int i) { return UNI ? T.du(i) : T.dv(i); };
+    if (n == 1) return end(ys);
+    const double x0 = end(xs), xl = end(xs + n - 1);
+    if (x <= x0) return end(ys);
+    if (hist ? x > xl : x >= xl) return end(ys + n - 1);  // step tables search x == xl (plateaus)
+    if (!hist && w == w) {
+        int i = (int)((x - x0) * rcp);
+        i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+        double xlo = x0 + (double)i * w;
+        if (x < xlo) { i -= 1; xlo = x0 + (double)i * w; }
+        double xhi = x0 + (double)(i + 1) * w;
+        if (!(x < xhi)) { i += 1; xlo = xhi; xhi = x0 + (double)(i + 1) * w; }
+        if (xlo <= x && x < xhi) {   // always, the product being within an ulp or two of the true quotient
+            const double ylo = T.dv(ys + i), yhi = T.dv(ys + i + 1);
+            return ylo + div_known((yhi - ylo) * (x - xlo), xhi - xlo, rcp);
+        }
+    }
     int b = (int)((x - x0) * scale);
     b = b < 0 ? 0 : (b > n - 2 ? n - 2 : b);
     int lo = T.iv(guide + b), hi = T.iv(guide + b + 1) + 1;
@@ -211,7 +233,13 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
         const double xm = T.dv(xs + mid);
         if (xm <= x) { lo = mid; xlo = xm; } else { hi = mid; xhi = xm; }
     }
-    const double ylo = T.dv(ys + lo), yhi = T.dv(ys + hi);
+    double ylo, yhi;
+    if (yw == yw) {   // ordinates of an evenly spaced grid: computed, same bits as the table's
+        const double y0 = end(ys);
+        ylo = y0 + (double)lo * yw; yhi = y0 + (double)hi * yw;
+    } else {
+        ylo = T.dv(ys + lo); yhi = T.dv(ys + hi);
+    }
     if (xhi == xlo) return ylo;
     // evenly spaced abscissae (every interval has the same bits, checked by the host): the
     // divisor is known in advance, see div_known
@@ -644,6 +672,13 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         bool em = false, em_acos = false;   // re-emission pending: acos argument (or theta) and phi
         double em_x = 0.0, em_phi = 0.0;
 
+        // ---- stage 1: where does the ray go?  (every live lane) ------------------------------------
+        // Lane classes for the rest of the step; the divergent bodies below are keyed on them.
+        enum { CLS_NONE = 0, CLS_SURF, CLS_EXIT, CLS_ABS };
+        int cls = CLS_NONE;
+        int hit = -1, container = -1, adjacent = -1;
+        double t0 = 0.0;
+        bool pend = false;   // reaches the exit / absorption / surface decision
         if (alive) {
             count += 1;
             bool budget_kill = false;
@@ -657,161 +692,176 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 int nhits = 0, n1 = -1, n2 = -1, cnode = -1;
                 tri1 = -1;
                 double t1 = INFINITY, t2 = INFINITY, cbest = INFINITY;
+                V3 d{0, 0, 0};
+                double inv[3] = {0, 0, 0};
+                bool inv_ok = false;   // wave-uniform
+                int rot = -1;          // rotation class of `d` (wave-uniform)
                 for (int node = 0; node < A.n_nodes; node++) {
                     const int m = node * ND + ND_W2L;
-                    V3 o, d;
+                    V3 o;
                     o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + T.du(m + 3);
                     o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + T.du(m + 7);
                     o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + T.du(m + 11);
-                    d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
-                    d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
-                    d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
-                    const int gp = node * ND + ND_PARAMS;
-                    const int gt = T.iu(node * NI + NI_GEOM);
-                    // Hits are folded as they are found, in the reference's (node, k)
-                    // order, so no per-ray hit list exists; the tie-breaks equal the
-                    // reference's argmin scans over its hit arrays (:684-714).
-                    int nl = 0;
-                    double tfirst = 0.0;
-                    auto fold = [&](double t) {
-                        if (nl == 0) tfirst = t;
-                        nl += 1;
-                        if (nhits == 0) { t1 = t; n1 = node; }
-                        else if (t < t1) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
-                        else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
-                        nhits += 1;
-                    };
-                    if (MESH && gt == PVT_GEOM_MESH) {
-                        // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
-                        // forward crossing of the node's triangles, found by a stack-free walk of
-                        // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
-                        // (t, face) so the result does not depend on the walk order.
-                        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-                        const double ax = pvt_fabs(d.x), ay = pvt_fabs(d.y), az = pvt_fabs(d.z);
-                        const int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-                        int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
-                        auto pick = [](const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
-                        const double dz = pick(dd, kz);
-                        if (dz < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
-                        const double shx = pick(dd, kx) / dz, shy = pick(dd, ky) / dz, shz = 1.0 / dz;
-                        // Box culling only has to be conservative (a false hit costs a triangle test, a
-                        // false miss would lose a crossing).  A ray parallel to a slab gets a huge finite
-                        // reciprocal instead of inf: inside the slab the two plane distances then have
-                        // opposite signs (interval covers everything), outside the same sign (pushed out
-                        // of range, or a harmless false hit), and 0 * inf = NaN can never arise.
-                        double inv[3];
+                    // Nodes whose world->local rotations are bit-identical (the host files them under the
+                    // first such node) see the same local direction: it and its reciprocals are reused.
+                    const int rc = T.iu(node * NI + NI_ROT);
+                    if (rc != rot) {
+                        d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
+                        d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
+                        d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
+                        rot = rc;
+                        inv_ok = false;
+                    }
+                const int gp = node * ND + ND_PARAMS;
+                const int gt = T.iu(node * NI + NI_GEOM);
+                // Hits are folded as they are found, in the reference's (node, k)
+                // order, so no per-ray hit list exists; the tie-breaks equal the
+                // reference's argmin scans over its hit arrays (:684-714).
+                int nl = 0;
+                double tfirst = 0.0;
+                auto fold = [&](double t) {
+                    if (nl == 0) tfirst = t;
+                    nl += 1;
+                    if (nhits == 0) { t1 = t; n1 = node; }
+                    else if (t < t1) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
+                    else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
+                    nhits += 1;
+                };
+                if (MESH && gt == PVT_GEOM_MESH) {
+                    // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
+                    // forward crossing of the node's triangles, found by a stack-free walk of
+                    // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
+                    // (t, face) so the result does not depend on the walk order.
+                    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+                    const double ax = pvt_fabs(d.x), ay = pvt_fabs(d.y), az = pvt_fabs(d.z);
+                    const int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+                    int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+                    auto pick = [](const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
+                    const double dz = pick(dd, kz);
+                    if (dz < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
+                    const double shx = pick(dd, kx) / dz, shy = pick(dd, ky) / dz, shz = 1.0 / dz;
+                    // Box culling only has to be conservative (a false hit costs a triangle test, a
+                    // false miss would lose a crossing).  A ray parallel to a slab gets a huge finite
+                    // reciprocal instead of inf: inside the slab the two plane distances then have
+                    // opposite signs (interval covers everything), outside the same sign (pushed out
+                    // of range, or a harmless false hit), and 0 * inf = NaN can never arise.
+                    double minv[3];
 #pragma unroll
-                        for (int a = 0; a < 3; a++) inv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
-                        long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
-                        int i = T.iu(node * NI + NI_MESH);
-                        const int end = A.bvh[i].skip;
-                        while (i < end) {
-                            const pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
-                            double tmin = -INFINITY, tmax = INFINITY;
-#pragma unroll
-                            for (int a = 0; a < 3; a++) {
-                                const double ta = ((double)b.lo[a] - oo[a]) * inv[a], tb = ((double)b.hi[a] - oo[a]) * inv[a];
-                                tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
-                                tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
-                            }
-                            if (tmax < tmin || tmax < 0.0) { i = b.skip; continue; }
-                            const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
-                            const pvt::MeshTri* tr = A.tris + tri_start;
-                            for (int k = 0; k < tn; k++, tr++) {
-                                double va[3], vb[3], vc[3];
-#pragma unroll
-                                for (int a = 0; a < 3; a++) {
-                                    va[a] = tr->v[a] - oo[a]; vb[a] = tr->v[3 + a] - oo[a]; vc[a] = tr->v[6 + a] - oo[a];
-                                }
-                                const double az_ = pick(va, kz), bz_ = pick(vb, kz), cz_ = pick(vc, kz);
-                                const double axs = pick(va, kx) - shx * az_, ays = pick(va, ky) - shy * az_;
-                                const double bxs = pick(vb, kx) - shx * bz_, bys = pick(vb, ky) - shy * bz_;
-                                const double cxs = pick(vc, kx) - shx * cz_, cys = pick(vc, ky) - shy * cz_;
-                                const double u = cxs * bys - cys * bxs;
-                                const double v = axs * cys - ays * cxs;
-                                const double w = bxs * ays - bys * axs;
-                                if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) continue;
-                                const double det = u + v + w;
-                                if (det == 0.0) continue;
-                                const double sg = det < 0.0 ? -1.0 : 1.0;
-                                auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
-                                if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) continue;
-                                if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) continue;
-                                if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
-                                const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
-                                if (!(t > kEps)) continue;
-                                const long long face = tr->face;
-                                const int tri = tri_start + k;
-                                if (nl == 0 || t < tfirst) tfirst = t;
-                                nl += 1;
-                                if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
-                                else if (t < t1 || (t == t1 && f1 >= 0 && face < f1)) {
-                                    t2 = t1; n2 = n1; f2 = f1; t1 = t; n1 = node; tri1 = tri; f1 = face;
-                                } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
-                                nhits += 1;
-                            }
-                            i += 1;
-                        }
-                    } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
+                    for (int a = 0; a < 3; a++) minv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
+                    long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
+                    int i = T.iu(node * NI + NI_MESH);
+                    const int end = A.bvh[i].skip;
+                    while (i < end) {
+                        const pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
                         double tmin = -INFINITY, tmax = INFINITY;
-                        bool miss = false;
-                        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
 #pragma unroll
                         for (int a = 0; a < 3; a++) {
-                            double sz = T.du(gp + a);
-                            double lo = -0.5 * sz, hi = 0.5 * sz;
-                            if (pvt_fabs(dd[a]) < 1e-300) {
-                                if (oo[a] < lo || oo[a] > hi) miss = true;
-                            } else {
-                                double inv = 1.0 / dd[a];
-                                double ta = (lo - oo[a]) * inv, tb = (hi - oo[a]) * inv;
-                                if (ta > tb) { double tmp = ta; ta = tb; tb = tmp; }
-                                if (ta > tmin) tmin = ta;
-                                if (tb < tmax) tmax = tb;
+                            const double ta = ((double)b.lo[a] - oo[a]) * minv[a], tb = ((double)b.hi[a] - oo[a]) * minv[a];
+                            tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                            tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                        }
+                        if (tmax < tmin || tmax < 0.0) { i = b.skip; continue; }
+                        const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
+                        const pvt::MeshTri* tr = A.tris + tri_start;
+                        for (int k = 0; k < tn; k++, tr++) {
+                            double va[3], vb[3], vc[3];
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                va[a] = tr->v[a] - oo[a]; vb[a] = tr->v[3 + a] - oo[a]; vc[a] = tr->v[6 + a] - oo[a];
                             }
+                            const double az_ = pick(va, kz), bz_ = pick(vb, kz), cz_ = pick(vc, kz);
+                            const double axs = pick(va, kx) - shx * az_, ays = pick(va, ky) - shy * az_;
+                            const double bxs = pick(vb, kx) - shx * bz_, bys = pick(vb, ky) - shy * bz_;
+                            const double cxs = pick(vc, kx) - shx * cz_, cys = pick(vc, ky) - shy * cz_;
+                            const double u = cxs * bys - cys * bxs;
+                            const double v = axs * cys - ays * cxs;
+                            const double w = bxs * ays - bys * axs;
+                            if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) continue;
+                            const double det = u + v + w;
+                            if (det == 0.0) continue;
+                            const double sg = det < 0.0 ? -1.0 : 1.0;
+                            auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
+                            if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) continue;
+                            if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) continue;
+                            if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
+                            const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
+                            if (!(t > kEps)) continue;
+                            const long long face = tr->face;
+                            const int tri = tri_start + k;
+                            if (nl == 0 || t < tfirst) tfirst = t;
+                            nl += 1;
+                            if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
+                            else if (t < t1 || (t == t1 && f1 >= 0 && face < f1)) {
+                                t2 = t1; n2 = n1; f2 = f1; t1 = t; n1 = node; tri1 = tri; f1 = face;
+                            } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
+                            nhits += 1;
                         }
-                        if (!miss && !(tmax < tmin)) {
-                            if (tmin > kEps) fold(tmin);
-                            if (tmax > kEps) fold(tmax);
-                        }
-                    } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
-                        double radius = T.du(gp);
-                        double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
+                        i += 1;
+                    }
+                } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
+                double tmin = -INFINITY, tmax = INFINITY;
+                bool miss = false;
+                const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+                if (!inv_ok) {   // 1/d per axis, shared by consecutive nodes whose rotations have the same bits
+#pragma unroll
+                    for (int a = 0; a < 3; a++) inv[a] = 1.0 / dd[a];   // (inf for a zero component: never used below)
+                    inv_ok = true;
+                }
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    double sz = T.du(gp + a);
+                    double lo = -0.5 * sz, hi = 0.5 * sz;
+                    if (pvt_fabs(dd[a]) < 1e-300) {
+                        if (oo[a] < lo || oo[a] > hi) miss = true;
+                    } else {
+                        double ta = (lo - oo[a]) * inv[a], tb = (hi - oo[a]) * inv[a];
+                        if (ta > tb) { double tmp = ta; ta = tb; tb = tmp; }
+                        if (ta > tmin) tmin = ta;
+                        if (tb < tmax) tmax = tb;
+                    }
+                }
+                if (!miss && !(tmax < tmin)) {
+                    if (tmin > kEps) fold(tmin);
+                    if (tmax > kEps) fold(tmax);
+                }
+            } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
+                    double radius = T.du(gp);
+                    double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
+                    double disc = b * b - 4.0 * a * c;
+                    if (!(disc < 0.0)) {
+                        double sq = pvt_sqrt(disc);
+                        double t = (-b - sq) / (2.0 * a);
+                        if (t > kEps) fold(t);
+                        t = (-b + sq) / (2.0 * a);
+                        if (t > kEps) fold(t);
+                    }
+                } else {  // capped z cylinder (:301-345)
+                    double half = 0.5 * T.du(gp), radius = T.du(gp + 1);
+                    double a = d.x * d.x + d.y * d.y;
+                    if (a > 1e-300) {
+                        double b = 2.0 * (o.x * d.x + o.y * d.y);
+                        double c = o.x * o.x + o.y * o.y - radius * radius;
                         double disc = b * b - 4.0 * a * c;
-                        if (!(disc < 0.0)) {
+                        if (disc >= 0.0) {
                             double sq = pvt_sqrt(disc);
                             double t = (-b - sq) / (2.0 * a);
-                            if (t > kEps) fold(t);
+                            double z = o.z + t * d.z;
+                            if (z > -half && z < half && t > kEps) fold(t);
                             t = (-b + sq) / (2.0 * a);
-                            if (t > kEps) fold(t);
-                        }
-                    } else {  // capped z cylinder (:301-345)
-                        double half = 0.5 * T.du(gp), radius = T.du(gp + 1);
-                        double a = d.x * d.x + d.y * d.y;
-                        if (a > 1e-300) {
-                            double b = 2.0 * (o.x * d.x + o.y * d.y);
-                            double c = o.x * o.x + o.y * o.y - radius * radius;
-                            double disc = b * b - 4.0 * a * c;
-                            if (disc >= 0.0) {
-                                double sq = pvt_sqrt(disc);
-                                double t = (-b - sq) / (2.0 * a);
-                                double z = o.z + t * d.z;
-                                if (z > -half && z < half && t > kEps) fold(t);
-                                t = (-b + sq) / (2.0 * a);
-                                z = o.z + t * d.z;
-                                if (z > -half && z < half && t > kEps) fold(t);
-                            }
-                        }
-                        if (pvt_fabs(d.z) > 1e-300) {
-                            double t = (-half - o.z) / d.z;
-                            double x = o.x + t * d.x, y = o.y + t * d.y;
-                            if (x * x + y * y <= radius * radius && t > kEps) fold(t);
-                            t = (half - o.z) / d.z;
-                            x = o.x + t * d.x;
-                            y = o.y + t * d.y;
-                            if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                            z = o.z + t * d.z;
+                            if (z > -half && z < half && t > kEps) fold(t);
                         }
                     }
+                    if (pvt_fabs(d.z) > 1e-300) {
+                        double t = (-half - o.z) / d.z;
+                        double x = o.x + t * d.x, y = o.y + t * d.y;
+                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                        t = (half - o.z) / d.z;
+                        x = o.x + t * d.x;
+                        y = o.y + t * d.y;
+                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                    }
+                }
                     if (nl == 1 && tfirst < cbest) { cbest = tfirst; cnode = node; }
                 }
 
@@ -819,150 +869,174 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 if (nhits == 0) {
                     terminal = true;  // nothing ahead: the ray vanishes silently (:681-682)
                 } else {
-                    const int hit = n1;
-                    const double t0 = t1;
-                    int container, adjacent;
+                    hit = n1;
+                    t0 = t1;
                     if (nhits == 1) { container = hit; adjacent = -1; }
                     else {
                         container = (cnode >= 0) ? cnode : hit;
                         adjacent = (container == hit) ? n2 : hit;
                     }
                     ev_container = container;
-
                     if (count > A.maxsteps) {  // (:716-723)
                         ev_kind = PVT_EV_KILL;
                         terminal = true;
                         t_sel = PVT_REC_KILLED; t_node = container;
                     } else {
-                        const double n_container = T.dv(container * ND + ND_N);
-                        if (hit == A.root) {  // leaves the scene (:728-744)
-                            pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
-                            travelled += t0;
-                            duration += div_known(t0 * n_container, kCcm, kRcpCcm);
-                            ev_kind = PVT_EV_EXIT; ev_hit = hit; ev_adjacent = adjacent;
-                            terminal = true;
-                            t_sel = PVT_REC_EXIT; t_node = hit; t_normal = true;
-                        } else {
-                            // ---- volume absorption (:746-760) ----------------
-                            const int cbase = T.iv(container * NI + NI_CSTART);
-                            const int ccount = T.iv(container * NI + NI_CCOUNT);
-                            // alpha = sum of the components' coefficients; the running partial
-                            // sums ARE the cumulative thresholds the reference recomputes when it
-                            // picks the absorbing component (:768-781), so keep the first four
-                            double alpha = 0.0, pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0;
-                            for (int k = 0; k < ccount; k++) {
-                                const int ci = L.comp_i + (cbase + k) * CI;
-                                alpha += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
-                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
-                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_RCP));
-                                if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
-                                else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
-                            }
-                            double depth = INFINITY;
-                            if (alpha > kAlphaZero) depth = ABL(5) ? rng_uniform(rng) / alpha : -pvt_log(1.0 - rng_uniform(rng)) / alpha;
-
-                            if (depth < t0) {  // absorbed (:762-832)
-                                pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
-                                travelled += depth;
-                                duration += div_known(depth * n_container, kCcm, kRcpCcm);
-                                const double target = rng_uniform(rng) * alpha;
-                                int comp = cbase;
-                                if (ccount <= 4) {
-                                    if (target <= pre0) comp = cbase;
-                                    else if (ccount > 1 && target <= pre1) comp = cbase + 1;
-                                    else if (ccount > 2 && target <= pre2) comp = cbase + 2;
-                                    else if (ccount > 3 && target <= pre3) comp = cbase + 3;
-                                } else {
-                                    double running = 0.0;
-                                    for (int k = 0; k < ccount; k++) {
-                                        const int ci = L.comp_i + (cbase + k) * CI;
-                                        running += interp_clamped(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N), T.iv(ci + CI_ABS_G),
-                                                                  T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
-                                                        T.dv(L.comp_d + (cbase + k) * CD + CD_ABS_RCP));
-                                        if (target <= running) { comp = cbase + k; break; }
-                                    }
-                                }
-                                log_row<RECORD>(A, base, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
-                                                dir, false, pos, wl, travelled, duration);
-                                const int ctype = T.iv(L.comp_i + comp * CI + CI_TYPE);
-                                ev_component = comp;
-                                bool radiative = false;
-                                if (ctype == PVT_COMP_SCATTERER || ctype == PVT_COMP_LUMINOPHORE)
-                                    radiative = rng_uniform(rng) < T.dv(L.comp_d + comp * CD + CD_QY);
-                                double tau = 0.0;
-                                if (radiative) {
-                                    // phase function (_kernel.pyx:455-476): only the DRAWS happen here, in the
-                                    // reference's order; acos / sincos run later at the sites shared with the
-                                    // surface lanes, and the new direction is written before the event is logged
-                                    const int pt = T.iv(L.comp_i + comp * CI + CI_PHASE);
-                                    const double pp = T.dv(L.comp_d + comp * CD + CD_PHASE);
-                                    if (pt == PVT_PHASE_HG && pvt_fabs(pp) >= kEps) {
-                                        double g1 = rng_uniform(rng);
-                                        double sg = 2.0 * g1 - 1.0;
-                                        double q = (1.0 - pp * pp) / (1.0 + pp * sg);
-                                        em_x = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
-                                        em_phi = 2.0 * kPi * rng_uniform(rng);
-                                        em_acos = true;
-                                    } else if (pt == PVT_PHASE_CONE) {
-                                        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-                                        em_x = pvt_asin(pvt_sqrt(g1) * pvt_sin(pp));  // theta itself
-                                        em_phi = 2.0 * kPi * g2;
-                                    } else {
-                                        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-                                        em_phi = 2.0 * kPi * g1;
-                                        em_x = 2.0 * g2 - 1.0;
-                                        em_acos = true;
-                                    }
-                                    em = true;
-                                    source = comp;
-                                    if (ctype == PVT_COMP_LUMINOPHORE) {
-                                        const int ci = L.comp_i + comp * CI;
-                                        const int ex = T.iv(ci + CI_EMS_X), ec = T.iv(ci + CI_EMS_CDF), en = T.iv(ci + CI_EMS_N);
-                                        double p1;
-                                        if (A.emit_method == PVT_EMIT_FULL) {
-                                            p1 = 0.0;
-                                        } else {
-                                            double e_nm = wl;
-                                            if (A.emit_method == PVT_EMIT_KT) {
-                                                const double kb_ev = 1.380649e-23 / 1.60217662e-19;
-                                                double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
-                                                e_nm = 1240.0 / e_ev;
-                                            }
-                                            p1 = ABL(2) ? 0.3 : interp_clamped(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_X), T.iv(ci + CI_EMS_HIST), T.dv(L.comp_d + comp * CD + CD_EMS_RCP_X));
-                                        }
-                                        double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
-                                        wl = ABL(2) ? 600.0 + 50.0 * gamma : interp_clamped(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(L.comp_d + comp * CD + CD_EMS_SCALE_C), T.iv(ci + CI_EMS_HIST), T.dv(L.comp_d + comp * CD + CD_EMS_RCP_C));
-                                        tau = T.dv(L.comp_d + comp * CD + CD_TAU_RAD);
-                                        ev_kind = PVT_EV_EMIT;
-                                    } else {
-                                        ev_kind = PVT_EV_SCATTER;
-                                    }
-                                } else {
-                                    tau = T.dv(L.comp_d + comp * CD + CD_TAU_NR);
-                                    if (ctype == PVT_COMP_REACTOR) { ev_kind = PVT_EV_REACT; t_sel = PVT_REC_REACTED; }
-                                    else { ev_kind = PVT_EV_NONRADIATIVE; t_sel = PVT_REC_LOST; }
-                                    t_node = container;
-                                    terminal = true;
-                                }
-                                // radiative / non-radiative lifetime: the last draw of either branch
-                                if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
-                            } else {
-                                // ---- surface interaction (:834-895) ---------
-                                pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
-                                travelled += t0;
-                                duration += div_known(t0 * n_container, kCcm, kRcpCcm);
-                                ev_hit = hit;
-                                if (adjacent < 0) {  // malformed scene (:840-845)
-                                    ev_kind = PVT_EV_KILL;
-                                    terminal = true;
-                                } else {
-                                    ev_adjacent = adjacent;
-                                    t_node = hit; t_normal = true; ev_normal = true;
-                                }
-                            }
-                        }
+                        pend = true;
                     }
                 }
+            }
+        }
+        // ---- container properties + volume absorption coefficient (:746-760) -----------------------
+        // The container takes few distinct values across a wave (two in a one-slab scene), so the
+        // wave walks them: node and component records then come through the scalar cache as SGPR
+        // operands instead of chains of dependent per-lane LDS reads.
+        // alpha = sum of the components' coefficients; the running partial sums ARE the cumulative
+        // thresholds the reference recomputes when it picks the absorbing component (:768-781), so
+        // keep the first four
+        double alpha = 0.0, pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0, n_container = 1.0;
+        int cbase = 0, ccount = 0;
+        if (pend) {
+            n_container = T.dv(container * ND + ND_N);
+            cbase = T.iv(container * NI + NI_CSTART); ccount = T.iv(container * NI + NI_CCOUNT);
+            if (hit != A.root) {
+                for (int k = 0; k < ccount; k++) {
+                    const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
+                    alpha += interp_clamped<TAB_LDS, false>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
+                                                            T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
+                                                            T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
+                    if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
+                    else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
+                }
+            }
+        }
+        int comp = -1;
+        if (pend) {
+            if (hit == A.root) {  // leaves the scene (:728-744)
+                pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
+                travelled += t0;
+                duration += div_known(t0 * n_container, kCcm, kRcpCcm);
+                ev_kind = PVT_EV_EXIT; ev_hit = hit; ev_adjacent = adjacent;
+                terminal = true;
+                t_sel = PVT_REC_EXIT; t_node = hit; t_normal = true;
+                cls = CLS_EXIT;
+            } else {
+                double depth = INFINITY;
+                if (alpha > kAlphaZero) depth = ABL(5) ? rng_uniform(rng) / alpha : -pvt_log(1.0 - rng_uniform(rng)) / alpha;
+                if (depth < t0) {  // absorbed (:762-832)
+                    pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
+                    travelled += depth;
+                    duration += div_known(depth * n_container, kCcm, kRcpCcm);
+                    const double target = rng_uniform(rng) * alpha;
+                    comp = cbase;
+                    if (ccount <= 4) {
+                        if (target <= pre0) comp = cbase;
+                        else if (ccount > 1 && target <= pre1) comp = cbase + 1;
+                        else if (ccount > 2 && target <= pre2) comp = cbase + 2;
+                        else if (ccount > 3 && target <= pre3) comp = cbase + 3;
+                    } else {
+                        double running = 0.0;
+                        for (int k = 0; k < ccount; k++) {
+                            const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
+                            running += interp_clamped<TAB_LDS, false>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
+                                                                      T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
+                                                                      T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
+                            if (target <= running) { comp = cbase + k; break; }
+                        }
+                    }
+                    log_row<RECORD>(A, base, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
+                                    dir, false, pos, wl, travelled, duration);
+                    ev_component = comp;
+                    cls = CLS_ABS;
+                } else {
+                    // ---- surface interaction (:834-895) ---------
+                    pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
+                    travelled += t0;
+                    duration += div_known(t0 * n_container, kCcm, kRcpCcm);
+                    ev_hit = hit;
+                    if (adjacent < 0) {  // malformed scene (:840-845)
+                        ev_kind = PVT_EV_KILL;
+                        terminal = true;
+                    } else {
+                        ev_adjacent = adjacent;
+                        t_node = hit; t_normal = true; ev_normal = true;
+                        cls = CLS_SURF;
+                    }
+                }
+            }
+        }
+        // ---- the absorbing component decides (:783-832): one pass per distinct component of the wave,
+        // its record in SGPRs
+        {
+            const int cu = comp;
+            const bool mine = cls == CLS_ABS;
+            const int ci = L.comp_i + cu * CI, cd = L.comp_d + cu * CD;
+            const int ctype = T.iv(ci + CI_TYPE);
+            if (mine) {
+                bool radiative = false;
+                if (ctype == PVT_COMP_SCATTERER || ctype == PVT_COMP_LUMINOPHORE)
+                    radiative = rng_uniform(rng) < T.dv(cd + CD_QY);
+                double tau = 0.0;
+                if (radiative) {
+                    // phase function (_kernel.pyx:455-476): only the DRAWS happen here, in the
+                    // reference's order; acos / sincos run later at the sites shared with the
+                    // surface lanes, and the new direction is written before the event is logged
+                    const int pt = T.iv(ci + CI_PHASE);
+                    const double pp = T.dv(cd + CD_PHASE);
+                    if (pt == PVT_PHASE_HG && pvt_fabs(pp) >= kEps) {
+                        double g1 = rng_uniform(rng);
+                        double sg = 2.0 * g1 - 1.0;
+                        double q = (1.0 - pp * pp) / (1.0 + pp * sg);
+                        em_x = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
+                        em_phi = 2.0 * kPi * rng_uniform(rng);
+                        em_acos = true;
+                    } else if (pt == PVT_PHASE_CONE) {
+                        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+                        em_x = pvt_asin(pvt_sqrt(g1) * pvt_sin(pp));  // theta itself
+                        em_phi = 2.0 * kPi * g2;
+                    } else {
+                        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+                        em_phi = 2.0 * kPi * g1;
+                        em_x = 2.0 * g2 - 1.0;
+                        em_acos = true;
+                    }
+                    em = true;
+                    source = cu;
+                    if (ctype == PVT_COMP_LUMINOPHORE) {
+                        const int ex = T.iv(ci + CI_EMS_X), ec = T.iv(ci + CI_EMS_CDF), en = T.iv(ci + CI_EMS_N);
+                        const int eh = T.iv(ci + CI_EMS_HIST);
+                        const double ew = T.dv(cd + CD_EMS_W);
+                        double p1;
+                        if (A.emit_method == PVT_EMIT_FULL) {
+                            p1 = 0.0;
+                        } else {
+                            double e_nm = wl;
+                            if (A.emit_method == PVT_EMIT_KT) {
+                                const double kb_ev = 1.380649e-23 / 1.60217662e-19;
+                                double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
+                                e_nm = 1240.0 / e_ev;
+                            }
+                            p1 = ABL(2) ? 0.3 : interp_clamped<TAB_LDS, false>(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(cd + CD_EMS_SCALE_X),
+                                                                              eh, T.dv(cd + CD_EMS_RCP_X), ew);
+                        }
+                        double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
+                        wl = ABL(2) ? 600.0 + 50.0 * gamma
+                                    : interp_clamped<TAB_LDS, false>(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(cd + CD_EMS_SCALE_C), eh,
+                                                                    T.dv(cd + CD_EMS_RCP_C), __builtin_nan(""), eh ? __builtin_nan("") : ew);
+                        tau = T.dv(cd + CD_TAU_RAD);
+                        ev_kind = PVT_EV_EMIT;
+                    } else {
+                        ev_kind = PVT_EV_SCATTER;
+                    }
+                } else {
+                    tau = T.dv(cd + CD_TAU_NR);
+                    if (ctype == PVT_COMP_REACTOR) { ev_kind = PVT_EV_REACT; t_sel = PVT_REC_REACTED; }
+                    else { ev_kind = PVT_EV_NONRADIATIVE; t_sel = PVT_REC_LOST; }
+                    t_node = container;
+                    terminal = true;
+                }
+                // radiative / non-radiative lifetime: the last draw of either branch
+                if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
             }
         }
 
@@ -978,15 +1052,18 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         // Both are pure functions of (t_node, pos, tri1), so the coating / Lambertian code and the
         // x,y,z histogram axes RECOMPUTE them where needed (same arithmetic, same bits) instead of
         // keeping 12 VGPRs alive across the transcendental sites, the register-pressure peak.
-        auto local_point = [&]() -> V3 {
-            const int m = t_node * ND + ND_W2L;
-            return V3{T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(m + 3),
-                      T.dv(m + 4) * pos.x + T.dv(m + 5) * pos.y + T.dv(m + 6) * pos.z + T.dv(m + 7),
-                      T.dv(m + 8) * pos.x + T.dv(m + 9) * pos.y + T.dv(m + 10) * pos.z + T.dv(m + 11)};
+        // (UNI: the node index is wave-uniform -> its record comes through the scalar cache)
+        auto local_point_of = [&](auto uni, int node) -> V3 {
+            const int m = node * ND + ND_W2L;
+            auto rd = [&](int i) { return decltype(uni)::value ? T.du(i) : T.dv(i); };
+            return V3{rd(m + 0) * pos.x + rd(m + 1) * pos.y + rd(m + 2) * pos.z + rd(m + 3),
+                      rd(m + 4) * pos.x + rd(m + 5) * pos.y + rd(m + 6) * pos.z + rd(m + 7),
+                      rd(m + 8) * pos.x + rd(m + 9) * pos.y + rd(m + 10) * pos.z + rd(m + 11)};
         };
-        auto local_normal = [&](const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
-            const int gp = t_node * ND + ND_PARAMS;
-            const int gt = T.iv(t_node * NI + NI_GEOM);
+        auto local_normal_of = [&](auto uni, int node, const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
+            auto rd = [&](int i) { return decltype(uni)::value ? T.du(i) : T.dv(i); };
+            const int gp = node * ND + ND_PARAMS;
+            const int gt = decltype(uni)::value ? T.iu(node * NI + NI_GEOM) : T.iv(node * NI + NI_GEOM);
             if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
                 const pvt::MeshTri* tr = A.tris + tri1;
                 return V3{tr->n[0], tr->n[1], tr->n[2]};
@@ -998,7 +1075,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 const double pp[3] = {lp.x, lp.y, lp.z};
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    double hs = 0.5 * T.dv(gp + a);
+                    double hs = 0.5 * rd(gp + a);
                     double dm = pvt_fabs(pp[a] - (-1.0) * hs);
                     if (dm < best) { best = dm; baxis = a; bsign = -1.0; }
                     double dp = pvt_fabs(pp[a] - hs);
@@ -1010,13 +1087,17 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                 double mag = pvt_sqrt(dot3(lp, lp));
                 return V3{lp.x / mag, lp.y / mag, lp.z / mag};
             }
-            double half = 0.5 * T.dv(gp);
+            double half = 0.5 * rd(gp);
             double tol = 1e-8 + 1e-5 * pvt_fabs(half);
             if (pvt_fabs(lp.z + half) <= tol) return V3{0.0, 0.0, -1.0};
             if (pvt_fabs(lp.z - half) <= tol) return V3{0.0, 0.0, 1.0};
             double r = pvt_sqrt(lp.x * lp.x + lp.y * lp.y);
             return V3{lp.x / r, lp.y / r, 0.0};
         };
+        auto local_point = [&]() -> V3 { return local_point_of(std::false_type{}, t_node); };
+        auto local_normal = [&](const V3& lp) -> V3 { return local_normal_of(std::false_type{}, t_node, lp); };
+        // one pass per distinct node of the wave's surface / exit lanes: matrices and shape in SGPRs,
+        // and the shape switch is wave-uniform
         if (alive && t_normal) {
             const V3 nloc = local_normal(local_point());
             const int q = t_node * ND + ND_L2W;

@@ -28,6 +28,8 @@ if __name__ == "__main__":
     if which == "lsc":
         for n in (1_000_000, 4_000_000):
             probe("lsc_equivalent", scenes.lsc_equivalent(), n)
+    elif which == "one":
+        probe("lsc_equivalent", scenes.lsc_equivalent(), 4_000_000, reps=4)
     elif which == "mesh":
         import pvtrace_amd as pv
         probe("mesh_lsc (12 tri)", scenes.mesh_lsc(), 1_000_000)
