@@ -51,28 +51,36 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(compiled, pos, dirs, wl, budget_s=12.0):
-    """Time the CPU referee (kind 'port') with all host cores on a bounded sample:
-    repeated 10^6-photon bundles of the same workload (fresh RNG streams each) until
-    about `budget_s` seconds of wall time have been spent."""
+def cpu_baseline(compiled, pos, dirs, wl, budget_s=(9.0, 6.0)):
+    """Time the CPU referee (kind 'port': oracle/pvt_oracle.c, built -O3 -fopenmp like the reference's
+    own kernel, pvtrace/engine/build.py:34) on a bounded sample of the same workload, with all usable
+    host cores and with ONE thread, as the reference's harness does (benchmarks/benchmark_engine.py:121-124):
+    repeated bundles (fresh RNG streams each) until about `budget_s` seconds have been spent per leg."""
     from oracle import oracle as O
 
     cores = usable_cores()
     n = pos.shape[0]
     O.trace_bundle(compiled, pos[:20000], dirs[:20000], wl[:20000], 1, 1000, 128, 0, cores, 0)  # warm
-    photons, bundles = 0, 0
-    tic = time.perf_counter()
-    while True:
-        O.trace_bundle(compiled, pos, dirs, wl, 1 + bundles * n, 1000, 128, 0, cores, 0)
-        photons += n
-        bundles += 1
-        elapsed = time.perf_counter() - tic
-        if elapsed >= budget_s or bundles >= 400:
-            break
+
+    def leg(threads, m, budget):
+        photons, bundles = 0, 0
+        tic = time.perf_counter()
+        while True:
+            O.trace_bundle(compiled, pos[:m], dirs[:m], wl[:m], 1 + bundles * m, 1000, 128, 0, threads, 0)
+            photons += m
+            bundles += 1
+            elapsed = time.perf_counter() - tic
+            if elapsed >= budget or bundles >= 400:
+                return photons / elapsed, bundles, elapsed
+
+    v_all, b_all, t_all = leg(cores, n, budget_s[0])
+    m1 = min(n, 250_000)
+    v_one, b_one, t_one = leg(1, m1, budget_s[1])
     return {
-        "value": photons / elapsed, "unit": "photons/s", "cores": cores, "kind": "port",
-        "sample": f"{bundles} bundles x {n} photons of the same workload, oracle/pvt_oracle.c "
-                  f"(libm mode, OpenMP {cores} threads, tally mode), {elapsed:.2f} s",
+        "value": v_all, "unit": "photons/s", "cores": cores, "kind": "port", "value_1thread": v_one,
+        "sample": f"{b_all} bundles x {n} photons of the same workload on {cores} OpenMP threads ({t_all:.2f} s), then "
+                  f"{b_one} bundles x {m1} photons on 1 thread ({t_one:.2f} s); oracle/pvt_oracle.c, libm mode, "
+                  f"tally mode, gcc -O3 -fopenmp",
     }
 
 
@@ -85,6 +93,18 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="bundles kept in flight (HIP streams); 1 = strictly serial launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup-s", type=float, default=0.3,
+                    help="untimed seconds of the same workload before the warm-up steps (GPU clock ramp)")
+    ap.add_argument("--ray-buffers", type=int, default=7,
+                    help="distinct resident ray sets the steps rotate through (7 x 56 MB = 392 MB: past the "
+                         "256 MiB Infinity Cache, so the ray stream of a step comes from HBM)")
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="extra, independent timed windows of --steps steps after the headline one (spread estimate)")
+    ap.add_argument("--sustained-s", type=float, default=1.2,
+                    help="length of the sustained leg (back-to-back bundles) in seconds of GPU work; 0 = skip")
+    ap.add_argument("--total-photons", type=int, default=100_000_000,
+                    help="strong-scaling leg (BASELINE configs[2]): ONE job of this many photons split over the "
+                         "ranks by index range, tallies all-reduced once; 0 = skip")
     ap.add_argument("--reduce", choices=("end", "bundle"), default="end",
                     help="multi-GPU: all-reduce the tallies once per job, inside the timed region "
                          "(default), or after every bundle")
@@ -127,9 +147,16 @@ def main():
     n = args.photons
     scene = scenes.lsc_equivalent()
     compiled = compile_scene(scene)
-    # each rank's shard: global indices [rank*n, (rank+1)*n); emission seeded per shard
-    pos, dirs, wl, _ = emit_bundle(scene, n, seed=1000 + rank)
-    rays = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (pos, dirs, wl))
+    # each rank's shard: global indices [rank*n, (rank+1)*n); emission seeded per shard and per buffer.
+    # The steps rotate through `--ray-buffers` distinct ray sets so that a step's input does not sit in
+    # the Infinity Cache from the previous step.
+    nbuf = max(1, args.ray_buffers)
+    ray_sets = []
+    for b in range(nbuf):
+        p_, d_, w_, _ = emit_bundle(scene, n, seed=1000 + rank + 7919 * b)
+        if b == 0:
+            pos, dirs, wl = p_, d_, w_
+        ray_sets.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (p_, d_, w_)))
     dscene = native.DeviceScene(compiled, device=local_rank)
     # Steps are independent bundles; like any streaming consumer of the engine they go
     # through the product's BundlePipeline (engine/pipeline.py): bundle k+1 is enqueued on a
@@ -139,7 +166,7 @@ def main():
     pipe.wait_for_inputs()
 
     def step(k, timed):
-        pipe.submit(rays, n, seed=12345 + k * world * n, ray_offset=rank * n, maxsteps=1000,
+        pipe.submit(ray_sets[k % nbuf], n, seed=12345 + k * world * n, ray_offset=rank * n, maxsteps=1000,
                     max_events=128, emit_method=0, timed=timed)
 
     def fence():
@@ -148,6 +175,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Clocks: an idle MI355X needs tens of milliseconds of work to reach its sustained clocks, far more
+    # than `--warmup` steps of ~0.5 ms provide; spin the same path up first (untimed, not counted).
+    t_spin = time.perf_counter()
+    k_spin = 0
+    while time.perf_counter() - t_spin < args.spinup_s:
+        for _ in range(20):
+            step(1_000_000 + k_spin, False)
+            k_spin += 1
+        pipe.synchronize()
     for k in range(args.warmup):
         step(k, True)      # same path as the timed steps (events included); reset below
     pipe.reduce_totals()   # also warms the RCCL communicator up (its first collective is slow)
@@ -166,6 +202,67 @@ def main():
     kernel_ms = pipe.kernel_ms()
     mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     totals = pipe.totals_host()
+
+    def window(first_step, steps, timed_events=False):
+        """One more independent window of `steps` steps, fenced like the headline one -> seconds (max over ranks)."""
+        pipe.reset_totals()
+        fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(first_step + k, timed_events)
+        pipe.reduce_totals()
+        fence()
+        dt = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    next_step = args.warmup + args.steps
+    repeat_values = []
+    for r in range(max(0, args.repeats)):
+        dt = window(next_step, args.steps)
+        next_step += args.steps
+        repeat_values.append(n * world * args.steps / dt)
+    sustained = None
+    if args.sustained_s > 0:
+        est = elapsed / args.steps                      # seconds per step, from the headline window
+        sus_steps = max(args.steps, int(args.sustained_s / est))
+        dt = window(next_step, sus_steps)
+        next_step += sus_steps
+        sustained = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt,
+                     "value": n * world * sus_steps / dt}
+    strong = None
+    if args.total_photons > 0:
+        # BASELINE configs[2]: ONE job of `total` photons, rank r traces the index range
+        # [r*total/world, (r+1)*total/world) in bundles of n (ray seed = seed + global index), the tallies
+        # are all-reduced once at the end; time = barrier to barrier, max over ranks
+        from pvtrace_amd.engine.distributed import shard_range
+
+        lo, hi = shard_range(args.total_photons, rank, world)
+        pipe.reset_totals()
+        fence()
+        t0 = time.perf_counter()
+        at, k = lo, 0
+        while at < hi:
+            m = min(n, hi - at)
+            pipe.submit(tuple(t[:m] for t in ray_sets[k % nbuf]), m, seed=777, ray_offset=at, maxsteps=1000,
+                        max_events=128, emit_method=0, timed=False)
+            at += m
+            k += 1
+        pipe.reduce_totals()
+        fence()
+        dt = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        st = pipe.totals_host()
+        strong = {"scaling": "strong", "total_photons": args.total_photons, "seconds": dt,
+                  "value": args.total_photons / dt,
+                  "photons_tallied": int(st["rec_distinct"][list(compiled.recorder_names).index("entering")]
+                                         + st["rec_distinct"][list(compiled.recorder_names).index("reflected")])}
 
     if rank == 0:
         total_photons = n * world * args.steps
@@ -219,7 +316,8 @@ def main():
                 "sharding": (f"index-range x{world}, tallies {'RCCL' if os.environ.get('PVT_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['PVT_BENCH_BACKEND']} all-reduce "
                              + ("once per job, inside the timed region" if args.reduce == "end" else "per step")) if distributed
                             else "single GPU",
-                "input": "rays resident in HBM (array-input mode, 56 B/photon)",
+                "input": f"rays resident in HBM (array-input mode, 56 B/photon), steps rotate through {nbuf} distinct "
+                         f"ray sets ({nbuf * 56 * n / 1e6:.0f} MB)",
                 "bundles_in_flight": args.streams,
             },
             "roofline": {
@@ -238,6 +336,14 @@ def main():
             "launch": dscene.launch_info(),
             "tallies": fractions,
         }
+        if repeat_values:
+            rv = sorted(repeat_values + [value])
+            out["repeats"] = {"windows": len(rv), "steps_each": args.steps, "min": rv[0], "median": rv[len(rv) // 2],
+                              "max": rv[-1], "spread": (rv[-1] - rv[0]) / rv[len(rv) // 2]}
+        if sustained is not None:
+            out["sustained"] = sustained
+        if strong is not None:
+            out["strong_scaling"] = strong
         if not args.no_cpu_baseline and world == 1:   # the CPU referee is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(compiled, pos, dirs, wl)
         print(json.dumps(out))

@@ -86,6 +86,8 @@ struct PvtScene {
     int num_cu = 0;
     int last_grid = 0, last_lds = 0;
     size_t lds_limit = 0;
+    bool consolidate = true;        // developer switches (environment), read once at scene creation
+    double dev_blocks_per_cu = 0.0;
 };
 
 extern "C" {
@@ -347,6 +349,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     s->num_cu = prop.multiProcessorCount;
     s->lds_limit = prop.sharedMemPerBlock;
+    s->consolidate = getenv("PVT_NO_CONSOLIDATE") == nullptr;
+    if (const char* env = getenv("PVT_BLOCKS_PER_CU")) s->dev_blocks_per_cu = atof(env);
     HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
     HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
@@ -517,32 +521,31 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     a.cursor = reinterpret_cast<unsigned int*>(g_stats);  // dev build: counters live in their own buffer
 #endif
 
-    // LDS budget: tables (if they fit) + recorder accumulators (+ bins if they fit)
-    const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 2 * 4);
+    // LDS budget: recorder accumulators + control words, tables if they fit, bins if they fit, then the
+    // drain-phase consolidation buffer (kXSlots photon states, also the seed pools) within 40 KB
+    const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 8) + (size_t)((s->n_rec + 1) & ~1) * 4 + CTL_WORDS * 4;
     const size_t tab_bytes = (size_t)s->nd * 8 + (size_t)((s->ni + 1) & ~1) * 4;
-    const size_t bins_bytes = (size_t)s->total_bins * 4;
+    const size_t bins_bytes = ((size_t)s->total_bins * 4 + 7) & ~(size_t)7;
     const size_t budget = 64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit;  // keep >= 2 workgroups per CU
-    bool tab_lds = acc_bytes + tab_bytes <= budget;
+    if (acc_bytes > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
+    const bool tab_lds = acc_bytes + tab_bytes <= budget;
     size_t lds = acc_bytes + (tab_lds ? tab_bytes : 0);
     a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
-    if (a.bins_in_lds) lds += (bins_bytes + 7) & ~(size_t)7;
-    lds += CTL_WORDS * 4;
-    // drain-phase consolidation buffer: kXSlots photon states (also the seed pools), within 40 KB
+    if (a.bins_in_lds) lds += bins_bytes;
     const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 3 : 0);
     const size_t xbytes = (size_t)kXSlots * xw * 8;
     a.xslots = 0;
-    if (!getenv("PVT_NO_CONSOLIDATE") && lds + xbytes <= 40 * 1024) {
+    if (s->consolidate && lds + xbytes <= 40 * 1024 && lds + xbytes <= s->lds_limit) {
         a.xslots = kXSlots;
         lds += xbytes;
     }
-    if (lds > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
     lds = (lds + 15) & ~(size_t)15;
 
     // persistent grid: enough workgroups to fill every CU a few times over,
     // never more than the rays can feed
     long long blocks_for_rays = (p->n_rays + kBlock - 1) / kBlock;
     double per_cu = p->workgroups_per_cu > 0 ? (double)p->workgroups_per_cu : 4.0;
-    if (const char* env = getenv("PVT_BLOCKS_PER_CU")) per_cu = atof(env) > 0 ? atof(env) : per_cu;   // dev override
+    if (s->dev_blocks_per_cu > 0) per_cu = s->dev_blocks_per_cu;   // developer override, read once per scene
     long long grid = (long long)((double)s->num_cu * per_cu);
     if (grid > blocks_for_rays) grid = blocks_for_rays;
     if (grid < 1) grid = 1;

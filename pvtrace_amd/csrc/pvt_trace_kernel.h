@@ -409,7 +409,7 @@ __device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev
 }
 
 // LDS accumulator layout (per workgroup), after the table copies:
-//   u32 cross[n_rec] | u32 distinct[n_rec] | f64 sums[n_rec*8] | u32 bins[total_bins] (if they fit)
+//   f64 sums[n_rec*8] | u64 cross[n_rec] | u32 distinct[n_rec] | u32 bins[total_bins] (if they fit)
 struct Accum {
     unsigned int* cross;
     unsigned int* distinct;
@@ -437,9 +437,11 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     int ni_lds = TAB_LDS ? ((A.ni + 1) & ~1) : 0;  // keep 8-byte alignment after the ints
     int* lds_i = reinterpret_cast<int*>(lds_d + nd_lds);
     double* acc_sums = reinterpret_cast<double*>(lds_i + ni_lds);
-    unsigned int* acc_cross = reinterpret_cast<unsigned int*>(acc_sums + A.n_rec * 8);
-    unsigned int* acc_distinct = acc_cross + A.n_rec;
-    unsigned int* acc_bins = acc_distinct + A.n_rec;
+    // crossings are 64-bit: a trapped photon crosses surfaces up to `maxsteps` times, and a persistent
+    // workgroup of a 2^31-photon launch sees millions of photons (distinct rays and bins are bounded by them)
+    unsigned long long* acc_cross = reinterpret_cast<unsigned long long*>(acc_sums + A.n_rec * 8);
+    unsigned int* acc_distinct = reinterpret_cast<unsigned int*>(acc_cross + A.n_rec);
+    unsigned int* acc_bins = acc_distinct + ((A.n_rec + 1) & ~1);   // (keeps what follows 8-byte aligned)
     int* ctl = reinterpret_cast<int*>(acc_bins + ((A.bins_in_lds ? A.total_bins : 0) + 1 & ~1));
     unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [14 + SEENW (+3 when RECORD)][xslots] u64 words
     if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
         for (int i = threadIdx.x; i < A.ni; i += kBlock) lds_i[i] = A.gi[i];
     }
     for (int i = threadIdx.x; i < A.n_rec * 8; i += kBlock) acc_sums[i] = 0.0;
-    for (int i = threadIdx.x; i < A.n_rec * 2; i += kBlock) acc_cross[i] = 0u;
+    for (int i = threadIdx.x; i < A.n_rec; i += kBlock) { acc_cross[i] = 0ull; acc_distinct[i] = 0u; }
     if (A.bins_in_lds)
         for (int i = threadIdx.x; i < A.total_bins; i += kBlock) acc_bins[i] = 0u;
     __syncthreads();
@@ -1288,7 +1290,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                         else if (pvt_fabs(T.dv(rd + RD_FACET + 2) - nrm.z) > atol) match = false;
                     }
                     if (match) {
-                        atomicAdd(&acc_cross[r], 1u);
+                        atomicAdd(&acc_cross[r], 1ull);
                         const unsigned long long bit = 1ull << (r & 63);
                         bool first;
                         if constexpr (SEENW == 1) {
@@ -1371,8 +1373,9 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     if (order != kWaves - 1) return;
     __threadfence_block();
     for (int i = lane; i < A.n_rec; i += 64) {
-        unsigned int c = acc_cross[i], d = acc_distinct[i];
-        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_crossings) + i, (unsigned long long)c);
+        const unsigned long long c = acc_cross[i];
+        const unsigned int d = acc_distinct[i];
+        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_crossings) + i, c);
         if (d) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_distinct) + i, (unsigned long long)d);
     }
     for (int i = lane; i < A.n_rec * 8; i += 64) {

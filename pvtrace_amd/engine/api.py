@@ -173,6 +173,20 @@ class EngineResult:
             yield steps
 
 
+_WORKERS_WARNED = False
+
+
+def _warn_workers(workers):
+    """`workers` meant CPU threads in the reference (api.py:201); nothing here runs on CPU threads."""
+    global _WORKERS_WARNED
+    if workers not in (None, 0, 1) and not _WORKERS_WARNED:
+        import warnings
+
+        _WORKERS_WARNED = True
+        warnings.warn("pvtrace_amd.engine: `workers` is accepted for compatibility and ignored "
+                      "(the trace runs on the GPU; results never depended on it).", stacklevel=3)
+
+
 def _default_device():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -383,6 +397,7 @@ def simulate(
         raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
     if seed is None:
         seed = np.random.randint(0, 2 ** 31 - 1)
+    _warn_workers(workers)
     with Session(scene, device=device, emission=emission) as session:
         return session.run(num_rays, seed, maxsteps=maxsteps, max_events=max_events,
                            emit_method=emit_method, record_every=record_every,
@@ -399,7 +414,8 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
     if seed is None:
         seed = np.random.randint(0, 2 ** 31 - 1)
     emit_seed = kwargs.pop("emit_seed", None)
-    kwargs.pop("workers", None)
+    _warn_workers(kwargs.pop("workers", None))
+    base_offset = int(kwargs.pop("ray_offset", 0))   # global index of the stream's first ray (sharded jobs)
     session = Session(scene, device=kwargs.pop("device", None), emission=kwargs.pop("emission", "auto"))
     if session.emission == "device" and emit_seed is None:
         emit_seed = np.random.randint(0, 2 ** 31 - 1)
@@ -408,10 +424,11 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
         if session.emission == "device":
             # one emission stream for the whole job: ray i of the job is the same photon
             # whatever the bundle size
-            return session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=traced,
+            return session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=base_offset + traced,
                                   workgroups_per_cu=3, **kwargs), n     # two bundles in flight
         bundle_emit_seed = None if emit_seed is None else int(emit_seed) + traced
-        return session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, workgroups_per_cu=3, **kwargs), n
+        return session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, ray_offset=base_offset,
+                              workgroups_per_cu=3, **kwargs), n
 
     traced = 0
     try:

@@ -365,6 +365,13 @@ class CompiledScene:
                 elif src == "components":
                     self.rec_source_mode[r] = SOURCE_COMPONENTS
                 elif src in self.component_names:
+                    if self.component_names.count(src) > 1:
+                        # the filter is one component id; the reference's dataframe filter by name
+                        # would match every component of that name
+                        raise UnsupportedSceneError(
+                            f"Recorder {recorder.name!r}: source {src!r} names "
+                            f"{self.component_names.count(src)} components; give them distinct names."
+                        )
                     self.rec_source_mode[r] = SOURCE_COMPONENT
                     self.rec_source_id[r] = self.component_names.index(src)
                 else:

@@ -41,6 +41,7 @@ class BundlePipeline:
         self.totals = [dscene.new_tallies() for _ in range(self.depth)]
         self.events = []       # (start, stop) HIP events of every trace launch
         self.submitted = 0
+        self.wait_for_inputs()   # the zero-fills above ran on the current stream
 
     def submit(self, rays, n_rays, seed, ray_offset=0, emit_seed=0, maxsteps=1000, max_events=128,
                emit_method=0, timed=True):
@@ -92,6 +93,7 @@ class BundlePipeline:
             t["_sums"].zero_()
         self.events = []
         self._reduced = False
+        self.wait_for_inputs()   # the zero-fills ran on the current stream
 
     def reduce_totals(self):
         """Fold the per-stream totals into one buffer and, for a distributed job in

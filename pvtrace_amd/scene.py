@@ -250,12 +250,13 @@ class Scene(object):
         crossings = [x.to(self.root) for x in self.root.intersections(ray_origin, ray_direction)]
         return tuple(sorted(crossings, key=lambda x: x.distance))
 
-    def simulate(self, num_rays, seed=None, **kwargs):
-        """Trace on the MI355X engine; returns an `EngineResult`.
+    def simulate(self, num_rays, workers=None, seed=None, **kwargs):
+        """Trace on the MI355X engine; returns an `EngineResult`.  Positional order as in the
+        reference (num_rays, workers, seed); `workers` is accepted and ignored (no CPU tracing threads).
 
         (The reference's Scene.simulate, pvtrace/scene/scene.py:197-313, fans the
         Python tracer over a process pool; here the device engine is the tracer.)
         """
         from pvtrace_amd import engine
 
-        return engine.simulate(self, num_rays, seed=seed, **kwargs)
+        return engine.simulate(self, num_rays, seed=seed, workers=workers, **kwargs)
