@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 5
+#define PVT_ABI_VERSION 6
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -240,6 +240,25 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
                      const PvtRays* rays, const PvtTraceParams* params,
                      const PvtTallies* tallies, const PvtEventLog* log, int device,
                      double* kernel_ms);
+
+/* In-process multi-GPU form of pvt_trace_bundle: the bundle is split over
+ * `devices[0 .. n_devices)` by contiguous index range — shard g traces the global indices
+ * pvt_shard_range(n_rays, g, n_devices, record_every) with ray_offset advanced accordingly, so every ray
+ * keeps the RNG stream seed + ray_offset + global index and the result does not depend on the device
+ * list.  One host thread, one resident scene and one stream per entry of `devices` (an id may appear
+ * several times: its shards then share that GPU).  Integer tallies are summed exactly, the f64 moment
+ * sums in shard order; each shard writes the rows of its own rays into the caller's event log (inner shard
+ * boundaries are multiples of record_every, so the shards' logs together ARE the single-device log).
+ * `kernel_ms` (nullable) receives the longest shard's kernel time.  The reference splits a bundle over
+ * OpenMP threads instead (_kernel.pyx:1074-1095); there as here the output is independent of the split. */
+int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables* emitter,
+                           const PvtRays* rays, const PvtTraceParams* params,
+                           const PvtTallies* tallies, const PvtEventLog* log,
+                           const int* devices, int n_devices, double* kernel_ms);
+
+/* [start, stop) of shard `shard` of `n_shards` over n_rays rays; inner boundaries are rounded down to
+ * multiples of `align` (pass record_every; <= 1 means no alignment).  Pure host arithmetic. */
+int pvt_shard_range(int64_t n_rays, int shard, int n_shards, int64_t align, int64_t* start, int64_t* stop);
 
 /* Device emission only (fills caller-owned DEVICE arrays); used by tests. */
 int pvt_emit_device(PvtScene* scene, const PvtTraceParams* params, double* position,

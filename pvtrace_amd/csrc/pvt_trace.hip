@@ -33,6 +33,7 @@
 #include <atomic>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <mutex>
 #include <vector>
 
@@ -769,6 +770,85 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
         HIP_TRY(hipMemcpy(log->travelled, dl.travelled, rows * 8, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(log->duration, dl.duration, rows * 8, hipMemcpyDeviceToHost));
     }
+    return PVT_OK;
+}
+
+int pvt_shard_range(int64_t n_rays, int shard, int n_shards, int64_t align, int64_t* start, int64_t* stop) {
+    if (n_rays < 0 || n_shards <= 0 || shard < 0 || shard >= n_shards || !start || !stop)
+        return fail(PVT_ERR_INVALID, "bad shard arguments");
+    if (align < 1) align = 1;
+    auto edge = [&](int r) -> int64_t {
+        if (r <= 0) return 0;
+        if (r >= n_shards) return n_rays;
+        // n_rays * r fits: n_rays < 2^31 per bundle in practice, and __int128 keeps the general case exact
+        const int64_t e = (int64_t)(((__int128)n_rays * r) / n_shards);
+        return (e / align) * align;
+    };
+    *start = edge(shard);
+    *stop = edge(shard + 1);
+    return PVT_OK;
+}
+
+int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables* emitter, const PvtRays* rays,
+                           const PvtTraceParams* p, const PvtTallies* tl, const PvtEventLog* log,
+                           const int* devices, int n_devices, double* kernel_ms) {
+    if (!tables || !p || !tl || !devices || n_devices <= 0) return fail(PVT_ERR_INVALID, "null argument");
+    if (p->record_every > 0 && !log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+    const int ndev = pvt_device_count();
+    for (int g = 0; g < n_devices; g++)
+        if (devices[g] < 0 || devices[g] >= ndev) return fail(PVT_ERR_NO_DEVICE, "no such HIP device in the device list");
+    if (n_devices == 1) return pvt_trace_bundle(tables, emitter, rays, p, tl, log, devices[0], kernel_ms);
+
+    const size_t R = (size_t)(tables->n_recorders > 0 ? tables->n_recorders : 1);
+    const size_t B = (size_t)(tables->total_bins > 0 ? tables->total_bins : 1);
+    struct Shard {
+        int rc = PVT_OK;
+        std::string error;
+        double ms = 0.0;
+        std::vector<int64_t> distinct, crossings, bins;
+        std::vector<double> sums;
+    };
+    std::vector<Shard> shards((size_t)n_devices);
+    std::vector<std::thread> workers;
+    for (int g = 0; g < n_devices; g++) {
+        workers.emplace_back([&, g]() {
+            Shard& sh = shards[(size_t)g];
+            int64_t start = 0, stop = 0;
+            sh.rc = pvt_shard_range(p->n_rays, g, n_devices, p->record_every, &start, &stop);
+            if (sh.rc == PVT_OK && stop > start) {
+                sh.distinct.assign(R, 0); sh.crossings.assign(R, 0); sh.bins.assign(B, 0); sh.sums.assign(R * 8, 0.0);
+                PvtTraceParams q = *p;
+                q.n_rays = stop - start;
+                q.ray_offset = p->ray_offset + (uint64_t)start;
+                PvtRays r{};
+                if (rays) r = PvtRays{rays->position + 3 * start, rays->direction + 3 * start, rays->wavelength + start};
+                PvtTallies t{sh.distinct.data(), sh.crossings.data(), sh.sums.data(), sh.bins.data()};
+                PvtEventLog l{};
+                if (p->record_every > 0) {   // the shard's recorded rays start at global slot start / record_every
+                    const int64_t j0 = start / p->record_every, row0 = j0 * p->max_events;
+                    l = PvtEventLog{log->counts + j0, log->kind + row0, log->hit + row0, log->container + row0,
+                                    log->adjacent + row0, log->component + row0, log->source + row0,
+                                    log->position + 3 * row0, log->direction + 3 * row0, log->normal + 3 * row0,
+                                    log->wavelength + row0, log->travelled + row0, log->duration + row0};
+                }
+                sh.rc = pvt_trace_bundle(tables, emitter, rays ? &r : nullptr, &q, &t, p->record_every > 0 ? &l : nullptr,
+                                         devices[g], &sh.ms);
+            }
+            if (sh.rc != PVT_OK) sh.error = g_error;   // thread-local: carry it to the caller's thread
+        });
+    }
+    for (auto& w : workers) w.join();
+    double longest = 0.0;
+    for (int g = 0; g < n_devices; g++) {
+        const Shard& sh = shards[(size_t)g];
+        if (sh.rc != PVT_OK) return fail(sh.rc, "shard " + std::to_string(g) + " on device " + std::to_string(devices[g]) + ": " + sh.error);
+        if (sh.distinct.empty()) continue;
+        for (int i = 0; i < tables->n_recorders; i++) { tl->rec_distinct[i] += sh.distinct[(size_t)i]; tl->rec_crossings[i] += sh.crossings[(size_t)i]; }
+        for (int i = 0; i < tables->n_recorders * 8; i++) tl->rec_sums[i] += sh.sums[(size_t)i];
+        for (int i = 0; i < tables->total_bins; i++) tl->rec_bins[i] += sh.bins[(size_t)i];
+        if (sh.ms > longest) longest = sh.ms;
+    }
+    if (kernel_ms) *kernel_ms = longest;
     return PVT_OK;
 }
 

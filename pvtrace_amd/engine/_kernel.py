@@ -32,13 +32,15 @@ def _host_outputs(compiled, n_rays, record_every, max_events):
 
 
 def trace_bundle(compiled, positions, directions, wavelengths, seed, maxsteps, max_events,
-                 emit_method, num_threads, record_every, *, device=0, ray_offset=0,
+                 emit_method, num_threads, record_every, *, device=0, devices=None, ray_offset=0,
                  emitter=None, emit_seed=0, timing=None):
     """Trace a bundle on the GPU; returns the reference's result dict.
 
     `num_threads` is accepted for signature compatibility and ignored.  With
     `positions is None` and an `emit.EmitterTables` in `emitter`, rays are
-    sampled on the device (`wavelengths` must then be the ray count)."""
+    sampled on the device (`wavelengths` must then be the ray count).  `devices` (a list of GPU
+    ids, repeats allowed) splits the bundle over several GPUs inside this one call
+    (`pvt_trace_bundle_multi`); the result is independent of the list."""
     lib = N.load_library()
     st, keep = N.scene_tables_struct(compiled)
     if positions is None:
@@ -66,9 +68,15 @@ def trace_bundle(compiled, positions, directions, wavelengths, seed, maxsteps, m
     params = N.trace_params(n, seed, ray_offset, emit_seed, record_every, maxsteps, max_events,
                             emit_method)
     ms = C.c_double(0.0)
-    code = lib.pvt_trace_bundle(C.byref(st), em_ref, rays_ref, C.byref(params), C.byref(tl),
-                                C.byref(el) if record_every > 0 else None, int(device),
-                                C.byref(ms))
+    if devices is None:
+        code = lib.pvt_trace_bundle(C.byref(st), em_ref, rays_ref, C.byref(params), C.byref(tl),
+                                    C.byref(el) if record_every > 0 else None, int(device),
+                                    C.byref(ms))
+    else:
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        code = lib.pvt_trace_bundle_multi(C.byref(st), em_ref, rays_ref, C.byref(params), C.byref(tl),
+                                          C.byref(el) if record_every > 0 else None, ids, len(devices),
+                                          C.byref(ms))
     N.check(code, "pvt_trace_bundle")
     if timing is not None:
         timing["kernel_ms"] = ms.value

@@ -246,6 +246,7 @@ def download(compiled, tallies, log, n_rays, record_every, max_events):
 
 
 _SIDE_STREAMS = {}   # device index -> [torch.cuda.Stream, torch.cuda.Stream]
+_SIDE_STREAMS_LOCK = __import__("threading").Lock()
 
 
 class Session:
@@ -289,10 +290,11 @@ class Session:
         self.close()
 
     def submit(self, num_rays, seed, maxsteps=1000, max_events=128, emit_method="kT", record_every=1,
-               emit_seed=None, ray_offset=0, workgroups_per_cu=0):
+               emit_seed=None, ray_offset=0, workgroups_per_cu=0, host_rays=None):
         """Enqueue one bundle on one of two HIP streams and return a handle for `collect`.
         Two bundles may be in flight: the next one is traced while the caller consumes the
-        previous result."""
+        previous result.  `host_rays`: (positions, directions, wavelengths, sources) already emitted
+        on the host (a shard of a bundle emitted once for several GPUs)."""
         import torch
 
         from pvtrace_amd.engine import emit as emit_mod
@@ -301,7 +303,12 @@ class Session:
             raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
         device, dscene = self.device, self.dscene
         with torch.cuda.device(device):
-            if self.emission == "device":
+            if host_rays is not None:
+                pos, direc, wl, sources = host_rays
+                dev = torch.device("cuda", device)
+                rays = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                             for a in (pos, direc, wl))
+            elif self.emission == "device":
                 if emit_seed is None:
                     emit_seed = np.random.randint(0, 2 ** 31 - 1)
                 sources = emit_mod.sources_for(self.scene, num_rays, offset=ray_offset)
@@ -315,10 +322,11 @@ class Session:
                 # the two side streams are shared by every Session on this device: torch's caching
                 # allocator pools memory per stream, so fresh streams per call would re-malloc
                 # (and later free) every buffer, multi-GB event logs included
-                streams = _SIDE_STREAMS.setdefault(device, [])
-                while len(streams) < 2:
-                    streams.append(torch.cuda.Stream(device=device))
-                self._slots = [{"stream": st, "tallies": dscene.new_tallies()} for st in streams]
+                with _SIDE_STREAMS_LOCK:
+                    streams = _SIDE_STREAMS.setdefault(device, [])
+                    while len(streams) < 2:
+                        streams.append(torch.cuda.Stream(device=device))
+                self._slots = [{"stream": st, "tallies": dscene.new_tallies()} for st in streams[:2]]
             slot = self._slots[self._submitted % 2]
             self._submitted += 1
             stream, tallies = slot["stream"], slot["tallies"]
@@ -380,8 +388,13 @@ def simulate(
     emission="auto",
     emit_seed=None,
     ray_offset=0,
+    devices=None,
 ):
     """Trace `num_rays` through `scene` on the GPU.
+
+    `devices`: a list of GPU ids (repeats allowed) — the bundle is split over them by contiguous
+    index range inside this one call (one host thread and one resident scene per entry); ray i keeps
+    the stream `seed + ray_offset + i`, so the result does not depend on the list.
 
     Recorders attached to nodes tally every ray; full event histories are kept
     for every `record_every`-th ray (all when 1, none when 0).  Raises
@@ -398,10 +411,79 @@ def simulate(
     if seed is None:
         seed = np.random.randint(0, 2 ** 31 - 1)
     _warn_workers(workers)
+    if devices is not None:
+        if device is not None:
+            raise ValueError("give `device` or `devices`, not both")
+        return _simulate_on_devices(scene, num_rays, seed, list(devices), maxsteps, max_events, emit_method,
+                                    record_every, emission, emit_seed, ray_offset)
     with Session(scene, device=device, emission=emission) as session:
         return session.run(num_rays, seed, maxsteps=maxsteps, max_events=max_events,
                            emit_method=emit_method, record_every=record_every,
                            emit_seed=emit_seed, ray_offset=ray_offset)
+
+
+def merge_shards(results):
+    """EngineResults of consecutive index-range shards of ONE bundle (boundaries on multiples of
+    `record_every`) -> the EngineResult of the whole bundle: tallies add, event logs and sources
+    concatenate in shard order."""
+    first = results[0]
+    data = {}
+    for key in ("rec_distinct", "rec_crossings", "rec_sums", "rec_bins"):
+        total = np.array(first.data[key], copy=True)
+        for r in results[1:]:
+            total += r.data[key]
+        data[key] = total
+    for key in first.data:
+        if key not in data:
+            data[key] = np.concatenate([r.data[key] for r in results])
+    sources = [s for r in results for s in r.sources]
+    kernel_ms = [r.kernel_ms for r in results if r.kernel_ms is not None]
+    return EngineResult(first.compiled, data, sources, first.max_events, first.record_every,
+                        max(r.elapsed for r in results), kernel_ms=max(kernel_ms) if kernel_ms else None)
+
+
+def _simulate_on_devices(scene, num_rays, seed, devices, maxsteps, max_events, emit_method, record_every,
+                         emission, emit_seed, ray_offset):
+    """One bundle over several GPUs of this process (reference: one bundle over OpenMP threads,
+    _kernel.pyx:1074-1095; either way the outcome is independent of the split)."""
+    import concurrent.futures
+
+    from pvtrace_amd.engine import emit as emit_mod
+    from pvtrace_amd.engine.distributed import shard_range
+
+    if not devices:
+        raise ValueError("`devices` is empty")
+    sessions = [Session(scene, device=d, emission=emission) for d in devices]
+    try:
+        host = None
+        if sessions[0].emission == "host":   # the lights are sampled once, in the reference's global order
+            host = emit_mod.emit_bundle(scene, num_rays, seed=emit_seed)
+        elif emit_seed is None:
+            emit_seed = np.random.randint(0, 2 ** 31 - 1)
+        spans = [shard_range(num_rays, g, len(devices), align=record_every) for g in range(len(devices))]
+
+        def run(g):
+            lo, hi = spans[g]
+            if hi <= lo:
+                return None
+            kw = dict(maxsteps=maxsteps, max_events=max_events, emit_method=emit_method,
+                      record_every=record_every, ray_offset=ray_offset + lo)
+            if host is not None:
+                pos, direc, wl, sources = host
+                kw["host_rays"] = (pos[lo:hi], direc[lo:hi], wl[lo:hi], sources[lo:hi])
+                return sessions[g].run(hi - lo, int(seed), **kw)
+            return sessions[g].run(hi - lo, int(seed), emit_seed=emit_seed, **kw)
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=len(devices)) as pool:
+            results = [r for r in pool.map(run, range(len(devices))) if r is not None]
+    finally:
+        for session in sessions:
+            session.close()
+    if not results:   # num_rays == 0
+        with Session(scene, device=devices[0], emission=emission) as session:
+            return session.run(0, int(seed), maxsteps=maxsteps, max_events=max_events, emit_method=emit_method,
+                               record_every=record_every, emit_seed=emit_seed, ray_offset=ray_offset)
+    return merge_shards(results)
 
 
 def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
@@ -416,30 +498,46 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
     emit_seed = kwargs.pop("emit_seed", None)
     _warn_workers(kwargs.pop("workers", None))
     base_offset = int(kwargs.pop("ray_offset", 0))   # global index of the stream's first ray (sharded jobs)
-    session = Session(scene, device=kwargs.pop("device", None), emission=kwargs.pop("emission", "auto"))
-    if session.emission == "device" and emit_seed is None:
+    devices = kwargs.pop("devices", None)
+    device = kwargs.pop("device", None)
+    if devices is not None and device is not None:
+        raise ValueError("give `device` or `devices`, not both")
+    emission = kwargs.pop("emission", "auto")
+    # one resident scene per GPU; bundle b goes to GPU b mod N, two bundles in flight per GPU, results are
+    # yielded in bundle order
+    sessions = [Session(scene, device=d, emission=emission) for d in (devices if devices is not None else [device])]
+    if sessions[0].emission == "device" and emit_seed is None:
         emit_seed = np.random.randint(0, 2 ** 31 - 1)
-    def submit(traced):
+
+    def submit(index, traced):
+        session = sessions[index % len(sessions)]
         n = min(bundle, num_rays - traced)
         if session.emission == "device":
             # one emission stream for the whole job: ray i of the job is the same photon
             # whatever the bundle size
-            return session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=base_offset + traced,
-                                  workgroups_per_cu=3, **kwargs), n     # two bundles in flight
+            return session, session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=base_offset + traced,
+                                           workgroups_per_cu=3, **kwargs), n     # two bundles in flight
         bundle_emit_seed = None if emit_seed is None else int(emit_seed) + traced
-        return session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, ray_offset=base_offset,
-                              workgroups_per_cu=3, **kwargs), n
+        return session, session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, ray_offset=base_offset,
+                                       workgroups_per_cu=3, **kwargs), n
 
-    traced = 0
+    in_flight = collections.deque()
+    window = 2 * len(sessions)
+    submitted, index, traced = 0, 0, 0
     try:
-        pending = submit(0) if num_rays > 0 else None
-        while pending is not None:
-            handle, n = pending
-            following = traced + n
-            # bundle k+1 is traced while the consumer works on bundle k
-            pending = submit(following) if following < num_rays else None
+        while traced < num_rays or in_flight:
+            # bundles k+1 .. are traced while the consumer works on bundle k
+            while submitted < num_rays and len(in_flight) < window:
+                item = submit(index, submitted)
+                in_flight.append(item)
+                submitted += item[2]
+                index += 1
+            if not in_flight:
+                break
+            session, handle, n = in_flight.popleft()
             result = session.collect(handle)
-            traced = following
+            traced += n
             yield result, traced
     finally:
-        session.close()
+        for session in sessions:
+            session.close()

@@ -207,6 +207,11 @@ def declare_signatures(lib, names):
             [C.POINTER(PvtSceneTables), C.POINTER(PvtEmitterTables), C.POINTER(PvtRays),
              C.POINTER(PvtTraceParams), C.POINTER(PvtTallies), C.POINTER(PvtEventLog), C.c_int,
              C.POINTER(C.c_double)], C.c_int),
+        "pvt_trace_bundle_multi": (
+            [C.POINTER(PvtSceneTables), C.POINTER(PvtEmitterTables), C.POINTER(PvtRays),
+             C.POINTER(PvtTraceParams), C.POINTER(PvtTallies), C.POINTER(PvtEventLog), C.POINTER(C.c_int),
+             C.c_int, C.POINTER(C.c_double)], C.c_int),
+        "pvt_shard_range": ([C.c_int64, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
         "pvt_emit_device": ([vp, C.POINTER(PvtTraceParams), vp, vp, vp, vp], C.c_int),
         "pvt_selftest_math": ([C.c_int, vp, vp, C.c_int64, C.c_int], C.c_int),
         "pvt_mesh_bvh_check": (
@@ -227,10 +232,11 @@ ABI_SYMBOLS = (
     "pvt_abi_version", "pvt_last_error", "pvt_device_count", "pvt_scene_create",
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
+    "pvt_trace_bundle_multi", "pvt_shard_range",
 )
 
 _lib = None
-ABI_VERSION = 5   # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 6   # include/pvtrace_hip.h PVT_ABI_VERSION
 
 
 def library_built():
@@ -308,6 +314,15 @@ def is_available():
         return device_count() > 0
     except OSError:
         return False
+
+
+def shard_range(n_rays, shard, n_shards, align=1):
+    """The library's own shard arithmetic (pvt_shard_range; pure host code, no GPU needed)."""
+    lib = load_library()
+    a, b = C.c_int64(), C.c_int64()
+    check(lib.pvt_shard_range(int(n_rays), int(shard), int(n_shards), int(align), C.byref(a), C.byref(b)),
+          "pvt_shard_range")
+    return a.value, b.value
 
 
 def selftest_math(fn, x, device=0):

@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol(built):
     lib = native.load_library()
     for name in names:
         assert hasattr(lib, name), name
-    assert lib.pvt_abi_version() == 5 == native.ABI_VERSION
+    assert lib.pvt_abi_version() == 6 == native.ABI_VERSION
     # the embedded device code object really targets gfx950
     blob = open(native.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
@@ -99,3 +99,59 @@ def test_product_never_imports_the_oracle():
                         "oracle/pvt_oracle.c", "").replace("pvt_oracle_emit", ""):
                     offenders.append(os.path.join(dirpath, f))
     assert offenders == []
+
+
+def test_shard_ranges_of_the_library_match_the_python_sharder(built):
+    """pvt_shard_range (what pvt_trace_bundle_multi splits by) against engine.distributed.shard_range
+    (what the one-process-per-GPU path splits by): contiguous, exhaustive, inner edges on multiples of
+    record_every.  Pure host arithmetic."""
+    from pvtrace_amd.engine import native as N
+    from pvtrace_amd.engine.distributed import shard_range
+
+    for n in (0, 1, 63, 1000, 1_000_003, 2 ** 31 - 1):
+        for shards in (1, 2, 3, 8):
+            for align in (0, 1, 7, 1000):
+                spans = [N.shard_range(n, g, shards, align) for g in range(shards)]
+                assert spans == [shard_range(n, g, shards, align) for g in range(shards)]
+                assert spans[0][0] == 0 and spans[-1][1] == n
+                for (a, b), (c, d) in zip(spans, spans[1:]):
+                    assert a <= b == c <= d and b % max(align, 1) == 0
+    with pytest.raises(ValueError):
+        N.shard_range(10, 3, 3)
+
+
+def test_last_error_is_per_thread(built):
+    """pvt_last_error() is thread-local: a worker thread's failure neither leaks into nor is overwritten by
+    another thread's (the reference's consumer calls the engine from an executor thread, studio/server.py:229)."""
+    import threading
+
+    from pvtrace_amd.engine import native as N
+
+    lib = N.load_library()
+    a, b = C.c_int64(), C.c_int64()
+    assert lib.pvt_shard_range(-1, 0, 1, 1, C.byref(a), C.byref(b)) != 0   # this thread's own last failure
+    mine = lib.pvt_last_error().decode()
+    seen = {}
+    barrier = threading.Barrier(2)
+
+    def shard_fails():
+        a, b = C.c_int64(), C.c_int64()
+        assert lib.pvt_shard_range(10, 5, 2, 1, C.byref(a), C.byref(b)) != 0
+        barrier.wait()
+        barrier.wait()      # the other thread has failed differently meanwhile
+        seen["shard"] = lib.pvt_last_error().decode()
+
+    def create_fails():
+        barrier.wait()
+        assert lib.pvt_scene_create(None, 0, None) != 0
+        seen["create"] = lib.pvt_last_error().decode()
+        barrier.wait()
+
+    threads = [threading.Thread(target=shard_fails), threading.Thread(target=create_fails)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert "shard" in seen["shard"] and "null" in seen["create"]
+    assert seen["shard"] != seen["create"]
+    assert lib.pvt_last_error().decode() == mine   # untouched by the workers' failures

@@ -329,6 +329,82 @@ def test_the_binding_printed_in_INTEGRATION_md_works_as_documented():
         assert_bundles_identical(theirs, ours, sums_rtol=1e-12, what="INTEGRATION.md stub")
 
 
+def test_the_INTEGRATION_md_stub_splits_a_bundle_over_a_device_list():
+    """Same stub, `devices=(0, 0)`: two shards (here on the one GPU of the test box) give the
+    single-device arrays — event log rows in their global slots, integer tallies exact."""
+    import os
+    import re
+
+    from pvtrace_amd.engine import native
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, numpy as np\n.*?)```", text, flags=re.S).group(1)
+    native.load_library()
+    code = code.replace('C.CDLL("libpvtrace_hip.so")', f"C.CDLL({native.LIB_PATH!r})")
+    module = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), module)
+    scene = scenes.bench_slab(recorders=True)
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, 3001, seed=4)
+    for record_every in (1, 7, 0):
+        one = module["trace_bundle"](compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, record_every)
+        for devices in ((0, 0), (0, 0, 0)):
+            many = module["trace_bundle"](compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, record_every, devices=devices)
+            assert_bundles_identical(many, one, sums_rtol=1e-12, what=f"devices={devices} record_every={record_every}")
+
+
+@pytest.mark.parametrize("emission", ["host", "device"])
+def test_simulate_over_a_device_list_equals_one_device(emission):
+    scene = scenes.bench_slab(recorders=True)
+    kw = dict(seed=17, emit_seed=5, max_events=64, emission=emission)
+    for record_every in (1, 5, 0):
+        if emission == "host":
+            np.random.seed(3)
+        one = engine.simulate(scene, 2503, record_every=record_every, **kw)
+        if emission == "host":
+            np.random.seed(3)
+        two = engine.simulate(scene, 2503, record_every=record_every, devices=[0, 0], **kw)
+        assert_bundles_identical(two.data, one.data, sums_rtol=1e-12, what=f"{emission} {record_every}")
+        assert two.sources == one.sources and two.num_recorded == one.num_recorded
+    with pytest.raises(ValueError):
+        engine.simulate(scene, 10, seed=1, device=0, devices=[0])
+
+
+def test_simulate_stream_over_a_device_list_yields_the_same_bundles_in_order():
+    scene = scenes.bench_slab(recorders=True)
+    kw = dict(bundle=700, seed=23, emit_seed=9, record_every=0)
+    one = list(engine.simulate_stream(scene, 3000, **kw))
+    two = list(engine.simulate_stream(scene, 3000, devices=[0, 0], **kw))
+    assert [t for _, t in one] == [t for _, t in two] == [700, 1400, 2100, 2800, 3000]
+    for (a, _), (b, _) in zip(one, two):
+        assert_bundles_identical(b.data, a.data, sums_rtol=1e-12, what="stream over devices")
+
+
+def test_the_engine_runs_from_worker_threads_like_the_studio_consumer():
+    """The reference's streaming consumer drives the engine from an executor thread
+    (studio/server.py:225-230); two threads may also trace two scenes on one GPU at once.  Results are
+    those of the same calls made serially from the main thread."""
+    import concurrent.futures
+
+    slab, box = scenes.bench_slab(recorders=True), scenes.fresnel_box()
+
+    def stream(scene, seed):
+        return [r.data for r, _ in engine.simulate_stream(scene, 2400, bundle=800, seed=seed, emit_seed=seed + 1,
+                                                          record_every=3, max_events=48)]
+
+    serial = [stream(slab, 31), stream(box, 37)]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:     # off the main thread
+        off_main = pool.submit(stream, slab, 31).result()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:     # two scenes at once
+        futures = [pool.submit(stream, slab, 31), pool.submit(stream, box, 37)]
+        both = [f.result() for f in futures]
+    for got, want in ((off_main, serial[0]), (both[0], serial[0]), (both[1], serial[1])):
+        assert len(got) == len(want) == 3
+        for a, b in zip(got, want):
+            assert_bundles_identical(a, b, sums_rtol=1e-12, what="threaded stream")
+
+
 def _kernel_module():
     from pvtrace_amd.engine import _kernel
 
