@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 6
+#define PVT_ABI_VERSION 7
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -177,6 +177,17 @@ typedef struct PvtTraceParams {
                                 * fills the chip).  Launches that overlap on several streams run best
                                 * with fewer (2 with three in flight): each then holds fewer CU slots
                                 * while it drains, and a workgroup amortises its drain over more photons */
+    /* A stream of equal bundles in ONE launch (the reference's simulate_stream, api.py:249-264, hands
+     * its kernel one bundle per call; a 50 000-photon bundle is far too little to occupy an MI355X).
+     * With tally_bundle = m > 0 (tally mode only: record_every == 0) the n_rays rays are the
+     * concatenation of bundles of m rays (the last may be shorter): ray i still uses the stream
+     * seed + ray_offset + i — exactly the seeds of the streamed bundles — but the rays of bundle
+     * j = i / m are tallied into set j of the tally arrays, set j starting tally_stride_i64 int64
+     * elements (rec_distinct, rec_crossings, rec_bins alike) and tally_stride_f64 doubles (rec_sums)
+     * after set j-1.  0 = the launch is one bundle. */
+    int64_t tally_bundle;
+    int64_t tally_stride_i64;
+    int64_t tally_stride_f64;
 } PvtTraceParams;
 
 /* initial rays, world frame (exactly trace_bundle's three array arguments) */

@@ -80,6 +80,7 @@ struct PvtScene {
     int* d_ei = nullptr;
     pvt::BvhNode* d_bvh = nullptr;      // triangle meshes: BVH nodes + gathered triangles
     pvt::MeshTri* d_tris = nullptr;
+    unsigned int* d_set_cursor = nullptr;   // kCursorSlots x kMaxSets cursors: launches with tally sets
     unsigned int* d_cursor = nullptr;   // kCursorSlots cursors (64 B apart), one per stream: launches on
                                         // different streams may overlap, each needs its own
     std::mutex slot_mutex;              // launches on one stream are ordered and may share a cursor;
@@ -355,6 +356,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
     HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
+    HIP_TRY(hipMalloc(&s->d_set_cursor, (size_t)kCursorSlots * kMaxSets * 4));
     if (!bvh_nodes.empty()) {
         HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
         HIP_TRY(hipMalloc(&s->d_tris, bvh_tris.size() * sizeof(pvt::MeshTri)));
@@ -407,6 +409,7 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_ed) (void)hipFree(s->d_ed);
     if (s->d_ei) (void)hipFree(s->d_ei);
     if (s->d_cursor) (void)hipFree(s->d_cursor);
+    if (s->d_set_cursor) (void)hipFree(s->d_set_cursor);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->d_tris) (void)hipFree(s->d_tris);
     delete s;
@@ -475,6 +478,14 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     if (!rays && !s->d_ed) return fail(PVT_ERR_INVALID, "no rays and no emitter");
     if (p->record_every > 0 && !log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
     if (p->n_rays == 0) return PVT_OK;
+    long long n_sets = 0;
+    if (p->tally_bundle > 0) {
+        if (p->record_every > 0) return fail(PVT_ERR_INVALID, "tally_bundle needs record_every == 0");
+        n_sets = (p->n_rays + p->tally_bundle - 1) / p->tally_bundle;
+        if (p->tally_bundle > 0x7fffffffLL || n_sets > kMaxSets)
+            return fail(PVT_ERR_INVALID, "at most 1024 tally sets per launch");
+        if (p->tally_stride_i64 < 0 || p->tally_stride_f64 < 0) return fail(PVT_ERR_INVALID, "negative tally stride");
+    }
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
@@ -512,9 +523,9 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
                 return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
             s->slot_of.push_back(st);
         }
-        a.cursor = s->d_cursor + 16 * slot;
+        a.cursor = n_sets ? s->d_set_cursor + (size_t)kMaxSets * slot : s->d_cursor + 16 * slot;
     }
-    HIP_TRY(hipMemsetAsync(a.cursor, 0, PVT_STATS ? 256 : 4, st));
+    HIP_TRY(hipMemsetAsync(a.cursor, 0, n_sets ? (size_t)n_sets * 4 : (PVT_STATS ? 256 : 4), st));
 #if PVT_STATS
     static unsigned long long* g_stats = nullptr;
     if (!g_stats) (void)hipMalloc(&g_stats, 256);
@@ -550,6 +561,17 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     long long grid = (long long)((double)s->num_cu * per_cu);
     if (grid > blocks_for_rays) grid = blocks_for_rays;
     if (grid < 1) grid = 1;
+    if (n_sets) {   // a workgroup serves one set: the same total, split evenly over the sets
+        long long per_set = grid / n_sets;
+        const long long for_rays = (p->tally_bundle + kBlock - 1) / kBlock;
+        if (per_set > for_rays) per_set = for_rays;
+        if (per_set < 1) per_set = 1;
+        grid = per_set * n_sets;
+        a.set_size = (unsigned int)p->tally_bundle;
+        a.wgs_per_set = (int)per_set;
+        a.set_stride_i = p->tally_stride_i64;
+        a.set_stride_d = p->tally_stride_f64;
+    }
     s->last_grid = (int)grid;
     s->last_lds = (int)lds;
 
@@ -712,14 +734,26 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
         HIP_TRY(hipMemcpy(dw, rays->wavelength, n * 8, hipMemcpyHostToDevice));
         drays = PvtRays{(const double*)dp, (const double*)dd, (const double*)dw};
     }
+    // tally sets (PvtTraceParams.tally_bundle): the device copies keep the caller's strides, slices move as
+    // 2-D copies (one row per set)
+    const size_t n_sets = p->tally_bundle > 0 ? (size_t)((p->n_rays + p->tally_bundle - 1) / p->tally_bundle) : 1;
+    const size_t si = n_sets > 1 ? (size_t)p->tally_stride_i64 : 0, sd = n_sets > 1 ? (size_t)p->tally_stride_f64 : 0;
+    if (n_sets > 1 && (si < R || si < B || sd < R * 8)) return fail(PVT_ERR_INVALID, "tally strides smaller than a set");
+    const size_t nR = (size_t)tables->n_recorders, nB = (size_t)tables->total_bins;
     PvtTallies dt{};
     void *t0, *t1, *t2, *t3;
-    HIP_TRY(dalloc(R * 8, &t0)); HIP_TRY(dalloc(R * 8, &t1)); HIP_TRY(dalloc(R * 64, &t2)); HIP_TRY(dalloc(B * 8, &t3));
+    HIP_TRY(dalloc(((n_sets - 1) * si + R) * 8, &t0)); HIP_TRY(dalloc(((n_sets - 1) * si + R) * 8, &t1));
+    HIP_TRY(dalloc(((n_sets - 1) * sd + R * 8) * 8, &t2)); HIP_TRY(dalloc(((n_sets - 1) * si + B) * 8, &t3));
+    auto move = [&](void* dst, const void* src, size_t pitch_elems, size_t width_elems, hipMemcpyKind kind) -> hipError_t {
+        if (width_elems == 0) return hipSuccess;
+        if (n_sets == 1) return hipMemcpy(dst, src, width_elems * 8, kind);
+        return hipMemcpy2D(dst, pitch_elems * 8, src, pitch_elems * 8, width_elems * 8, n_sets, kind);
+    };
     // the trace ADDS into the caller's tallies: seed the device copies with them
-    HIP_TRY(hipMemcpy(t0, tl->rec_distinct, (size_t)tables->n_recorders * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t1, tl->rec_crossings, (size_t)tables->n_recorders * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t2, tl->rec_sums, (size_t)tables->n_recorders * 64, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t3, tl->rec_bins, (size_t)tables->total_bins * 8, hipMemcpyHostToDevice));
+    HIP_TRY(move(t0, tl->rec_distinct, si, nR, hipMemcpyHostToDevice));
+    HIP_TRY(move(t1, tl->rec_crossings, si, nR, hipMemcpyHostToDevice));
+    HIP_TRY(move(t2, tl->rec_sums, sd, nR * 8, hipMemcpyHostToDevice));
+    HIP_TRY(move(t3, tl->rec_bins, si, nB, hipMemcpyHostToDevice));
     dt = PvtTallies{(int64_t*)t0, (int64_t*)t1, (double*)t2, (int64_t*)t3};
 
     PvtEventLog dl{};
@@ -751,10 +785,10 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 
-    HIP_TRY(hipMemcpy(tl->rec_distinct, t0, (size_t)tables->n_recorders * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tl->rec_crossings, t1, (size_t)tables->n_recorders * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tl->rec_sums, t2, (size_t)tables->n_recorders * 64, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tl->rec_bins, t3, (size_t)tables->total_bins * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(move(tl->rec_distinct, t0, si, nR, hipMemcpyDeviceToHost));
+    HIP_TRY(move(tl->rec_crossings, t1, si, nR, hipMemcpyDeviceToHost));
+    HIP_TRY(move(tl->rec_sums, t2, sd, nR * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(move(tl->rec_bins, t3, si, nB, hipMemcpyDeviceToHost));
     if (record) {
         HIP_TRY(hipMemcpy(log->counts, dl.counts, nrec * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(log->kind, dl.kind, rows, hipMemcpyDeviceToHost));

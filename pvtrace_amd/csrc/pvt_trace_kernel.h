@@ -19,6 +19,7 @@ constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
 constexpr int kWaves = kBlock / 64;
 constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
+constexpr int kMaxSets = 1024;       // tally sets (bundles of a stream) one launch may serve
 constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a draining workgroup (>= 64: the
                                      // last stage packs the survivors into one wave; >= 69 so that the 8 KB of
                                      // per-wave seed pools fit in the same region); small enough that FIVE
@@ -94,6 +95,11 @@ struct KArgs {
     double* rec_sums;
     long long* rec_bins;
     PvtEventLog log;
+    // tally sets (0 = the launch is one bundle): rays [j*set_size, (j+1)*set_size) are bundle j of a stream of
+    // equal bundles; a workgroup serves ONE set (its own ray cursor, its own slice of the tally arrays)
+    unsigned int set_size;
+    int wgs_per_set;
+    long long set_stride_i, set_stride_d;   // elements between consecutive sets in rec_distinct/crossings/bins and rec_sums
     int bins_in_lds;
     int xslots;   // photon-state slots in LDS for drain-phase consolidation (0 = off)
 };
@@ -460,6 +466,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
+    // ---- the rays this workgroup draws from: the whole launch, or its tally set (wave-uniform) ------
+    const unsigned int set = A.set_size ? blockIdx.x / (unsigned int)A.wgs_per_set : 0u;
+    const unsigned int ray_lo = set * A.set_size;
+    const unsigned int n_local = A.set_size ? (A.n_rays - ray_lo < A.set_size ? A.n_rays - ray_lo : A.set_size) : A.n_rays;
+    unsigned int* const cursor = A.cursor + set;
+
     // ---- per-photon state --------------------------------------------------
     bool alive = false;
     V3 pos{0, 0, 0}, dir{0, 0, 1};
@@ -502,16 +514,16 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             if (w_next >= w_end) {
                 if (exhausted) break;
                 unsigned int b = 0;
-                if (lane == 0) b = atomicAdd(A.cursor, (unsigned int)kChunk);
+                if (lane == 0) b = atomicAdd(cursor, (unsigned int)kChunk);
                 b = __builtin_amdgcn_readfirstlane(b);
-                if (b >= A.n_rays) { exhausted = true; break; }
+                if (b >= n_local) { exhausted = true; break; }
                 w_next = b;
-                w_end = (A.n_rays - b < (unsigned int)kChunk) ? A.n_rays : b + kChunk;
+                w_end = (n_local - b < (unsigned int)kChunk) ? n_local : b + kChunk;
                 if (seed_pool) {
                     // Seed the whole chunk NOW, with every lane busy, instead of inside each later
                     // refill with only the dead lanes active (8 64-bit multiplies per seed): lane l
                     // prepares the stream of ray b + l and parks it in this wave's slice of LDS.
-                    unsigned long long st = A.seed + (unsigned long long)b + (unsigned long long)lane;
+                    unsigned long long st = A.seed + (unsigned long long)ray_lo + (unsigned long long)b + (unsigned long long)lane;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {   // one word at a time: keeps the live range short
                         xbuf[pool_at + k * 64 + lane] = splitmix64(st);
@@ -524,7 +536,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             unsigned int rank = __popcll(need & lane_lt);
             unsigned int want = __popcll(need);
             if (!alive && rank < avail) {
-                unsigned int i = w_next + rank;
+                const unsigned int il = w_next + rank;   // index within the set
+                const unsigned int i = ray_lo + il;      // index within the launch
                 if constexpr (EMIT) {
                     emit_one(A, A.ray_offset + i, pos, dir, wl);
                 } else {
@@ -533,7 +546,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                     wl = A.wl[i];
                 }
                 if (seed_pool) {
-                    const int k = pool_at + (int)(i - w_base);
+                    const int k = pool_at + (int)(il - w_base);
                     rng.s0 = xbuf[k]; rng.s1 = xbuf[k + 64]; rng.s2 = xbuf[k + 128]; rng.s3 = xbuf[k + 192];
                 } else {
                     rng_seed(rng, A.seed + (unsigned long long)i);
@@ -1335,7 +1348,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
                                     slot = T.iv(hi_ + HI_OFF) + ia * nb + ib;
                                 }
                                 if (A.bins_in_lds) atomicAdd(&acc_bins[slot], 1u);
-                                else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + slot, 1ull);
+                                else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i + slot, 1ull);
                             }
                         }
                     }
@@ -1372,20 +1385,24 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
     order = __builtin_amdgcn_readfirstlane(order);
     if (order != kWaves - 1) return;
     __threadfence_block();
+    unsigned long long* const out_distinct = reinterpret_cast<unsigned long long*>(A.rec_distinct) + (long long)set * A.set_stride_i;
+    unsigned long long* const out_crossings = reinterpret_cast<unsigned long long*>(A.rec_crossings) + (long long)set * A.set_stride_i;
+    unsigned long long* const out_bins = reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i;
+    double* const out_sums = A.rec_sums + (long long)set * A.set_stride_d;
     for (int i = lane; i < A.n_rec; i += 64) {
         const unsigned long long c = acc_cross[i];
         const unsigned int d = acc_distinct[i];
-        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_crossings) + i, c);
-        if (d) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_distinct) + i, (unsigned long long)d);
+        if (c) atomicAdd(out_crossings + i, c);
+        if (d) atomicAdd(out_distinct + i, (unsigned long long)d);
     }
     for (int i = lane; i < A.n_rec * 8; i += 64) {
         double v = acc_sums[i];
-        if (v != 0.0) atomicAdd(A.rec_sums + i, v);
+        if (v != 0.0) atomicAdd(out_sums + i, v);
     }
     if (A.bins_in_lds)
         for (int i = lane; i < A.total_bins; i += 64) {
             unsigned int v = acc_bins[i];
-            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + i, (unsigned long long)v);
+            if (v) atomicAdd(out_bins + i, (unsigned long long)v);
         }
 }
 

@@ -92,3 +92,30 @@ def trace_bundle(compiled, positions, directions, wavelengths, seed, maxsteps, m
         col = out[name][: rows * width]
         data[name] = col.reshape(rows, 3) if width == 3 else col
     return data
+
+
+def trace_bundle_sets(compiled, positions, directions, wavelengths, seed, maxsteps, emit_method, bundle,
+                      *, device=0, ray_offset=0):
+    """Tally-mode trace of consecutive bundles of `bundle` rays in ONE launch (host buffers; the C entry
+    `pvt_trace_bundle` with `PvtTraceParams.tally_bundle`) -> one dict of rec_* arrays per bundle."""
+    lib = N.load_library()
+    st, keep = N.scene_tables_struct(compiled)
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    dirs = np.ascontiguousarray(directions, dtype=np.float64)
+    wl = np.ascontiguousarray(wavelengths, dtype=np.float64)
+    n = pos.shape[0]
+    sets = -(-n // int(bundle))
+    nrec, nbins = int(compiled.rec_node.shape[0]), int(compiled.total_bins)
+    pad = max(nrec, 1)
+    stride_i, stride_d = 2 * pad + max(nbins, 1), pad * 8
+    ints = np.zeros(sets * stride_i, dtype=np.int64)
+    sums = np.zeros(sets * stride_d, dtype=np.float64)
+    tl = N.PvtTallies(N.np_ptr(ints), N.np_ptr(ints[pad:]), N.np_ptr(sums), N.np_ptr(ints[2 * pad:]))
+    params = N.trace_params(n, seed, ray_offset, 0, 0, maxsteps, 2, emit_method, 0, bundle, stride_i, stride_d)
+    rays = N.PvtRays(N.np_ptr(pos), N.np_ptr(dirs), N.np_ptr(wl))
+    N.check(lib.pvt_trace_bundle(C.byref(st), None, C.byref(rays), C.byref(params), C.byref(tl), None,
+                                 int(device), None), "pvt_trace_bundle")
+    ints, sums = ints.reshape(sets, stride_i), sums.reshape(sets, stride_d)
+    return [{"rec_distinct": ints[j, :nrec], "rec_crossings": ints[j, pad:pad + nrec],
+             "rec_bins": ints[j, 2 * pad:2 * pad + nbins], "rec_sums": sums[j, :nrec * 8].reshape(nrec, 4, 2)}
+            for j in range(sets)]

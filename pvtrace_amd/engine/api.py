@@ -173,6 +173,7 @@ class EngineResult:
             yield steps
 
 
+GROUP_PHOTONS = 1_000_000   # photons one launch of simulate_stream traces in tally mode (bundles grouped)
 _WORKERS_WARNED = False
 
 
@@ -290,11 +291,13 @@ class Session:
         self.close()
 
     def submit(self, num_rays, seed, maxsteps=1000, max_events=128, emit_method="kT", record_every=1,
-               emit_seed=None, ray_offset=0, workgroups_per_cu=0, host_rays=None):
+               emit_seed=None, ray_offset=0, workgroups_per_cu=0, host_rays=None, tally_bundle=0):
         """Enqueue one bundle on one of two HIP streams and return a handle for `collect`.
         Two bundles may be in flight: the next one is traced while the caller consumes the
         previous result.  `host_rays`: (positions, directions, wavelengths, sources) already emitted
-        on the host (a shard of a bundle emitted once for several GPUs)."""
+        on the host (a shard of a bundle emitted once for several GPUs).  `tally_bundle` = m > 0
+        (tally mode): the rays are consecutive bundles of m rays traced by ONE launch, each tallied on
+        its own (PvtTraceParams.tally_bundle); `collect_bundles` returns one result per bundle."""
         import torch
 
         from pvtrace_amd.engine import emit as emit_mod
@@ -329,6 +332,9 @@ class Session:
                 self._slots = [{"stream": st, "tallies": dscene.new_tallies()} for st in streams[:2]]
             slot = self._slots[self._submitted % 2]
             self._submitted += 1
+            sets = -(-int(num_rays) // int(tally_bundle)) if tally_bundle else 1
+            if slot["tallies"].get("sets", 1) < sets:
+                slot["tallies"] = dscene.new_tallies(sets=sets)
             stream, tallies = slot["stream"], slot["tallies"]
             stream.wait_stream(torch.cuda.current_stream(device))   # ray upload, earlier downloads
             with torch.cuda.stream(stream):
@@ -343,11 +349,11 @@ class Session:
                              emit_seed=int(emit_seed or 0), record_every=int(record_every),
                              maxsteps=int(maxsteps), max_events=int(max_events),
                              emit_method=EMIT_METHODS[emit_method], stream=stream.cuda_stream,
-                             workgroups_per_cu=workgroups_per_cu)
+                             workgroups_per_cu=workgroups_per_cu, tally_bundle=int(tally_bundle))
                 stop.record(stream)
         return {"stream": stream, "tallies": tallies, "log": log, "events": (start, stop), "tic": tic,
                 "rays": rays, "sources": sources, "num_rays": num_rays, "record_every": record_every,
-                "max_events": max_events}
+                "max_events": max_events, "tally_bundle": int(tally_bundle)}
 
     def collect(self, pending, wall_clock=False):
         """Wait for a submitted bundle and bring its results to the host -> `EngineResult`.
@@ -365,6 +371,41 @@ class Session:
         return EngineResult(self.compiled, data, pending["sources"], pending["max_events"],
                             pending["record_every"], wall if wall_clock else kernel_ms * 1e-3,
                             kernel_ms=kernel_ms)
+
+    def collect_bundles(self, pending):
+        """Wait for a launch submitted with `tally_bundle` -> one `EngineResult` per bundle, in order
+        (one download for all of them)."""
+        import torch
+
+        m = pending["tally_bundle"]
+        n = pending["num_rays"]
+        sets = -(-n // m)
+        c = self.compiled
+        nrec = int(c.rec_node.shape[0])
+        pad, nbins = max(nrec, 1), int(c.total_bins)
+        t = pending["tallies"]
+        with torch.cuda.device(self.device):
+            pending["stream"].synchronize()
+            kernel_ms = pending["events"][0].elapsed_time(pending["events"][1])
+            with torch.cuda.stream(pending["stream"]):
+                ints = t["_ints"][: sets * t["stride_i64"]].cpu().numpy().reshape(sets, t["stride_i64"])
+                sums = t["_sums"][: sets * t["stride_f64"]].cpu().numpy().reshape(sets, t["stride_f64"])
+        empty = {"counts": np.zeros(0, dtype=np.int32)}
+        for name, dtype, width in native.EVENT_LOG_COLUMNS:
+            col = np.zeros(0, dtype=dtype)
+            empty[name] = col.reshape(0, 3) if width == 3 else col
+        results = []
+        sources = pending["sources"]
+        for j in range(sets):
+            lo, hi = j * m, min((j + 1) * m, n)
+            data = dict(empty)
+            data["rec_distinct"] = ints[j, :nrec]
+            data["rec_crossings"] = ints[j, pad:pad + nrec]
+            data["rec_bins"] = ints[j, 2 * pad: 2 * pad + nbins]
+            data["rec_sums"] = sums[j, : nrec * 8].reshape(nrec, 4, 2)
+            results.append(EngineResult(c, data, sources[lo:hi], pending["max_events"], 0,
+                                        kernel_ms * 1e-3 * (hi - lo) / n, kernel_ms=kernel_ms * (hi - lo) / n))
+        return results
 
     def run(self, num_rays, seed, **kwargs):
         """Trace one bundle -> `EngineResult` (submit + collect)."""
@@ -509,14 +550,31 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
     if sessions[0].emission == "device" and emit_seed is None:
         emit_seed = np.random.randint(0, 2 ** 31 - 1)
 
+    # Tally mode: a launch serves a GROUP of consecutive bundles (one tally set each), about a million
+    # photons' worth -- a 50 000-photon bundle alone leaves most of an MI355X idle and pays the launch and
+    # the drain of a kernel for very little.  The bundles of a group are yielded one by one, as ever.
+    per_group = 1
+    if int(kwargs.get("record_every", 1)) == 0 and bundle > 0:
+        per_group = max(1, min(1024, GROUP_PHOTONS // int(bundle)))
+
     def submit(index, traced):
         session = sessions[index % len(sessions)]
-        n = min(bundle, num_rays - traced)
+        n = min(bundle * per_group, num_rays - traced)
+        group = {"tally_bundle": bundle} if per_group > 1 else {}
         if session.emission == "device":
             # one emission stream for the whole job: ray i of the job is the same photon
             # whatever the bundle size
             return session, session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=base_offset + traced,
-                                           workgroups_per_cu=3, **kwargs), n     # two bundles in flight
+                                           workgroups_per_cu=3, **group, **kwargs), n     # two launches in flight
+        if per_group > 1:   # the lights are sampled bundle by bundle, in the reference's order, then traced together
+            from pvtrace_amd.engine import emit as emit_mod
+
+            parts = [emit_mod.emit_bundle(scene, min(bundle, n - at),
+                                          seed=None if emit_seed is None else int(emit_seed) + traced + at)
+                     for at in range(0, n, bundle)]
+            host = tuple(np.concatenate([p[k] for p in parts]) for k in range(3)) + ([x for p in parts for x in p[3]],)
+            return session, session.submit(n, int(seed) + traced, ray_offset=base_offset, workgroups_per_cu=3,
+                                           host_rays=host, **group, **kwargs), n
         bundle_emit_seed = None if emit_seed is None else int(emit_seed) + traced
         return session, session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, ray_offset=base_offset,
                                        workgroups_per_cu=3, **kwargs), n
@@ -526,7 +584,7 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
     submitted, index, traced = 0, 0, 0
     try:
         while traced < num_rays or in_flight:
-            # bundles k+1 .. are traced while the consumer works on bundle k
+            # launches k+1 .. are traced while the consumer works on the bundles of launch k
             while submitted < num_rays and len(in_flight) < window:
                 item = submit(index, submitted)
                 in_flight.append(item)
@@ -535,9 +593,14 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
             if not in_flight:
                 break
             session, handle, n = in_flight.popleft()
-            result = session.collect(handle)
-            traced += n
-            yield result, traced
+            if handle["tally_bundle"]:
+                for result in session.collect_bundles(handle):
+                    traced += result.num_rays
+                    yield result, traced
+            else:
+                result = session.collect(handle)
+                traced += n
+                yield result, traced
     finally:
         for session in sessions:
             session.close()

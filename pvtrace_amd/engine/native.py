@@ -74,6 +74,7 @@ class PvtTraceParams(C.Structure):
         ("n_rays", C.c_int64), ("seed", C.c_uint64), ("ray_offset", C.c_uint64),
         ("emit_seed", C.c_uint64), ("record_every", C.c_int64), ("maxsteps", C.c_int32),
         ("max_events", C.c_int32), ("emit_method", C.c_int32), ("workgroups_per_cu", C.c_int32),
+        ("tally_bundle", C.c_int64), ("tally_stride_i64", C.c_int64), ("tally_stride_f64", C.c_int64),
     ]
 
 
@@ -169,11 +170,12 @@ def emitter_tables_struct(emitter):
 
 
 def trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps, max_events,
-                 emit_method, workgroups_per_cu=0):
+                 emit_method, workgroups_per_cu=0, tally_bundle=0, tally_stride_i64=0, tally_stride_f64=0):
     mask = (1 << 64) - 1
     return PvtTraceParams(
         int(n_rays), int(seed) & mask, int(ray_offset) & mask, int(emit_seed) & mask,
         int(record_every), int(maxsteps), int(max_events), int(emit_method), int(workgroups_per_cu),
+        int(tally_bundle), int(tally_stride_i64), int(tally_stride_f64),
     )
 
 
@@ -236,7 +238,7 @@ ABI_SYMBOLS = (
 )
 
 _lib = None
-ABI_VERSION = 6   # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 7   # include/pvtrace_hip.h PVT_ABI_VERSION
 
 
 def library_built():
@@ -387,19 +389,20 @@ class DeviceScene:
         return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
 
     # -- device buffers (torch tensors) ----------------------------------
-    def new_tallies(self):
+    def new_tallies(self, sets=1):
         """Zeroed recorder accumulators on the GPU.  The three integer tables are
         views of ONE int64 buffer (`_ints`: distinct | crossings | bins) and the
         moment sums are `_sums`, so a whole tally set is zeroed by two memsets
-        and all-reduced by two collectives."""
+        and all-reduced by two collectives.  `sets` > 1: that many consecutive sets
+        (the bundles of a stream traced by one launch, PvtTraceParams.tally_bundle)."""
         import torch
 
         dev = torch.device("cuda", self.device)
         c = self.compiled
         nrec = max(int(c.rec_node.shape[0]), 1)
         nbins = max(int(c.total_bins), 1)
-        ints = torch.zeros(2 * nrec + nbins, dtype=torch.int64, device=dev)
-        sums = torch.zeros(nrec * 8, dtype=torch.float64, device=dev)
+        ints = torch.zeros(sets * (2 * nrec + nbins), dtype=torch.int64, device=dev)
+        sums = torch.zeros(sets * nrec * 8, dtype=torch.float64, device=dev)
         return {
             "rec_distinct": ints[:nrec],
             "rec_crossings": ints[nrec:2 * nrec],
@@ -407,6 +410,7 @@ class DeviceScene:
             "rec_bins": ints[2 * nrec:],
             "_ints": ints,
             "_sums": sums,
+            "sets": sets, "stride_i64": 2 * nrec + nbins, "stride_f64": nrec * 8,
         }
 
     def new_event_log(self, n_rays, record_every, max_events):
@@ -423,7 +427,7 @@ class DeviceScene:
 
     def trace(self, rays, n_rays, seed, tallies, log=None, ray_offset=0, emit_seed=0,
               record_every=0, maxsteps=1000, max_events=128, emit_method=0, stream=None,
-              workgroups_per_cu=0):
+              workgroups_per_cu=0, tally_bundle=0):
         """Enqueue one bundle (`workgroups_per_cu`: see PvtTraceParams; 0 = the library default).
         `rays` is None (device emission) or a tuple of
         three float64 CUDA tensors (positions (n,3), directions (n,3), wavelengths (n))."""
@@ -431,8 +435,14 @@ class DeviceScene:
 
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
+        if tally_bundle:
+            need = -(-int(n_rays) // int(tally_bundle))
+            if tallies.get("sets", 1) < need:
+                raise ValueError(f"{need} tally sets needed, the buffers hold {tallies.get('sets', 1)}")
         params = trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps,
-                              max_events, emit_method, workgroups_per_cu)
+                              max_events, emit_method, workgroups_per_cu, tally_bundle,
+                              tallies.get("stride_i64", 0) if tally_bundle else 0,
+                              tallies.get("stride_f64", 0) if tally_bundle else 0)
         tl = PvtTallies(
             addr_ptr(tallies["rec_distinct"].data_ptr(), C.c_int64),
             addr_ptr(tallies["rec_crossings"].data_ptr(), C.c_int64),

@@ -381,6 +381,44 @@ def test_simulate_stream_over_a_device_list_yields_the_same_bundles_in_order():
         assert_bundles_identical(b.data, a.data, sums_rtol=1e-12, what="stream over devices")
 
 
+@pytest.mark.parametrize("emission", ["device", "host"])
+def test_grouped_stream_bundles_equal_bundles_traced_one_by_one(emission):
+    """In tally mode `simulate_stream` traces a group of bundles with one launch (one tally set per
+    bundle, PvtTraceParams.tally_bundle).  Every yielded bundle must be what tracing that bundle alone
+    gives (reference contract api.py:249-264: bundle b = rays [b*m, (b+1)*m) with seeds seed + traced + i)."""
+    scene = scenes.bench_slab(recorders=True)
+    m, total, seed, emit_seed = 600, 2000, 41, 13
+    if emission == "host":
+        np.random.seed(5)
+    got = list(engine.simulate_stream(scene, total, bundle=m, seed=seed, emit_seed=emit_seed, record_every=0,
+                                      emission=emission))
+    assert [t for _, t in got] == [600, 1200, 1800, 2000]
+    traced = 0
+    for result, upto in got:
+        n = upto - traced
+        if emission == "device":
+            alone = engine.simulate(scene, n, seed=seed, emit_seed=emit_seed, ray_offset=traced, record_every=0,
+                                    emission="device")
+        else:
+            alone = engine.simulate(scene, n, seed=seed + traced, emit_seed=emit_seed + traced, record_every=0,
+                                    emission="host")
+        assert_bundles_identical(result.data, alone.data, sums_rtol=1e-12, what=f"bundle at {traced}")
+        assert list(result.sources) == list(alone.sources) and result.num_rays == n
+        traced = upto
+    # and the C entry with host buffers: sets with strides
+    from pvtrace_amd.engine import _kernel, native as N
+
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, total, seed=2)
+    whole = [_kernel.trace_bundle(compiled, pos[a:a + m], dirs[a:a + m], wl[a:a + m], seed, 1000, 16, 0, 1, 0,
+                                  ray_offset=a) for a in range(0, total, m)]
+    sets = _kernel.trace_bundle_sets(compiled, pos, dirs, wl, seed, 1000, 0, m)
+    for j, want in enumerate(whole):
+        for key in ("rec_distinct", "rec_crossings", "rec_bins"):
+            assert np.array_equal(sets[j][key], want[key]), (j, key)
+        assert np.allclose(sets[j]["rec_sums"], want["rec_sums"], rtol=1e-12, atol=0)
+
+
 def test_the_engine_runs_from_worker_threads_like_the_studio_consumer():
     """The reference's streaming consumer drives the engine from an executor thread
     (studio/server.py:225-230); two threads may also trace two scenes on one GPU at once.  Results are
