@@ -1,0 +1,178 @@
+"""Coatings pinned by HAND-TRACED rays.
+
+The reference expresses its coatings as Python surface delegates (pvtrace/device/lsc.py:22-86,
+examples/006 Coatings.ipynb cell 3); its native engine cannot express them, so no reference kernel output
+exists to compare with.  What the delegates imply IS checkable ray by ray when the ray never meets a
+probabilistic decision: a back-surface mirror reflects with R = 1 (lsc.py:36-37), a solar-cell edge has R = 0
+and transmits undeviated (:38-45, :55-63), every other face of the n = 1.5 slab totally reflects a 45-degree
+ray (critical angle 41.8 degrees; Fresnel, material/surface.py), the mirror quadrant of the Coatings notebook
+reflects from either side.  The expected event sequences below come from a 25-line specular box walk written
+here from plain geometry -- not from the oracle, not from the kernel -- and are compared row by row (kind,
+ids, position, direction, outward normal) with the CPU referee and, on a GPU box, with the HIP engine.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pvtrace_amd import LSC
+from pvtrace_amd.engine import compile_scene
+from tests import scenes
+
+GENERATE, REFLECT, TRANSMIT, EXIT = 0, 1, 2, 7
+S = np.sqrt(0.5)
+
+
+def box_walk(start, direction, half, cells, max_bounces=64):
+    """Specular walk inside the axis-aligned box |x_a| <= half[a]: [(kind, position, direction after,
+    outward normal)], ending with the TRANSMIT through a face listed in `cells` ((axis, sign) pairs)."""
+    p, d = np.array(start, float), np.array(direction, float)
+    events = []
+    for _ in range(max_bounces):
+        ts = [((half[a] if d[a] > 0 else -half[a]) - p[a]) / d[a] if d[a] != 0 else np.inf for a in range(3)]
+        a = int(np.argmin(ts))
+        assert np.sort(ts)[1] - ts[a] > 1e-9, "ray aimed at an edge: choose another start"
+        p = p + ts[a] * d
+        normal = np.zeros(3)
+        normal[a] = 1.0 if d[a] > 0 else -1.0
+        if (a, int(normal[a])) in cells:
+            events.append((TRANSMIT, p.copy(), d.copy(), normal))
+            return events, p, d
+        d = d.copy()
+        d[a] = -d[a]
+        events.append((REFLECT, p.copy(), d.copy(), normal))
+    raise AssertionError("walk did not end")
+
+
+def leave_world(p, d, half_world):
+    ts = [((half_world[a] if d[a] > 0 else -half_world[a]) - p[a]) / d[a] if d[a] != 0 else np.inf for a in range(3)]
+    return p + min(ts) * d
+
+
+def trace(tracer, compiled, starts, dirs, max_events=96):
+    n = len(starts)
+    return tracer(compiled, np.array(starts, float), np.array(dirs, float), np.full(n, 600.0), 3, 1000,
+                  max_events, 0, 1, 1)
+
+
+def oracle_tracer(compiled, pos, dirs, wl, *args):
+    return O.trace_bundle(compiled, pos, dirs, wl, *args, math_mode=O.MATH_PORTABLE)
+
+
+def gpu_tracer(compiled, pos, dirs, wl, *args):
+    from pvtrace_amd.engine import _kernel
+
+    return _kernel.trace_bundle(compiled, pos, dirs, wl, *args)
+
+
+def check_rows(data, j, max_events, expected, ids, atol=1e-11):
+    """expected: [(kind, position, direction, normal or None)]; ids: [(hit, container, adjacent)] per row."""
+    assert int(data["counts"][j]) == len(expected), (j, int(data["counts"][j]), len(expected))
+    for k, ((kind, pos, direc, normal), (hit, container, adjacent)) in enumerate(zip(expected, ids)):
+        row = j * max_events + k
+        assert int(data["kind"][row]) == kind, (j, k)
+        assert (int(data["hit"][row]), int(data["container"][row]), int(data["adjacent"][row])) == (hit, container, adjacent), (j, k)
+        assert np.allclose(data["position"][row], pos, rtol=0, atol=atol), (j, k, data["position"][row], pos)
+        assert np.allclose(data["direction"][row], direc, rtol=0, atol=atol), (j, k)
+        if normal is not None:
+            assert np.allclose(data["normal"][row], normal, rtol=0, atol=0), (j, k)
+
+
+def mirror_and_cells_scene():
+    lsc = LSC((5.0, 5.0, 1.0))
+    lsc.add_absorber("clear", 1e-12)       # below the kernel's ALPHA_ZERO (_kernel.pyx:32): no absorption draw at all
+    lsc.add_back_surface_mirror()
+    lsc.add_solar_cell({"right", "far"})
+    return lsc.scene
+
+
+TRAPPED_RAYS = [   # start inside the slab, 45 degrees to every face they can reach
+    ((0.25, 0.0, 0.0), (S, 0.0, -S)), ((-0.85, 0.3, 0.1), (S, 0.0, S)), ((1.9, -1.0, -0.2), (-S, 0.0, -S)),
+    ((0.0, 0.35, 0.0), (0.0, S, -S)), ((0.4, -1.15, 0.2), (0.0, S, S)), ((-2.0, 2.1, -0.3), (0.0, -S, S)),
+    ((-2.2, 0.0, 0.45), (-S, 0.0, S)), ((0.0, -2.3, -0.45), (0.0, -S, -S)),
+]
+
+
+def run_mirror_and_cells(tracer):
+    scene = mirror_and_cells_scene()
+    compiled = compile_scene(scene)
+    assert compiled.node_names == ["World", "LSC"]
+    data = trace(tracer, compiled, [r[0] for r in TRAPPED_RAYS], [r[1] for r in TRAPPED_RAYS])
+    for j, (start, direction) in enumerate(TRAPPED_RAYS):
+        walk, p, d = box_walk(start, direction, (2.5, 2.5, 0.5), cells={(0, 1), (1, 1)})
+        expected = [(GENERATE, start, direction, None)] + walk + [(EXIT, leave_world(p, d, (250.0, 250.0, 50.0)), d, None)]
+        # inside the slab: the slab is both the surface hit and the container, the world lies beyond
+        ids = [(-1, -1, -1)] + [(1, 1, 0)] * len(walk) + [(0, 0, -1)]
+        check_rows(data, j, 96, expected, ids)
+        kinds = [e[0] for e in walk]
+        assert kinds[-1] == TRANSMIT and set(kinds[:-1]) <= {REFLECT}
+        assert np.array_equal(walk[-1][2], walk[-2][2] if len(walk) > 1 else np.array(direction))   # undeviated
+    # the two rays that start towards -x / -y must cross the whole slab: many total reflections first
+    assert int(data["counts"][6]) > 8 and int(data["counts"][7]) > 8
+
+
+GAP_RAYS = [   # start in the air gap between the slab and the mirror sheet, heading down and outwards (3-4-5)
+    ((2.4, 0.0, -0.55), (0.6, 0.0, -0.8)), ((-2.4, 0.5, -0.55), (-0.6, 0.0, -0.8)),
+    ((0.3, 2.4, -0.55), (0.0, 0.6, -0.8)), ((-1.0, -2.4, -0.55), (0.0, -0.6, -0.8)),
+]
+
+
+def run_air_gap_mirror(tracer):
+    """add_air_gap_mirror: a thin sheet of the world's index 0.125 cm under the slab whose faces reflect with
+    R = 1 (lsc.py:65-71, :186-203).  [The reference's *specular* branch returns the Fresnel TRANSMITTED
+    direction of an index-matched interface, i.e. the unchanged direction (lsc.py:74-77) -- a slip that
+    turns its mirror into a window; the documented intent, a specular mirror, is what is built here.]"""
+    lsc = LSC((5.0, 5.0, 1.0))
+    lsc.add_absorber("clear", 1e-12)
+    lsc.add_air_gap_mirror(lambertian=False)
+    compiled = compile_scene(lsc.scene)
+    assert compiled.node_names == ["World", "LSC", "Air Gap Mirror"]
+    assert np.allclose(compiled.local_to_world[2][:3, 3], (0, 0, -0.75)) and np.allclose(compiled.geom_params[2][:3], (5, 5, 0.25))
+    data = trace(tracer, compiled, [r[0] for r in GAP_RAYS], [r[1] for r in GAP_RAYS])
+    for j, (start, direction) in enumerate(GAP_RAYS):
+        p, d = np.array(start), np.array(direction)
+        t = (-0.625 - p[2]) / d[2]                      # top face of the sheet
+        hit = p + t * d
+        assert abs(hit[0]) < 2.5 and abs(hit[1]) < 2.5
+        up = d * (1, 1, -1)
+        at_slab_height = hit + (0.125 / up[2]) * up     # back at z = -0.5: already outside the slab's footprint
+        assert max(abs(at_slab_height[0]), abs(at_slab_height[1])) > 2.5
+        expected = [(GENERATE, start, direction, None), (REFLECT, hit, up, (0.0, 0.0, 1.0)),
+                    (EXIT, leave_world(hit, up, (250.0, 250.0, 50.0)), up, None)]
+        # in the gap the world contains the ray; the sheet is what it hits and what lies beyond the surface
+        check_rows(data, j, 96, expected, [(-1, -1, -1), (2, 0, 2), (0, 0, -1)])
+
+
+def run_partial_top_mirror(tracer):
+    """Coatings.ipynb cell 3: R = 1 on the top face where local x > 0 and y > 0, from either side."""
+    compiled = compile_scene(scenes.coated_slab(recorders=False, scatter=0.0))
+    outside = [((1.0, 1.0, 2.0), (0.0, 0.0, -1.0)), ((4.9, 0.1, 3.0), (0.0, 0.0, -1.0)),
+               ((0.5, 2.0, 1.0), (0.6, 0.0, -0.8)), ((3.0, 4.0, 2.5), (0.0, -0.6, -0.8))]
+    inside = [((1.0, 1.0, 0.0), (0.0, 0.0, 1.0)), ((2.0, 3.0, -0.2), (0.28, 0.0, 0.96)),
+              ((4.0, 0.5, 0.3), (0.0, 0.28, 0.96)), ((0.2, 0.2, 0.0), (0.0, 0.0, 1.0))]
+    data = trace(tracer, compiled, [r[0] for r in outside + inside], [r[1] for r in outside + inside], max_events=16)
+    for j, (start, direction) in enumerate(outside):   # GENERATE, REFLECT off the coated quadrant, EXIT: nothing random
+        p, d = np.array(start), np.array(direction)
+        hit = p + ((0.5 - p[2]) / d[2]) * d
+        assert hit[0] > 0 and hit[1] > 0 and hit[0] < 5 and hit[1] < 5
+        up = d * (1, 1, -1)
+        expected = [(GENERATE, start, direction, None), (REFLECT, hit, up, (0.0, 0.0, 1.0)),
+                    (EXIT, leave_world(hit, up, (7.5, 7.5, 7.5)), up, None)]
+        check_rows(data, j, 16, expected, [(-1, -1, -1), (1, 0, 1), (0, 0, -1)])
+    for j, (start, direction) in enumerate(inside, start=len(outside)):   # steeper than the critical angle: only the coating can reflect them
+        p, d = np.array(start), np.array(direction)
+        hit = p + ((0.5 - p[2]) / d[2]) * d
+        assert hit[0] > 0 and hit[1] > 0
+        row = j * 16 + 1
+        assert int(data["kind"][row]) == REFLECT and int(data["hit"][row]) == 1 and int(data["container"][row]) == 1
+        assert np.allclose(data["position"][row], hit, atol=1e-12) and np.allclose(data["direction"][row], d * (1, 1, -1), atol=1e-12)
+
+
+@pytest.mark.parametrize("case", [run_mirror_and_cells, run_air_gap_mirror, run_partial_top_mirror])
+def test_hand_traced_rays_on_the_referee(case):
+    case(oracle_tracer)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [run_mirror_and_cells, run_air_gap_mirror, run_partial_top_mirror])
+def test_hand_traced_rays_on_the_hip_engine(case):
+    case(gpu_tracer)

@@ -61,3 +61,56 @@ def test_absorber_depth_known_answer():
         depth = -O.math("log", [1.0 - u], mode)[0] / 10.0
         assert depth == pytest.approx(0.1255930762965882, rel=1e-15)
         assert -0.5 + depth == pytest.approx(-0.3744069237034118, rel=1e-14)
+
+
+# ---- a second, independent accuracy referee -----------------------------------------------------------
+# The GPU and its CPU referee both evaluate pvt_math.h, so a flaw in that header would be common-mode; the
+# libm comparison above is one outside check.  These are two more, neither of which shares code with libm's
+# double-precision paths: glibc's 80-bit long-double functions at 10^6 points per function, and mpmath
+# (arbitrary precision, 40 digits) at 2*10^4.  The error is measured against the exact value, in units of
+# the last place of the double result: < 1 ulp everywhere on the tracer's domains.
+BIG = 1_000_000
+RNG2 = np.random.default_rng(20260928)
+DOMAINS = {
+    "log": lambda n: 1.0 - RNG2.random(n),              # log(1 - u), u in [0, 1)  (_kernel.pyx:765)
+    "sin": lambda n: RNG2.random(n) * 2 * np.pi,        # azimuths and polar angles
+    "cos": lambda n: RNG2.random(n) * 2 * np.pi,
+    "asin": lambda n: RNG2.random(n) * 2 - 1,
+    "acos": lambda n: np.concatenate([RNG2.random(n // 2) * 2 - 1, 1.0 - RNG2.random(n - n // 2) ** 4]),  # incl. near 1 (grazing exits)
+}
+LONG = {"log": np.log, "sin": np.sin, "cos": np.cos, "asin": np.arcsin, "acos": np.arccos}
+
+
+def _ulp_error(y, exact_longdouble):
+    err = np.abs(y.astype(np.longdouble) - exact_longdouble)
+    scale = np.spacing(np.abs(y)).astype(np.longdouble)
+    return (err / scale).astype(np.float64)
+
+
+@pytest.mark.parametrize("fn", sorted(DOMAINS))
+def test_portable_within_one_ulp_of_long_double_evaluation_at_a_million_points(fn):
+    assert np.finfo(np.longdouble).nmant >= 63, "needs x87 extended precision"
+    x = DOMAINS[fn](BIG)
+    y = O.math(fn, x, math_mode=O.MATH_PORTABLE)
+    exact = LONG[fn](x.astype(np.longdouble))
+    keep = np.abs(exact) > 1e-300          # (sin/cos exactly at a zero crossing: the ulp of ~0 is meaningless)
+    ulps = _ulp_error(y[keep], exact[keep])
+    assert ulps.max() < 1.0, (fn, float(ulps.max()), float(x[keep][np.argmax(ulps)]))
+    assert np.mean(ulps <= 0.5 + 1e-9) > 0.85            # mostly correctly rounded
+
+
+@pytest.mark.parametrize("fn", sorted(DOMAINS))
+def test_portable_within_one_ulp_of_mpmath(fn):
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.dps = 40
+    x = DOMAINS[fn](20_000)
+    y = O.math(fn, x, math_mode=O.MATH_PORTABLE)
+    f = getattr(mpmath, fn)
+    worst = 0.0
+    for xv, yv in zip(x.tolist(), y.tolist()):
+        exact = f(mpmath.mpf(xv))
+        if abs(exact) < 1e-300:
+            continue
+        ulp = mpmath.mpf(float(np.spacing(abs(yv))))
+        worst = max(worst, float(abs(mpmath.mpf(yv) - exact) / ulp))
+    assert worst < 1.0, (fn, worst)
