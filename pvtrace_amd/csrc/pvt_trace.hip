@@ -446,14 +446,14 @@ hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const
 #if PVT_DEV_VARIANTS
     if (emit || mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
     if constexpr (TAB_LDS && SEENW == 1)
-        hipLaunchKernelGGL((trace_kernel<RECORD, true, 1, false, false>), dim3(grid), dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((trace_kernel_w4<RECORD, true, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
 #else
     if (emit) {
         if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, true>), dim3(grid), dim3(kBlock), lds, st, a);
-        else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, false>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((trace_kernel_w4<RECORD, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
     } else {
         if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
-        else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, false>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((trace_kernel_w4<RECORD, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
     }
 #endif
     return hipGetLastError();

@@ -432,7 +432,7 @@ struct Seen {
 // MESH: the scene has triangle-mesh nodes.  The BVH walk costs ~35 VGPRs, so scenes made of
 // analytic shapes run the variant compiled without it (one more wave per SIMD).
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
-__global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
+__device__ __forceinline__ void trace_body(const KArgs& A) {
     extern __shared__ double smem[];
     const Lay L = A.lay;
     const bool coated = A.n_coat > 0;  // wave-uniform
@@ -1404,6 +1404,19 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
             unsigned int v = acc_bins[i];
             if (v) atomicAdd(out_bins + i, (unsigned long long)v);
         }
+}
+
+// Entry points.  Scenes of analytic shapes run four waves per SIMD: the history-keeping variants need a few
+// registers more than the 128 that allows, and are told to stay within them (the compiler then parks a
+// dozen rarely-used values in scratch) -- measured faster than three waves per SIMD.  Mesh variants
+// (BVH walk, ~170-190 registers) are left alone.
+template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
+__global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
+    trace_body<RECORD, TAB_LDS, SEENW, EMIT, MESH>(A);
+}
+template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_w4(KArgs A) {
+    trace_body<RECORD, TAB_LDS, SEENW, EMIT, false>(A);
 }
 
 }  // namespace

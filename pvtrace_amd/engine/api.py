@@ -126,11 +126,28 @@ class EngineResult:
                 self.data["rec_sums"][r], bins)
         return out
 
+    @property
+    def packed(self):
+        """True when the event log holds only the rows that were written (`simulate(packed_log=True)`):
+        the rows of recorded ray j are ``row_start[j] : row_start[j+1]`` instead of the reference's
+        ``j*max_events : j*max_events + counts[j]``."""
+        return "row_start" in self.data
+
+    def rows_of(self, j):
+        """Slice of the event-log columns holding the history of recorded ray j (either layout)."""
+        if self.packed:
+            return slice(int(self.data["row_start"][j]), int(self.data["row_start"][j + 1]))
+        first = j * self.max_events
+        return slice(first, first + int(self.data["counts"][j]))
+
     def event_counts(self):
         """Counter of logged events (recorded rays only)."""
         counts = self.data["counts"]
         if len(counts) == 0:
             return collections.Counter()
+        if self.packed:
+            values, tallies = np.unique(self.data["kind"], return_counts=True)
+            return collections.Counter({Event(int(v)): int(t) for v, t in zip(values, tallies)})
         kinds = self.data["kind"].reshape(self.num_recorded, self.max_events)
         valid = np.arange(self.max_events)[None, :] < counts[:, None]
         values, tallies = np.unique(kinds[valid], return_counts=True)
@@ -147,9 +164,9 @@ class EngineResult:
         d = self.data
         which = self.recorded_indices
         for j in range(self.num_recorded):
-            first = j * self.max_events
+            rows = self.rows_of(j)
             steps = []
-            for row in range(first, first + int(d["counts"][j])):
+            for row in range(rows.start, rows.stop):
                 sid = int(d["source"][row])
                 source = self.sources[int(which[j])] if sid < 0 else self._component(sid)
                 ray = Ray(
@@ -192,8 +209,10 @@ def _default_device():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def download(compiled, tallies, log, n_rays, record_every, max_events):
-    """Device buffers -> the reference's `data` dict (host numpy)."""
+def download(compiled, tallies, log, n_rays, record_every, max_events, packed=False):
+    """Device buffers -> the reference's `data` dict (host numpy).  `packed`: keep only the written
+    rows of the event log (plus `row_start`, see `EngineResult.packed`) instead of rebuilding the
+    reference's dense `rows = recorded * max_events` arrays."""
     nrec = int(compiled.rec_node.shape[0])
     n_recorded = native.num_recorded(n_rays, record_every)
     rows = n_recorded * max_events
@@ -223,7 +242,11 @@ def download(compiled, tallies, log, n_rays, record_every, max_events):
 
     counts = log["counts"][:n_recorded]
     used = int(counts.sum().item())
-    sparse = used < 0.6 * rows
+    sparse = packed or used < 0.6 * rows
+    if packed:
+        starts = np.zeros(n_recorded + 1, dtype=np.int64)
+        np.cumsum(data["counts"], out=starts[1:])
+        data["row_start"] = starts
     if sparse:
         written = (torch.arange(max_events, device=counts.device, dtype=torch.int32)[None, :]
                    < counts[:, None]).reshape(-1)
@@ -231,14 +254,17 @@ def download(compiled, tallies, log, n_rays, record_every, max_events):
         index_host = index.cpu().numpy()
     for name, dtype, width in native.EVENT_LOG_COLUMNS:
         col = log[name][: rows * width]
-        if sparse:
+        if packed:
+            view = col.view(rows, 3) if width == 3 else col
+            data[name] = view[index].cpu().numpy() if used else np.zeros((0, 3) if width == 3 else 0, dtype=dtype)
+        elif sparse:
             fill = -1 if name in ("hit", "container", "adjacent", "component", "source") else 0
             shape = (rows, 3) if width == 3 else (rows,)
             # zero columns stay uncommitted (calloc); the -1 fill is the reference's eager cost too
             host = np.zeros(shape, dtype=dtype) if fill == 0 else np.full(shape, fill, dtype=dtype)
             if used:
-                packed = (col.view(rows, 3) if width == 3 else col)[index].cpu().numpy()
-                host[index_host] = packed
+                written_rows = (col.view(rows, 3) if width == 3 else col)[index].cpu().numpy()
+                host[index_host] = written_rows
             data[name] = host
         else:
             host = col.cpu().numpy()
@@ -291,7 +317,8 @@ class Session:
         self.close()
 
     def submit(self, num_rays, seed, maxsteps=1000, max_events=128, emit_method="kT", record_every=1,
-               emit_seed=None, ray_offset=0, workgroups_per_cu=0, host_rays=None, tally_bundle=0):
+               emit_seed=None, ray_offset=0, workgroups_per_cu=0, host_rays=None, tally_bundle=0,
+               packed_log=False):
         """Enqueue one bundle on one of two HIP streams and return a handle for `collect`.
         Two bundles may be in flight: the next one is traced while the caller consumes the
         previous result.  `host_rays`: (positions, directions, wavelengths, sources) already emitted
@@ -353,7 +380,7 @@ class Session:
                 stop.record(stream)
         return {"stream": stream, "tallies": tallies, "log": log, "events": (start, stop), "tic": tic,
                 "rays": rays, "sources": sources, "num_rays": num_rays, "record_every": record_every,
-                "max_events": max_events, "tally_bundle": int(tally_bundle)}
+                "max_events": max_events, "tally_bundle": int(tally_bundle), "packed_log": bool(packed_log)}
 
     def collect(self, pending, wall_clock=False):
         """Wait for a submitted bundle and bring its results to the host -> `EngineResult`.
@@ -367,7 +394,7 @@ class Session:
             kernel_ms = pending["events"][0].elapsed_time(pending["events"][1])
             with torch.cuda.stream(pending["stream"]):
                 data = download(self.compiled, pending["tallies"], pending["log"], pending["num_rays"],
-                                pending["record_every"], pending["max_events"])
+                                pending["record_every"], pending["max_events"], packed=pending.get("packed_log", False))
         return EngineResult(self.compiled, data, pending["sources"], pending["max_events"],
                             pending["record_every"], wall if wall_clock else kernel_ms * 1e-3,
                             kernel_ms=kernel_ms)
@@ -430,8 +457,15 @@ def simulate(
     emit_seed=None,
     ray_offset=0,
     devices=None,
+    packed_log=False,
 ):
     """Trace `num_rays` through `scene` on the GPU.
+
+    `packed_log`: return the event log PACKED -- only the rows that were written, with `data["row_start"]`
+    giving each recorded ray's slice (`EngineResult.rows_of`, `.histories()` and `.event_counts()` work on
+    either layout) -- instead of the reference's dense `recorded * max_events` rows, of which a ray fills a
+    dozen: with the defaults (`record_every=1`, `max_events=128`) the dense arrays are 117 bytes x 128 per ray
+    and rebuilding them on the host costs far more than the trace.
 
     `devices`: a list of GPU ids (repeats allowed) — the bundle is split over them by contiguous
     index range inside this one call (one host thread and one resident scene per entry); ray i keeps
@@ -455,12 +489,14 @@ def simulate(
     if devices is not None:
         if device is not None:
             raise ValueError("give `device` or `devices`, not both")
+        if packed_log:
+            raise ValueError("packed_log is per device; use `device`")
         return _simulate_on_devices(scene, num_rays, seed, list(devices), maxsteps, max_events, emit_method,
                                     record_every, emission, emit_seed, ray_offset)
     with Session(scene, device=device, emission=emission) as session:
         return session.run(num_rays, seed, maxsteps=maxsteps, max_events=max_events,
                            emit_method=emit_method, record_every=record_every,
-                           emit_seed=emit_seed, ray_offset=ray_offset)
+                           emit_seed=emit_seed, ray_offset=ray_offset, packed_log=packed_log)
 
 
 def merge_shards(results):

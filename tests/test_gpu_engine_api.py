@@ -419,6 +419,27 @@ def test_grouped_stream_bundles_equal_bundles_traced_one_by_one(emission):
         assert np.allclose(sets[j]["rec_sums"], want["rec_sums"], rtol=1e-12, atol=0)
 
 
+def test_packed_event_log_holds_exactly_the_written_rows():
+    """`packed_log=True` (opt-in): the same histories without the reference's dense padding."""
+    scene = scenes.bench_slab(recorders=True)
+    dense = engine.simulate(scene, 3000, seed=51, emit_seed=4, max_events=64)
+    packed = engine.simulate(scene, 3000, seed=51, emit_seed=4, max_events=64, packed_log=True)
+    assert packed.packed and not dense.packed
+    assert np.array_equal(packed.data["counts"], dense.data["counts"])
+    assert packed.data["row_start"][-1] == dense.data["counts"].sum() == len(packed.data["kind"])
+    for key in ("rec_distinct", "rec_crossings", "rec_bins"):
+        assert np.array_equal(packed.data[key], dense.data[key])
+    for j in (0, 1, 17, 2999):
+        a, b = dense.rows_of(j), packed.rows_of(j)
+        for name in ("kind", "hit", "container", "adjacent", "component", "source", "position", "direction",
+                     "normal", "wavelength", "travelled", "duration"):
+            assert np.array_equal(dense.data[name][a], packed.data[name][b]), (j, name)
+    assert packed.event_counts() == dense.event_counts()
+    for h_dense, h_packed in zip(dense.histories(), packed.histories()):
+        assert [(e, m) for _, e, m in h_dense] == [(e, m) for _, e, m in h_packed]
+        assert [r.position for r, _, _ in h_dense] == [r.position for r, _, _ in h_packed]
+
+
 def test_the_engine_runs_from_worker_threads_like_the_studio_consumer():
     """The reference's streaming consumer drives the engine from an executor thread
     (studio/server.py:225-230); two threads may also trace two scenes on one GPU at once.  Results are

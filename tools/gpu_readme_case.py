@@ -14,3 +14,10 @@ for n in (100_000, 1_000_000):
           f"kernel+memsets {r.kernel_ms:.1f} ms, end-to-end incl. emission/alloc/15GB download {wall:.2f} s ({n/wall/1e6:.2f} M rays/s); "
           f"events {int(r.data['counts'].sum())}", flush=True)
     del r
+
+for n in (1_000_000,):
+    tic = time.perf_counter()
+    r = engine.simulate(scene, n, seed=1, packed_log=True)
+    wall = time.perf_counter() - tic
+    print(f"n={n} packed_log=True: trace {r.elapsed*1e3:.1f} ms, end-to-end {wall:.3f} s ({n/wall/1e6:.2f} M rays/s); "
+          f"rows {len(r.data['kind'])}", flush=True)
