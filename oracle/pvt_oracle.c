@@ -518,11 +518,18 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
             container = hit; adjacent = -1;
         } else {
             container = -1;
-            double best = INFINITY;
-            for (int node = 0; node < S->n_nodes; node++)
-                if (node_hits[node] == 1 && node_min_t[node] < best) { best = node_min_t[node]; container = node; }
+            int next_holder = -1;
+            double best = INFINITY, next_best = INFINITY;
+            for (int node = 0; node < S->n_nodes; node++) {
+                /* EXTENSION: a (possibly non-convex) mesh holds the ray when crossed an odd number of times */
+                int holds = S->geom_type[node] == PVT_GEOM_MESH ? (node_hits[node] & 1) : node_hits[node] == 1;
+                if (!holds) continue;
+                if (node_min_t[node] < best) { next_best = best; next_holder = container; best = node_min_t[node]; container = node; }
+                else if (node_min_t[node] < next_best) { next_best = node_min_t[node]; next_holder = node; }
+            }
             if (container < 0) container = hit;
             adjacent = (container == hit) ? hit_node_id[second] : hit;
+            if (container == hit && next_holder >= 0 && S->geom_type[hit] == PVT_GEOM_MESH) adjacent = next_holder;
         }
 
         if (count > maxsteps) { /* :716-723 */

@@ -26,13 +26,29 @@ EPS_ZERO = 2.220446049250313e-13
 KB_EV = 1.380649e-23 / 1.60217662e-19
 
 
+def _holders(crossings):
+    """Crossings of the nodes the ray starts inside of, nearest first: crossed exactly once
+    (photon_tracer.py:26-57) -- or, for a triangle mesh, which may be non-convex, an odd number of
+    times (extension: Mesh.contains semantics, geometry/mesh.py:29-32)."""
+    from pvtrace_amd.geometry import Mesh
+
+    count = collections.Counter(id(x.hit) for x in crossings)
+    firsts, seen = [], set()
+    for x in sorted(crossings, key=lambda c: c.distance):
+        if id(x.hit) in seen:
+            continue
+        seen.add(id(x.hit))
+        n = count[id(x.hit)]
+        if (n % 2 == 1) if isinstance(x.hit.geometry, Mesh) else n == 1:
+            firsts.append(x)
+    return firsts
+
+
 def find_container(crossings):
-    """The node the ray is inside: the nearest node crossed exactly once (photon_tracer.py:26-57)."""
+    """The node the ray is inside (photon_tracer.py:26-57)."""
     if len(crossings) == 1:
         return crossings[0].hit
-    count = collections.Counter(id(x.hit) for x in crossings)
-    once = [x for x in crossings if count[id(x.hit)] == 1]
-    return min(once, key=lambda x: x.distance).hit
+    return _holders(crossings)[0].hit
 
 
 def next_hit(scene, ray):
@@ -45,6 +61,12 @@ def next_hit(scene, ray):
         return first.hit, (first.hit, None), first.point, first.distance
     container = find_container(crossings)
     adjacent = crossings[1].hit if container is first.hit else first.hit
+    from pvtrace_amd.geometry import Mesh
+
+    if container is first.hit and isinstance(first.hit.geometry, Mesh):
+        holders = _holders(crossings)
+        if len(holders) > 1:      # beyond the surface of a mesh: the next node that holds the ray
+            adjacent = holders[1].hit
     return first.hit, (container, adjacent), first.point, first.distance
 
 

@@ -707,6 +707,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 int nhits = 0, n1 = -1, n2 = -1, cnode = -1;
                 tri1 = -1;
                 double t1 = INFINITY, t2 = INFINITY, cbest = INFINITY;
+                int c2node = -1;            // (mesh scenes) the next-nearest node that holds the ray
+                double c2best = INFINITY;
                 V3 d{0, 0, 0};
                 double inv[3] = {0, 0, 0};
                 bool inv_ok = false;   // wave-uniform
@@ -877,7 +879,17 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         if (x * x + y * y <= radius * radius && t > kEps) fold(t);
                     }
                 }
-                    if (nl == 1 && tfirst < cbest) { cbest = tfirst; cnode = node; }
+                    // The container is the nearest node the ray starts inside of: crossed exactly once for the
+                    // reference's convex shapes (:696-706); a triangle mesh may be non-convex, so it holds the
+                    // ray when it is crossed an ODD number of times (extension; Mesh.contains semantics,
+                    // pvtrace/geometry/mesh.py:29-32)
+                    const bool holds = (MESH && gt == PVT_GEOM_MESH) ? (nl & 1) != 0 : nl == 1;
+                    if (holds) {
+                        if (tfirst < cbest) {
+                            if constexpr (MESH) { c2best = cbest; c2node = cnode; }
+                            cbest = tfirst; cnode = node;
+                        } else if (MESH && tfirst < c2best) { c2best = tfirst; c2node = node; }
+                    }
                 }
 
                 PVT_MARK(1);  // node loop
@@ -890,6 +902,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     else {
                         container = (cnode >= 0) ? cnode : hit;
                         adjacent = (container == hit) ? n2 : hit;
+                        if constexpr (MESH) {
+                            // leaving a mesh: the second-nearest crossing may be the same (non-convex) mesh
+                            // again; what lies beyond the surface is the next node that holds the ray
+                            if (container == hit && c2node >= 0 && T.iv(hit * NI + NI_GEOM) == PVT_GEOM_MESH) adjacent = c2node;
+                        }
                     }
                     ev_container = container;
                     if (count > A.maxsteps) {  // (:716-723)

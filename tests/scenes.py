@@ -367,6 +367,41 @@ def mesh_gem():
     return Scene(world)
 
 
+def l_prism_mesh(material=None):
+    """A NON-CONVEX closed mesh: the L-shaped hexagon (0,0)-(2,0)-(2,1)-(1,1)-(1,2)-(0,2) extruded over
+    z in [0, 1] (24 triangles; the extra vertex (0,1) avoids a T-junction)."""
+    poly = [(0, 0), (2, 0), (2, 1), (1, 1), (1, 2), (0, 2), (0, 1)]
+    tris = [(0, 1, 2), (0, 2, 3), (0, 3, 6), (6, 3, 4), (6, 4, 5)]
+    n = len(poly)
+    verts = [(x, y, 0.0) for x, y in poly] + [(x, y, 1.0) for x, y in poly]
+    faces = [(a, c, b) for a, b, c in tris] + [(a + n, b + n, c + n) for a, b, c in tris]
+    for i in range(n):
+        j = (i + 1) % n
+        faces += [(i, j, j + n), (i, j + n, i + n)]
+    return Mesh((np.array(verts, dtype=np.float64), np.array(faces, dtype=np.int32)), material=material, recenter=False)
+
+
+def l_prism(recorders=True):
+    """Glass L-prism (non-convex mesh) with a dye, lit from inside one arm across the notch: a ray that
+    starts inside the mesh crosses its surface three times before reaching the world."""
+    world = Node(name="world", geometry=Sphere(10.0, material=Material(refractive_index=1.0)))
+    x = np.linspace(400.0, 700.0, 31)
+    dye = Luminophore(np.column_stack((x, 2.0 * gaussian(x, 1.0, 480.0, 50.0))),
+                      emission=np.column_stack((x, gaussian(x, 1.0, 600.0, 30.0))), quantum_yield=0.95, name="dye")
+    prism = Node(name="L", parent=world, geometry=l_prism_mesh(Material(refractive_index=1.5, components=[dye, Absorber(0.05, name="bg")])))
+    prism.rotate(0.3, (0.2, 1.0, 0.1))
+    inside = Node(name="inside-lamp", parent=prism, light=Light(direction=Cone(0.6), wavelength=lambda: 470.0, name="inside-lamp"))
+    inside.location = (1.6, 0.5, 0.5)       # in the x-arm ...
+    inside.look_at((-1.0, 2.0, 0.0))        # ... aimed across the notch at the y-arm
+    outside = Node(name="outside-lamp", parent=world, light=Light(position=CircularMask(1.5), direction=Cone(0.3), name="outside-lamp"))
+    outside.location = (1.0, 1.0, -4.0)
+    if recorders:
+        prism.recorders = [Recorder("in", event="entering"), Recorder("out", event="escaping", histograms=[Histogram("wavelength", 400, 700, 30)]),
+                           Recorder("lost", event="lost"), Recorder("refl", event="reflected")]
+        world.recorders = [Recorder("exit", event="exit")]
+    return Scene(world)
+
+
 REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
     "hello_world": hello_world,
     "lsc_equivalent": lsc_equivalent,
@@ -379,6 +414,7 @@ REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
 }
 EXTENSION_SCENES = {   # need an extension: coatings, hist spectra, meshes
     "coated_slab": coated_slab,
+    "l_prism": l_prism,
     "lambertian_sheet": lambertian_sheet,
     "hist_slab": hist_slab,
     "mesh_lsc": mesh_lsc,

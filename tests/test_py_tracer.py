@@ -75,11 +75,12 @@ def test_config1_hello_world_one_thousand_rays_in_pure_python():
 
 
 @pytest.mark.parametrize("name,n_python", [("fresnel_box", 800), ("bench_slab", 400), ("lsc_equivalent", 400),
-                                           ("nested_cylinders", 600), ("mesh_gem", 600)])
+                                           ("nested_cylinders", 600), ("mesh_gem", 600), ("l_prism", 500)])
 def test_python_tracer_and_table_driven_path_agree(name, n_python):
     """reference tests/test_engine.py:139-167 (Fresnel scene, dye slab) plus the headline LSC and the
     nested rotated cylinders, and the faceted gem (triangle meshes inside a mesh world, HG
-    scatterer in a rotated frame): two implementations that share no code below the scene objects."""
+    scatterer in a rotated frame) and the non-convex L-prism lit from inside (crossing-parity containment):
+    two implementations that share no code below the scene objects."""
     scene = scenes.bench_slab(recorders=False) if name == "bench_slab" else scenes.ALL_SCENES[name]()
     py, _ = python_counts(scene, n_python, seed=42)
     ref, _ = referee_counts(scene, 20000, seed=7)
