@@ -5,7 +5,7 @@
 // the traversal is `i = hit ? i + 1 : skip[i]` with no per-lane stack in scratch or LDS.  A
 // photon needs EVERY forward crossing of a mesh (the container rule counts them,
 // _kernel.pyx:684-714), so front-to-back ordering buys nothing and a fixed order is free.
-// Leaves hold one triangle (up to 8 for tiny meshes), pre-gathered (vertices + face normal +
+// The tree is built with a binned surface-area heuristic.  Leaves hold one triangle (up to 8 for tiny meshes), pre-gathered (vertices + face normal +
 // face id) so a leaf is one contiguous run of 104-byte records.  Nodes are 32 bytes (f32 boxes
 // rounded outwards): culling is only a filter, the triangle test itself stays f64.
 //
@@ -109,7 +109,11 @@ private:
                 tris_.push_back(t);
             }
         } else {
-            // median split of the centroids along their widest axis
+            // Binned surface-area heuristic: for each axis the centroids fall into kBins bins; the split plane
+            // between two bins that minimises  area(left) * n_left + area(right) * n_right  wins (the expected
+            // number of triangle tests of a random ray).  Degenerate cases (all centroids in one bin on every
+            // axis) fall back to the median along the widest axis.  Which tree is built never changes a
+            // result: a photon collects EVERY crossing and orders them by (t, face).
             double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (int k = begin; k < end; k++)
                 for (int a = 0; a < 3; a++) {
@@ -120,12 +124,72 @@ private:
             int axis = 0;
             if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
             if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
-            const int mid = (begin + end) / 2;
-            std::nth_element(order_.begin() + begin, order_.begin() + mid, order_.begin() + end,
-                             [&](int a, int b) {
-                                 double ca = cx_[3 * (size_t)(a - f0_) + axis], cb = cx_[3 * (size_t)(b - f0_) + axis];
-                                 return ca < cb || (ca == cb && a < b);
-                             });
+            int mid = (begin + end) / 2;
+            double best_cost = INFINITY, best_plane = 0.0;
+            int best_axis = -1;
+            constexpr int kBins = 16;
+            auto half_area = [](const double* l, const double* h) {
+                const double dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+                return dx * dy + dy * dz + dz * dx;
+            };
+            for (int a = 0; a < 3 && end - begin > 4; a++) {
+                const double span = chi[a] - clo[a];
+                if (!(span > 0.0)) continue;
+                int cnt[kBins] = {0};
+                double blo[kBins][3], bhi[kBins][3];
+                for (int b = 0; b < kBins; b++)
+                    for (int c = 0; c < 3; c++) { blo[b][c] = INFINITY; bhi[b][c] = -INFINITY; }
+                for (int k = begin; k < end; k++) {
+                    const int face = order_[k];
+                    int b = (int)((cx_[3 * (size_t)(face - f0_) + a] - clo[a]) / span * kBins);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    cnt[b] += 1;
+                    const int32_t* idx = f_ + 3 * (size_t)face;
+                    for (int c = 0; c < 3; c++)
+                        for (int e = 0; e < 3; e++) {
+                            const double x = v_[3 * (size_t)idx[c] + e];
+                            blo[b][e] = std::min(blo[b][e], x);
+                            bhi[b][e] = std::max(bhi[b][e], x);
+                        }
+                }
+                // right-to-left suffix boxes, then a left-to-right sweep
+                double rlo[kBins][3], rhi[kBins][3];
+                int rcnt[kBins];
+                double l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+                int n = 0;
+                for (int b = kBins - 1; b >= 0; b--) {
+                    for (int e = 0; e < 3; e++) { l3[e] = std::min(l3[e], blo[b][e]); h3[e] = std::max(h3[e], bhi[b][e]); }
+                    n += cnt[b];
+                    for (int e = 0; e < 3; e++) { rlo[b][e] = l3[e]; rhi[b][e] = h3[e]; }
+                    rcnt[b] = n;
+                }
+                for (int e = 0; e < 3; e++) { l3[e] = INFINITY; h3[e] = -INFINITY; }
+                n = 0;
+                for (int b = 0; b + 1 < kBins; b++) {
+                    for (int e = 0; e < 3; e++) { l3[e] = std::min(l3[e], blo[b][e]); h3[e] = std::max(h3[e], bhi[b][e]); }
+                    n += cnt[b];
+                    if (n == 0 || rcnt[b + 1] == 0) continue;
+                    const double cost = half_area(l3, h3) * n + half_area(rlo[b + 1], rhi[b + 1]) * rcnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_plane = clo[a] + span * (b + 1) / kBins; }
+                }
+            }
+            if (best_axis >= 0) {
+                auto left = [&](int face) {
+                    const double span = chi[best_axis] - clo[best_axis];
+                    int b = (int)((cx_[3 * (size_t)(face - f0_) + best_axis] - clo[best_axis]) / span * kBins);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    return clo[best_axis] + span * (b + 1) / kBins <= best_plane;
+                };
+                mid = (int)(std::stable_partition(order_.begin() + begin, order_.begin() + end, left) - order_.begin());
+            }
+            if (best_axis < 0 || mid == begin || mid == end) {
+                mid = (begin + end) / 2;
+                std::nth_element(order_.begin() + begin, order_.begin() + mid, order_.begin() + end,
+                                 [&](int a, int b) {
+                                     double ca = cx_[3 * (size_t)(a - f0_) + axis], cb = cx_[3 * (size_t)(b - f0_) + axis];
+                                     return ca < cb || (ca == cb && a < b);
+                                 });
+            }
             nodes_[me].leaf = 0;
             build(begin, mid);
             build(mid, end);

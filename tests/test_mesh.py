@@ -173,10 +173,10 @@ def test_host_built_bvh_is_a_proper_depth_first_tree():
     assert leaves == 80 and nodes == 159
     small = compile_scene(scenes.mesh_lsc())
     nodes, leaves, depth = native.mesh_bvh_check(small, 1)             # 12 faces: leaves of <= 8
-    assert (nodes, leaves, depth) == (3, 2, 2)
+    assert 2 <= leaves <= 4 and nodes == 2 * leaves - 1 and depth <= 4   # (the SAH split need not be even)
     big = Node(name="w", geometry=Mesh.icosphere(5, 3.0, material=Material(1.0)))
     nodes, leaves, depth = native.mesh_bvh_check(compile_scene(Scene(big)), 0)
-    assert leaves == 20480 and depth == 16
+    assert leaves == 20480 and 15 <= depth <= 20   # (balanced: 15; the SAH tree is a little deeper)
     with pytest.raises(Exception):
         native.mesh_bvh_check(compiled, 2)                              # the analytic sphere
 
