@@ -222,6 +222,17 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[NI_KSTART] = K > 0 ? t->coat_start[n] : 0;
         q[NI_KCOUNT] = K > 0 ? t->coat_count[n] : 0;
         q[NI_MESH] = -1;
+        {   // unrotated: the 3x3 blocks of both matrices are the identity, bit for bit (+0.0 off the diagonal)
+            bool ident = true;
+            const double one = 1.0, zero = 0.0;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    const double* want = r == c ? &one : &zero;
+                    if (std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], want, 8) != 0) ident = false;
+                    if (std::memcmp(&t->local_to_world[n * 16 + r * 4 + c], want, 8) != 0) ident = false;
+                }
+            q[NI_IDENT] = ident ? 1 : 0;
+        }
         q[NI_ROT] = n;   // first node whose world->local rotation (the 3x3 block) has the same bits
         for (int e = 0; e < n; e++) {
             bool same = true;

@@ -37,8 +37,9 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // table element is addressed as base + index*stride + field with compile-time strides
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
 enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND_RN = 26, ND = 27 };  // node doubles (RN: RN(1/n))
-enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI_ROT, NI };  // node ints (NI_MESH: BVH root, -1 = none;
-                                                                                          // NI_ROT: first node whose world->local rotation has the same bits)
+enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI_ROT, NI_IDENT, NI };  // node ints (NI_MESH: BVH root, -1 = none;
+                                                                                          // NI_ROT: first node whose world->local rotation has the same bits;
+                                                                                          // NI_IDENT: that rotation is the identity matrix, bit for bit)
 enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C,
        CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD_ABS_W, CD_EMS_W, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN;
                                                             // *_W: the spacing w when additionally xs[i] == xs[0] + i*w bit for bit, else NaN)
@@ -715,17 +716,29 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 int rot = -1;          // rotation class of `d` (wave-uniform)
                 for (int node = 0; node < A.n_nodes; node++) {
                     const int m = node * ND + ND_W2L;
+                    // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
+                    // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,
+                    // quotient or stored value below can see.
+                    const bool ident = T.iu(node * NI + NI_IDENT) != 0;   // wave-uniform
                     V3 o;
-                    o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + T.du(m + 3);
-                    o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + T.du(m + 7);
-                    o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + T.du(m + 11);
+                    if (ident) {
+                        o.x = pos.x + T.du(m + 3); o.y = pos.y + T.du(m + 7); o.z = pos.z + T.du(m + 11);
+                    } else {
+                        o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + T.du(m + 3);
+                        o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + T.du(m + 7);
+                        o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + T.du(m + 11);
+                    }
                     // Nodes whose world->local rotations are bit-identical (the host files them under the
                     // first such node) see the same local direction: it and its reciprocals are reused.
                     const int rc = T.iu(node * NI + NI_ROT);
                     if (rc != rot) {
-                        d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
-                        d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
-                        d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
+                        if (ident) {
+                            d = dir;
+                        } else {
+                            d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
+                            d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
+                            d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
+                        }
                         rot = rc;
                         inv_ok = false;
                     }
@@ -1088,6 +1101,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         auto local_point_of = [&](auto uni, int node) -> V3 {
             const int m = node * ND + ND_W2L;
             auto rd = [&](int i) { return decltype(uni)::value ? T.du(i) : T.dv(i); };
+            if ((decltype(uni)::value ? T.iu(node * NI + NI_IDENT) : T.iv(node * NI + NI_IDENT)) != 0)   // unrotated node
+                return V3{pos.x + rd(m + 3), pos.y + rd(m + 7), pos.z + rd(m + 11)};
             return V3{rd(m + 0) * pos.x + rd(m + 1) * pos.y + rd(m + 2) * pos.z + rd(m + 3),
                       rd(m + 4) * pos.x + rd(m + 5) * pos.y + rd(m + 6) * pos.z + rd(m + 7),
                       rd(m + 8) * pos.x + rd(m + 9) * pos.y + rd(m + 10) * pos.z + rd(m + 11)};
@@ -1132,10 +1147,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // and the shape switch is wave-uniform
         if (alive && t_normal) {
             const V3 nloc = local_normal(local_point());
-            const int q = t_node * ND + ND_L2W;
-            nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
-            nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
-            nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
+            if (T.iv(t_node * NI + NI_IDENT) != 0) {
+                nrm = nloc;
+            } else {
+                const int q = t_node * ND + ND_L2W;
+                nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
+                nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
+                nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
+            }
         }
 
         PVT_MARK(3);  // frame + normal

@@ -9,10 +9,11 @@ import csv, glob, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 stage = sys.argv[2] if len(sys.argv) > 2 else ""
+mode = sys.argv[3] if len(sys.argv) > 3 else "pipelined"
 photons = 1_000_000
 sums = collections.defaultdict(list)
 kernel = None
-for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*", "pmc_counter_collection.csv"))):
+for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{mode}_*", "pmc_counter_collection.csv"))):
     rows = [r for r in csv.DictReader(open(path)) if "trace_kernel" in r["Kernel_Name"]]
     per = collections.defaultdict(list)
     for r in rows:
@@ -25,9 +26,11 @@ c = dict(sums)
 read_b = c["FETCH_SIZE"] * 1024 * 2
 write_b = c["WRITE_SIZE"] * 1024
 out = {
-    "round": 1, "stage": stage,
-    "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --gpus 1 --steps 5 "
-               "--warmup 1 --streams 1 --no-cpu-baseline (one counter set per run; tools/gpu_pmc.sh)",
+    "round": 2, "stage": stage, "mode": mode,
+    "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --gpus 1 --steps 6 --warmup 1 "
+               "--no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2"
+               + (" --streams 1" if mode == "serial" else "") + " (one counter set per run; tools/gpu_pmc.sh " + mode + "); "
+               "rocprofv3 serialises dispatches while sampling counters",
     "kernel": kernel, "photons_per_launch": photons, "counters_mean_per_launch": c,
     "hbm_read_bytes_per_launch_corrected": read_b, "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
@@ -43,11 +46,14 @@ out = {
         "wait_inst_any_fraction": c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"],
         "active_inst_any_fraction": c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"],
         "lds_bank_conflict_fraction": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+        # VALU pipes busy, measured: 4 cycles per wave64 instruction over (SIMDs x kernel cycles); GRBM_GUI_ACTIVE
+        # is summed over the 8 XCDs
+        "valu_busy_measured": (4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8.0)) if "GRBM_GUI_ACTIVE" in c else None,
         "smem_instructions_per_wave": c.get("SQ_INSTS_SMEM", 0) / c["SQ_WAVES"],
         "vmem_instructions_per_wave": c.get("SQ_INSTS_VMEM", 0) / c["SQ_WAVES"],
     },
 }
-for name in (f"{tag}_pmc_summary.json", "pmc_summary.json"):
+for name in ((f"{tag}_pmc_summary.json", "pmc_summary.json") if mode == "pipelined" else (f"{tag}_pmc_summary.json",)):
     with open(os.path.join(ROOT, "profiles", name), "w") as fp:
         json.dump(out, fp, indent=1)
 print(json.dumps(out["derived"], indent=1), out["hbm_bytes_per_launch"])
