@@ -36,6 +36,9 @@ class BundlePipeline:
         # launches that overlap run best with fewer persistent workgroups each (measured on the
         # LSC, 10^6-photon bundles: 2 per CU with three in flight, 3 with two, 4 alone)
         self.workgroups_per_cu = {1: 4, 2: 3}.get(self.depth, 2)
+        import os
+        if os.environ.get("PVT_PIPE_WGS"):   # developer sweep
+            self.workgroups_per_cu = int(os.environ["PVT_PIPE_WGS"])
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.slots = [dscene.new_tallies() for _ in range(self.depth)]
         self.totals = [dscene.new_tallies() for _ in range(self.depth)]
