@@ -280,6 +280,9 @@ def main():
                     "valu_wave_instructions_per_photon": derived.get("valu_wave_instructions_per_photon"),
                     "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
                     "wait_fraction_of_wave_cycles": derived.get("wait_any_fraction_of_wave_cycles"),
+                    # measured with counters, for ONE launch of this shape alone (rocprofv3 serialises
+                    # dispatches while sampling): 4*SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8)
+                    "valu_busy_measured_single_launch": derived.get("valu_busy_measured"),
                 }
                 per_photon = derived.get("valu_wave_instructions_per_photon")
                 if per_photon:
