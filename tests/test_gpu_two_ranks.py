@@ -77,3 +77,29 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_job(tmp_path):
     # not the even split 100 016), so together they are the single-process log
     counts = np.concatenate([r["sharded_counts"] for r in ranks])
     assert np.array_equal(counts, whole.data["counts"])
+
+
+@pytest.mark.timeout(1800)
+def test_bench_script_runs_with_two_ranks_and_reports_every_leg(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process),
+    the two ranks sharing the one GPU of the test box and reducing over gloo: weak-scaling line, repeat
+    windows, sustained leg and the strong-scaling leg, whose reduced tallies must account for every photon."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, PVT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--photons", "20000", "--repeats", "2",
+           "--sustained-s", "0.02", "--total-photons", "100001", "--ray-buffers", "2", "--spinup-s", "0",
+           "--no-cpu-baseline"]
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert done.returncode == 0, done.stderr[-2000:]
+    line = [l for l in done.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["photons_per_gpu_per_step"] == 20000 and "index-range x2" in out["config"]["sharding"]
+    assert out["repeats"]["windows"] == 3 and out["sustained"]["photons"] >= 2 * 3 * 20000
+    assert out["strong_scaling"]["total_photons"] == 100001 == out["strong_scaling"]["photons_tallied"]
+    # the weak line's tallies are the sum over both ranks' steps: fractions of 2 * 3 * 20000 photons
+    assert abs(out["tallies"]["entering"] + out["tallies"]["reflected"] - 1.0) < 1e-12
