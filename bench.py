@@ -326,7 +326,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "trace_kernel<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=0,MESH=0>",
+                "kernel": "trace_kernel_w4<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=0> (pvt_trace_kernel.h trace_body, MESH=0)",
                 "kernel_ms_mean": mean_kernel_ms,
                 "instruction_side": instruction_side,
                 "kernel_photons_per_s": n / (mean_kernel_ms * 1e-3),
