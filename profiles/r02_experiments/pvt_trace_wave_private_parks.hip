@@ -1,0 +1,784 @@
+// pvt_trace.hip — the photon loop of pvtrace on CDNA4 (gfx950), and the C ABI
+// declared in include/pvtrace_hip.h.
+//
+// What it replaces: reference pvtrace/engine/_kernel.pyx trace_one / trace_bundle
+// (:603-1115), i.e. the per-photon while-alive loop behind engine.simulate().
+// This is not a translation of that file: the reference walks one ray per CPU
+// thread through per-thread scratch arrays; here
+//
+//   * one wavefront LANE owns one live photon; a persistent workgroup keeps all
+//     64 lanes of each wave busy by refilling dead lanes from a global ray
+//     cursor (wave-level ballot + prefix rank, one atomic per 64 rays);
+//   * the scene tables (a few KB) are packed once into two blobs in HBM and
+//     staged into LDS per workgroup; wave-uniform reads (the node loop, the
+//     recorder loop) go through the scalar cache from the global copy, lane-
+//     divergent reads (spectra binary search, per-lane node rows) hit LDS;
+//   * hit classification is streaming (nearest / second nearest / container are
+//     folded while the nodes are intersected) — no per-ray hit arrays;
+//   * every lane's event (row to log, recorder to tally) is deferred to ONE
+//     re-converged block at the end of the step instead of being emitted from
+//     each divergent branch;
+//   * recorders accumulate in LDS (integer + f64 atomics) and are flushed with
+//     one global atomic per slot per workgroup;
+//   * all arithmetic is FP64 with FMA contraction off and the transcendental
+//     functions of pvt_math.h, so a photon's whole history is bit-identical to
+//     the CPU referee (oracle/pvt_oracle.c, math_mode 1).
+//
+// No MFMA: there is no dense contraction anywhere on this path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <mutex>
+#include <vector>
+
+#include "../../include/pvtrace_hip.h"
+#include "pvt_math.h"
+#include "pvt_bvh.h"
+
+#include "pvt_trace_kernel.h"
+
+namespace {
+
+// ============================================================== host side
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(PVT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+int push(std::vector<T>& blob, const T* src, size_t n) {
+    int at = (int)blob.size();
+    if (n && src) blob.insert(blob.end(), src, src + n);
+    return at;
+}
+
+}  // namespace
+
+struct PvtScene {
+    int device = 0;
+    Lay lay{};
+    EmitOff eoff{};
+    int nd = 0, ni = 0;
+    int n_nodes = 0, root = 0, n_rec = 0, total_bins = 0, n_coat = 0, n_lights = 0;
+    double* d_gd = nullptr;
+    int* d_gi = nullptr;
+    double* d_ed = nullptr;
+    int* d_ei = nullptr;
+    pvt::BvhNode* d_bvh = nullptr;      // triangle meshes: BVH nodes + gathered triangles
+    pvt::MeshTri* d_tris = nullptr;
+    unsigned int* d_cursor = nullptr;   // kCursorSlots cursors (64 B apart), one per stream: launches on
+                                        // different streams may overlap, each needs its own
+    std::mutex slot_mutex;              // launches on one stream are ordered and may share a cursor;
+    std::vector<hipStream_t> slot_of;   // index = cursor slot owned by that stream
+    int num_cu = 0;
+    int last_grid = 0, last_lds = 0;
+    size_t lds_limit = 0;
+};
+
+extern "C" {
+
+int pvt_abi_version(void) { return PVT_ABI_VERSION; }
+const char* pvt_last_error(void) { return g_error.c_str(); }
+
+int pvt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
+    if (!t || !out) return fail(PVT_ERR_INVALID, "null argument");
+    if (t->n_nodes <= 0) return fail(PVT_ERR_INVALID, "scene has no nodes");
+    if (t->n_nodes > PVT_MAX_NODES) return fail(PVT_ERR_TOO_MANY_NODES, "more than 128 geometry nodes");
+    if (t->n_recorders > PVT_MAX_RECORDERS) return fail(PVT_ERR_INVALID, "more than 256 recorders");
+    if (t->n_components >= (1 << 28) - 1) return fail(PVT_ERR_INVALID, "more than 2^28 components");
+    if (pvt_device_count() <= device) return fail(PVT_ERR_NO_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+
+    const int N = t->n_nodes, C = t->n_components, R = t->n_recorders, H = t->n_hists, K = t->n_coatings;
+    std::vector<pvt::BvhNode> bvh_nodes;
+    std::vector<pvt::MeshTri> bvh_tris;
+    for (int n = 0; n < N; n++) {
+        const int g = t->geom_type[n];
+        if (g < PVT_GEOM_BOX || g > PVT_GEOM_MESH) return fail(PVT_ERR_INVALID, "unknown geometry type");
+        if (g != PVT_GEOM_MESH) continue;
+        if (!t->mesh_face_start || !t->mesh_face_count || !t->mesh_vertices || !t->mesh_faces || !t->mesh_normals)
+            return fail(PVT_ERR_INVALID, "mesh node without mesh tables");
+        const long long f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
+        if (fc <= 0 || f0 < 0 || f0 + fc > t->n_mesh_faces) return fail(PVT_ERR_INVALID, "mesh face range out of bounds");
+        if (t->n_mesh_faces >= (1 << 27)) return fail(PVT_ERR_INVALID, "more than 2^27 mesh faces in one scene");
+        for (long long k = 3 * f0; k < 3 * (f0 + fc); k++)
+            if (t->mesh_faces[k] < 0 || t->mesh_faces[k] >= t->n_mesh_vertices)
+                return fail(PVT_ERR_INVALID, "mesh face indexes a missing vertex");
+    }
+    // fixed-stride records, then the pooled spectra (see the enums next to struct Lay)
+    Lay lay{};
+    lay.comp_d = N * ND;
+    lay.rec_d = lay.comp_d + C * CD;
+    lay.hist_d = lay.rec_d + R * RD;
+    lay.coat_d = lay.hist_d + H * HD;
+    const int spec_d = lay.coat_d + K * KD;
+    const int abs_x0 = spec_d, abs_y0 = abs_x0 + t->n_abs, ems_x0 = abs_y0 + t->n_abs, ems_c0 = ems_x0 + t->n_ems;
+    bool index_ok = true;   // refractive indices the known-divisor division is proven for
+    for (int n = 0; n < N; n++) {
+        const double v = t->refractive_index[n];
+        if (!(std::isfinite(v) && v > 1e-100 && v < 1e100)) index_ok = false;
+    }
+    if (!index_ok) return fail(PVT_ERR_INVALID, "refractive indices must be finite and positive");
+    constexpr int kCritNodes = 16;
+    lay.crit_d = N <= kCritNodes ? ems_c0 + t->n_ems : -1;
+    std::vector<double> gd((size_t)ems_c0 + t->n_ems + (lay.crit_d >= 0 ? (size_t)N * N : 0) + 1, 0.0);
+    if (lay.crit_d >= 0)
+        for (int c = 0; c < N; c++)
+            for (int a = 0; a < N; a++) {
+                const double n1 = t->refractive_index[c], n2 = t->refractive_index[a];
+                gd[lay.crit_d + c * N + a] = n2 < n1 ? pvt_asin(n2 / n1) : INFINITY;   // same pvt_asin as the device
+            }
+    lay.comp_i = N * NI;
+    lay.rec_i = lay.comp_i + C * CI;
+    lay.hist_i = lay.rec_i + R * RI;
+    lay.coat_i = lay.hist_i + H * HI;
+    lay.cand_i = lay.coat_i + K * KI;
+    lay.cand_list = lay.cand_i + N * 7 * 8;
+    const int guide0 = lay.cand_list + R;  // guide tables: one entry per table point, per searched array
+    std::vector<int> gi((size_t)guide0 + (size_t)t->n_abs + 2 * (size_t)t->n_ems + 1, 0);
+    // guide[b] = largest i <= n-2 with xs[i] <= xs[0] + b*(xs[n-1]-xs[0])/(n-1), b = 0..n-1
+    auto build_guide = [&](const double* xs, int n, int at, double* scale) {
+        *scale = 0.0;
+        if (n < 2 || !(xs[n - 1] > xs[0])) return;
+        const int Kb = n - 1;
+        *scale = (double)Kb / (xs[n - 1] - xs[0]);
+        int i = 0;
+        for (int b = 0; b <= Kb; b++) {
+            const double edge = xs[0] + (double)b * ((xs[n - 1] - xs[0]) / (double)Kb);
+            while (i + 1 <= n - 2 && xs[i + 1] <= edge) i++;
+            gi[at + b] = i;
+        }
+    };
+    {   // recorders grouped by the (node, selector) they listen to.  A facet recorder whose facet
+        // has a clearly dominant component, alone in its (axis, sign) bin, goes to the bin table;
+        // the rest (no facet, oblique facets, bin collisions) to the walked list, ascending id.
+        int at = 0;
+        for (int key = 0; key < N * 7; key++) {
+            int* rec = gi.data() + lay.cand_i + key * 8;
+            rec[0] = at;
+            int owner[6] = {-1, -1, -1, -1, -1, -1};
+            bool clash[6] = {false, false, false, false, false, false};
+            auto bin_of = [&](int r) -> int {
+                if (!t->rec_has_facet[r]) return -1;
+                const double* f = t->rec_facet + r * 3;
+                const double a[3] = {std::fabs(f[0]), std::fabs(f[1]), std::fabs(f[2])};
+                int k = (a[0] >= a[1] && a[0] >= a[2]) ? 0 : (a[1] >= a[2] ? 1 : 2);
+                const double other = std::fmax(a[(k + 1) % 3], a[(k + 2) % 3]);
+                // any normal within atol of the facet must have the same dominant axis and sign
+                if (!(a[k] - other > 4.0 * t->rec_atol[r] + 1e-9) || !(a[k] > 2.0 * t->rec_atol[r])) return -1;
+                return k * 2 + (f[k] > 0.0 ? 1 : 0);
+            };
+            for (int r = 0; r < R; r++) {
+                if (t->rec_node[r] * 7 + t->rec_event[r] != key) continue;
+                int b = bin_of(r);
+                if (b >= 0) { if (owner[b] >= 0) clash[b] = true; else owner[b] = r; }
+            }
+            for (int b = 0; b < 6; b++) rec[2 + b] = (owner[b] >= 0 && !clash[b]) ? owner[b] : -1;
+            for (int r = 0; r < R; r++) {
+                if (t->rec_node[r] * 7 + t->rec_event[r] != key) continue;
+                int b = bin_of(r);
+                if (b >= 0 && !clash[b]) continue;  // served by the bin table
+                gi[lay.cand_list + at++] = r;
+            }
+            rec[1] = at - rec[0];
+        }
+    }
+    for (int n = 0; n < N; n++) {
+        double* d = gd.data() + n * ND;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) d[ND_W2L + r * 4 + c] = t->world_to_local[n * 16 + r * 4 + c];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) d[ND_L2W + r * 3 + c] = t->local_to_world[n * 16 + r * 4 + c];
+        for (int c = 0; c < 4; c++) d[ND_PARAMS + c] = t->geom_params[n * 4 + c];
+        d[ND_N] = t->refractive_index[n];
+        d[ND_RN] = 1.0 / t->refractive_index[n];
+        int* q = gi.data() + n * NI;
+        q[NI_GEOM] = t->geom_type[n];
+        q[NI_SURF] = t->surface_type[n];
+        q[NI_CSTART] = t->comp_start[n];
+        q[NI_CCOUNT] = t->comp_count[n];
+        q[NI_KSTART] = K > 0 ? t->coat_start[n] : 0;
+        q[NI_KCOUNT] = K > 0 ? t->coat_count[n] : 0;
+        q[NI_MESH] = -1;
+        q[NI_ROT] = n;   // first node whose world->local rotation (the 3x3 block) has the same bits
+        for (int e = 0; e < n; e++) {
+            bool same = true;
+            for (int r = 0; r < 3 && same; r++)
+                for (int c = 0; c < 3 && same; c++)
+                    same = std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], &t->world_to_local[e * 16 + r * 4 + c], 8) == 0;
+            if (same) { q[NI_ROT] = e; break; }
+        }
+        if (t->geom_type[n] == PVT_GEOM_MESH) {
+            const int f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
+            q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris)
+                             .add_mesh(f0, fc);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        double* d = gd.data() + lay.comp_d + c * CD;
+        d[CD_QY] = t->comp_qy[c];
+        d[CD_TAU_RAD] = t->comp_tau_rad[c];
+        d[CD_TAU_NR] = t->comp_tau_nr[c];
+        d[CD_PHASE] = t->comp_phase_param[c];
+        int* q = gi.data() + lay.comp_i + c * CI;
+        q[CI_TYPE] = t->comp_type[c];
+        q[CI_PHASE] = t->comp_phase_type[c];
+        q[CI_ABS_X] = abs_x0 + t->comp_abs_start[c];   // absolute offsets into the double blob
+        q[CI_ABS_Y] = abs_y0 + t->comp_abs_start[c];
+        q[CI_ABS_N] = t->comp_abs_n[c];
+        q[CI_EMS_X] = ems_x0 + t->comp_ems_start[c];
+        q[CI_EMS_CDF] = ems_c0 + t->comp_ems_start[c];
+        q[CI_EMS_N] = t->comp_ems_n[c];
+        q[CI_ABS_HIST] = t->comp_abs_hist ? t->comp_abs_hist[c] : 0;
+        q[CI_EMS_HIST] = t->comp_ems_hist ? t->comp_ems_hist[c] : 0;
+        q[CI_ABS_G] = guide0 + t->comp_abs_start[c];
+        q[CI_EMS_GX] = guide0 + t->n_abs + t->comp_ems_start[c];
+        q[CI_EMS_GC] = guide0 + t->n_abs + t->n_ems + t->comp_ems_start[c];
+        build_guide(t->abs_x + t->comp_abs_start[c], t->comp_abs_n[c], q[CI_ABS_G], &d[CD_ABS_SCALE]);
+        build_guide(t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GX], &d[CD_EMS_SCALE_X]);
+        build_guide(t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GC], &d[CD_EMS_SCALE_C]);
+        // RN(1/spacing) when EVERY interval of the abscissae has the same bits and the ordinates
+        // keep the quotient inside div_known's domain (no -0.0, no extreme magnitudes)
+        auto even_rcp = [](const double* xs, const double* ys, int n) -> double {
+            if (n < 2) return NAN;
+            const double w = xs[1] - xs[0];
+            if (!(w > 1e-100 && w < 1e100)) return NAN;
+            for (int i = 1; i + 1 < n; i++) if (xs[i + 1] - xs[i] != w) return NAN;
+            for (int i = 0; i < n; i++) {
+                if (ys[i] == 0.0 && std::signbit(ys[i])) return NAN;
+                if (!(std::fabs(ys[i]) < 1e100)) return NAN;
+                if (i > 0 && ys[i] != ys[i - 1] && std::fabs(ys[i] - ys[i - 1]) < 1e-100) return NAN;
+            }
+            return 1.0 / w;
+        };
+        // the spacing itself when, additionally, xs[i] == xs[0] + i*w bit for bit (then the kernel finds the
+        // reference's bisection index by arithmetic): evaluated exactly as the device does
+        auto even_w = [](const double* xs, int n, double rcp) -> double {
+            if (!(rcp == rcp) || n < 2) return NAN;
+            const double w = xs[1] - xs[0];
+            for (int i = 0; i < n; i++) {
+                volatile double prod = (double)i * w;   // two roundings, never contracted
+                volatile double at = xs[0] + prod;
+                if (at != xs[i]) return NAN;
+            }
+            return w;
+        };
+        d[CD_ABS_RCP] = even_rcp(t->abs_x + t->comp_abs_start[c], t->abs_y + t->comp_abs_start[c], t->comp_abs_n[c]);
+        d[CD_EMS_RCP_X] = even_rcp(t->ems_x + t->comp_ems_start[c], t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c]);
+        d[CD_EMS_RCP_C] = even_rcp(t->ems_cdf + t->comp_ems_start[c], t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c]);
+        d[CD_ABS_W] = even_w(t->abs_x + t->comp_abs_start[c], t->comp_abs_n[c], d[CD_ABS_RCP]);
+        d[CD_EMS_W] = even_w(t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c], d[CD_EMS_RCP_X]);
+    }
+    for (int r = 0; r < R; r++) {
+        double* d = gd.data() + lay.rec_d + r * RD;
+        for (int a = 0; a < 3; a++) d[RD_FACET + a] = t->rec_facet[r * 3 + a];
+        d[RD_ATOL] = t->rec_atol[r];
+        int* q = gi.data() + lay.rec_i + r * RI;
+        q[RI_NODE] = t->rec_node[r];
+        q[RI_EVENT] = t->rec_event[r];
+        q[RI_HAS_FACET] = t->rec_has_facet[r];
+        q[RI_HSTART] = t->rec_hist_start[r];
+        q[RI_HN] = t->rec_hist_n[r];
+        q[RI_SRC_MODE] = t->rec_source_mode ? t->rec_source_mode[r] : 0;
+        q[RI_SRC_ID] = t->rec_source_id ? t->rec_source_id[r] : -1;
+    }
+    for (int h = 0; h < H; h++) {
+        double* d = gd.data() + lay.hist_d + h * HD;
+        d[HD_LO_A] = t->hist_lo_a[h]; d[HD_HI_A] = t->hist_hi_a[h];
+        d[HD_LO_B] = t->hist_lo_b[h]; d[HD_HI_B] = t->hist_hi_b[h];
+        auto rcp_or_nan = [](double width) {   // NaN: the kernel divides for real
+            return (std::isfinite(width) && std::fabs(width) > 1e-290 && std::fabs(width) < 1e290) ? 1.0 / width : NAN;
+        };
+        d[HD_RA] = rcp_or_nan(t->hist_hi_a[h] - t->hist_lo_a[h]);
+        d[HD_RB] = rcp_or_nan(t->hist_hi_b[h] - t->hist_lo_b[h]);
+        int* q = gi.data() + lay.hist_i + h * HI;
+        q[HI_PA] = t->hist_prop_a[h]; q[HI_PB] = t->hist_prop_b[h];
+        q[HI_NA] = t->hist_na[h]; q[HI_NB] = t->hist_nb[h]; q[HI_OFF] = t->hist_offset[h];
+    }
+    for (int k = 0; k < K; k++) {
+        double* d = gd.data() + lay.coat_d + k * KD;
+        for (int a = 0; a < 3; a++) {
+            d[KD_FACET + a] = t->coat_facet[k * 3 + a];
+            d[KD_LO + a] = t->coat_lo[k * 3 + a];
+            d[KD_HI + a] = t->coat_hi[k * 3 + a];
+        }
+        d[KD_REFL] = t->coat_reflectivity[k];
+        int* q = gi.data() + lay.coat_i + k * KI;
+        q[KI_RMODE] = t->coat_reflect_mode[k];
+        q[KI_TMODE] = t->coat_transmit_mode[k];
+    }
+    for (int i = 0; i < t->n_abs; i++) { gd[abs_x0 + i] = t->abs_x[i]; gd[abs_y0 + i] = t->abs_y[i]; }
+    for (int i = 0; i < t->n_ems; i++) { gd[ems_x0 + i] = t->ems_x[i]; gd[ems_c0 + i] = t->ems_cdf[i]; }
+
+    // owned until every upload has succeeded: a failing HIP call must not leak the scene
+    struct Owner {
+        PvtScene* p;
+        ~Owner() { if (p) pvt_scene_destroy(p); }
+    } owner{new PvtScene()};
+    PvtScene* s = owner.p;
+    s->device = device;
+    s->lay = lay;
+    s->nd = (int)gd.size();
+    s->ni = (int)gi.size();
+    s->n_nodes = N;
+    s->root = t->root_id;
+    s->n_rec = R;
+    s->total_bins = t->total_bins;
+    s->n_coat = K;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->num_cu = prop.multiProcessorCount;
+    s->lds_limit = prop.sharedMemPerBlock;
+    HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
+    HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 512));   // + room for the PVT_STATS counters
+    if (!bvh_nodes.empty()) {
+        HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
+        HIP_TRY(hipMalloc(&s->d_tris, bvh_tris.size() * sizeof(pvt::MeshTri)));
+        HIP_TRY(hipMemcpy(s->d_bvh, bvh_nodes.data(), bvh_nodes.size() * sizeof(pvt::BvhNode), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_tris, bvh_tris.data(), bvh_tris.size() * sizeof(pvt::MeshTri), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(s->d_gd, gd.data(), gd.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_gi, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice));
+    owner.p = nullptr;
+    *out = s;
+    return PVT_OK;
+}
+
+int pvt_scene_set_emitter(PvtScene* s, const PvtEmitterTables* e) {
+    if (!s || !e || e->n_lights <= 0) return fail(PVT_ERR_INVALID, "bad emitter");
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<double> ed;
+    std::vector<int> ei;
+    EmitOff o{};
+    const int Lt = e->n_lights;
+    o.wl_value = push(ed, e->wl_value, Lt);
+    o.pos_param = push(ed, e->pos_param, (size_t)Lt * 3);
+    o.dir_param = push(ed, e->dir_param, Lt);
+    o.l2w = push(ed, e->light_to_world, (size_t)Lt * 16);
+    o.spec_x = push(ed, e->spec_x, e->n_spec);
+    o.spec_cdf = push(ed, e->spec_cdf, e->n_spec);
+    o.wl_type = push(ei, e->wl_type, Lt);
+    o.wl_spec_start = push(ei, e->wl_spec_start, Lt);
+    o.wl_spec_n = push(ei, e->wl_spec_n, Lt);
+    o.pos_type = push(ei, e->pos_type, Lt);
+    o.dir_type = push(ei, e->dir_type, Lt);
+    ed.push_back(0.0);
+    ei.push_back(0);
+    if (s->d_ed) { (void)hipFree(s->d_ed); s->d_ed = nullptr; }
+    if (s->d_ei) { (void)hipFree(s->d_ei); s->d_ei = nullptr; }
+    HIP_TRY(hipMalloc(&s->d_ed, ed.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&s->d_ei, ei.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(s->d_ed, ed.data(), ed.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_ei, ei.data(), ei.size() * sizeof(int), hipMemcpyHostToDevice));
+    s->eoff = o;
+    s->n_lights = Lt;
+    return PVT_OK;
+}
+
+void pvt_scene_destroy(PvtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->d_gd) (void)hipFree(s->d_gd);
+    if (s->d_gi) (void)hipFree(s->d_gi);
+    if (s->d_ed) (void)hipFree(s->d_ed);
+    if (s->d_ei) (void)hipFree(s->d_ei);
+    if (s->d_cursor) (void)hipFree(s->d_cursor);
+    if (s->d_bvh) (void)hipFree(s->d_bvh);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    delete s;
+}
+
+}  // extern "C"
+
+namespace {
+
+KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
+    KArgs a{};
+    a.gd = s->d_gd; a.gi = s->d_gi; a.ed = s->d_ed; a.ei = s->d_ei;
+    a.bvh = s->d_bvh; a.tris = s->d_tris;
+    a.lay = s->lay; a.eoff = s->eoff;
+    a.nd = s->nd; a.ni = s->ni;
+    a.n_nodes = s->n_nodes; a.root = s->root; a.n_rec = s->n_rec; a.total_bins = s->total_bins;
+    a.n_coat = s->n_coat; a.n_lights = s->n_lights;
+    a.n_rays = (unsigned int)p->n_rays;
+    a.cursor = s->d_cursor;
+    a.seed = p->seed + p->ray_offset;
+    a.emit_seed = p->emit_seed;
+    a.ray_offset = p->ray_offset;
+    a.maxsteps = p->maxsteps; a.max_events = p->max_events; a.emit_method = p->emit_method;
+    a.record_every = p->record_every;
+    return a;
+}
+
+#ifndef PVT_DEV_VARIANTS
+#define PVT_DEV_VARIANTS 0   // developer builds: only the analytic, array-input, <=64-recorder variants (fast compile)
+#endif
+template <bool RECORD, bool TAB_LDS, int SEENW>
+hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
+    const bool mesh = a.bvh != nullptr;
+#if PVT_DEV_VARIANTS
+    if (emit || mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
+    if constexpr (TAB_LDS && SEENW == 1)
+        hipLaunchKernelGGL((trace_kernel<RECORD, true, 1, false, false>), dim3(grid), dim3(kBlock), lds, st, a);
+#else
+    if (emit) {
+        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, true>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    } else {
+        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    }
+#endif
+    return hipGetLastError();
+}
+
+template <bool RECORD, bool TAB_LDS>
+hipError_t launch_seen(int n_rec, bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
+    if (n_rec <= 64) return launch_variant<RECORD, TAB_LDS, 1>(emit, grid, lds, st, a);
+    return launch_variant<RECORD, TAB_LDS, 4>(emit, grid, lds, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
+                     const PvtEventLog* log, void* stream) {
+    if (!s || !p || !tl) return fail(PVT_ERR_INVALID, "null argument");
+    if (p->n_rays < 0 || p->n_rays > 0x7fffffffLL)
+        return fail(PVT_ERR_INVALID, "n_rays must fit in 31 bits per bundle");
+    if (p->max_events < 2 && p->record_every > 0) return fail(PVT_ERR_INVALID, "max_events must be >= 2");
+    if (!rays && !s->d_ed) return fail(PVT_ERR_INVALID, "no rays and no emitter");
+    if (p->record_every > 0 && !log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+    if (p->n_rays == 0) return PVT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    KArgs a = base_args(s, p);
+    if (rays) { a.pos = rays->position; a.dir = rays->direction; a.wl = rays->wavelength; }
+    a.rec_distinct = reinterpret_cast<long long*>(tl->rec_distinct);
+    a.rec_crossings = reinterpret_cast<long long*>(tl->rec_crossings);
+    a.rec_sums = tl->rec_sums;
+    a.rec_bins = reinterpret_cast<long long*>(tl->rec_bins);
+    const bool record = p->record_every > 0;
+    if (record) {
+        a.log = *log;
+        const size_t nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
+        const size_t rows = nrec * (size_t)p->max_events;
+        HIP_TRY(hipMemsetAsync(log->counts, 0, nrec * 4, st));
+        HIP_TRY(hipMemsetAsync(log->kind, 0, rows, st));
+        HIP_TRY(hipMemsetAsync(log->hit, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->container, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->adjacent, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->component, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->source, 0xFF, rows * 4, st));
+        HIP_TRY(hipMemsetAsync(log->position, 0, rows * 24, st));
+        HIP_TRY(hipMemsetAsync(log->direction, 0, rows * 24, st));
+        HIP_TRY(hipMemsetAsync(log->normal, 0, rows * 24, st));
+        HIP_TRY(hipMemsetAsync(log->wavelength, 0, rows * 8, st));
+        HIP_TRY(hipMemsetAsync(log->travelled, 0, rows * 8, st));
+        HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
+    }
+    {   // the cursor belongs to the stream: two launches can only overlap on different streams
+        std::lock_guard<std::mutex> lock(s->slot_mutex);
+        size_t slot = 0;
+        while (slot < s->slot_of.size() && s->slot_of[slot] != st) slot++;
+        if (slot == s->slot_of.size()) {
+            if (slot >= (size_t)kCursorSlots)
+                return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
+            s->slot_of.push_back(st);
+        }
+        a.cursor = s->d_cursor + 16 * slot;
+    }
+    HIP_TRY(hipMemsetAsync(a.cursor, 0, PVT_STATS ? 512 : 4, st));
+#if PVT_STATS
+    static unsigned long long* g_stats = nullptr;
+    if (!g_stats) (void)hipMalloc(&g_stats, 512);
+    (void)hipMemsetAsync(g_stats, 0, 512, st);
+    a.cursor = reinterpret_cast<unsigned int*>(g_stats);  // dev build: counters live in their own buffer
+#endif
+
+    // LDS budget: tables (if they fit) + recorder accumulators (+ bins if they fit)
+    const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 2 * 4);
+    const size_t tab_bytes = (size_t)s->nd * 8 + (size_t)((s->ni + 1) & ~1) * 4;
+    const size_t bins_bytes = (size_t)s->total_bins * 4;
+    const size_t budget = 64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit;  // keep >= 2 workgroups per CU
+    bool tab_lds = acc_bytes + tab_bytes <= budget;
+    size_t lds = acc_bytes + (tab_lds ? tab_bytes : 0);
+    a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
+    if (a.bins_in_lds) lds += (bins_bytes + 7) & ~(size_t)7;
+    lds += CTL_WORDS * 4;
+    // wave-private photon parks (see trace_kernel): as many slots per wave as keep four workgroups' LDS on
+    // a CU (<= 40 KB each), at most 72; below 24 parking is off and every body runs every step
+    const bool mesh_scene = s->d_bvh != nullptr;
+    const size_t xw = (size_t)((15 + (s->n_rec <= 64 ? 1 : 4) + (record ? 1 : 0) + (mesh_scene ? 1 : 0)) | 1);
+    a.xslots = 0;
+    if (!getenv("PVT_NO_PARK")) {
+        size_t target = 40 * 1024;
+        if (const char* env = getenv("PVT_LDS_TARGET")) target = (size_t)atoi(env) * 1024;   // dev override
+        const size_t room = lds < target ? target - lds : 0;
+        size_t slots = (room / (kWaves * xw * 8)) & ~(size_t)7;
+        if (slots > 72) slots = 72;
+        if (const char* env = getenv("PVT_XSLOTS")) slots = (size_t)atoi(env);   // dev override
+        if (slots >= 24 && lds + kWaves * slots * xw * 8 <= s->lds_limit) {
+            a.xslots = (int)slots;
+            lds += kWaves * slots * xw * 8;
+        }
+    }
+    if (lds > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
+    lds = (lds + 15) & ~(size_t)15;
+
+    // persistent grid: enough workgroups to fill every CU a few times over,
+    // never more than the rays can feed
+    long long blocks_for_rays = (p->n_rays + kBlock - 1) / kBlock;
+    double per_cu = p->workgroups_per_cu > 0 ? (double)p->workgroups_per_cu : 4.0;
+    if (const char* env = getenv("PVT_BLOCKS_PER_CU")) per_cu = atof(env) > 0 ? atof(env) : per_cu;   // dev override
+    long long grid = (long long)((double)s->num_cu * per_cu);
+    if (grid > blocks_for_rays) grid = blocks_for_rays;
+    if (grid < 1) grid = 1;
+    s->last_grid = (int)grid;
+    s->last_lds = (int)lds;
+
+    const bool emit = rays == nullptr;
+    hipError_t e;
+    if (record) {
+        e = tab_lds ? launch_seen<true, true>(s->n_rec, emit, (int)grid, lds, st, a)
+                    : launch_seen<true, false>(s->n_rec, emit, (int)grid, lds, st, a);
+    } else {
+        e = tab_lds ? launch_seen<false, true>(s->n_rec, emit, (int)grid, lds, st, a)
+                    : launch_seen<false, false>(s->n_rec, emit, (int)grid, lds, st, a);
+    }
+    if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
+#if PVT_STATS
+    {
+        unsigned long long c[64];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(c, a.cursor, 512, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[pvt stats] waves %llu  wave-iterations %llu (drain %llu)  lane-steps %llu (drain %llu)  "
+                "mean live lanes/iter %.1f (bulk %.1f, drain %.1f)  iters/wave %.1f (drain %.1f)\n",
+                c[5], c[1], c[3], c[2], c[4], (double)c[2] / c[1], (double)(c[2] - c[4]) / (double)(c[1] - c[3] + 1e-9),
+                (double)c[4] / (c[3] + 1e-9), (double)c[1] / c[5], (double)c[3] / c[5]);
+        const double bi = (double)(c[1] - c[3]) + 1e-9;
+        fprintf(stderr, "[pvt stats] bulk lanes/iteration after regrouping: live %.1f re-emitting %.1f (drew %.1f) surface %.1f terminal %.1f\n",
+                c[17] / bi, c[18] / bi, c[19] / bi, c[20] / bi, c[21] / bi);
+        fprintf(stderr, "[pvt stats] fraction of bulk wave-iterations that hold: re-emitting lanes %.3f surface lanes %.3f lanes that may tally %.3f\n",
+                c[22] / bi, c[23] / bi, c[24] / bi);
+        fprintf(stderr, "[pvt stats] bulk cycles/iteration: refill %.0f stage1 %.0f regroup %.0f emission %.0f frame+trig %.0f surface %.0f tally %.0f\n",
+                c[25] / bi, c[26] / bi, c[27] / bi, c[28] / bi, c[29] / bi, c[30] / bi, c[31] / bi);
+    }
+#endif
+    return PVT_OK;
+}
+
+int pvt_emit_device(PvtScene* s, const PvtTraceParams* p, double* position, double* direction,
+                    double* wavelength, void* stream) {
+    if (!s || !p || !s->d_ed) return fail(PVT_ERR_INVALID, "scene has no emitter");
+    if (p->n_rays <= 0) return PVT_OK;
+    if (p->n_rays > 0x7fffffffLL) return fail(PVT_ERR_INVALID, "n_rays must fit in 31 bits per bundle");
+    HIP_TRY(hipSetDevice(s->device));
+    KArgs a = base_args(s, p);
+    int grid = (int)((p->n_rays + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), a,
+                       position, direction, wavelength);
+    HIP_TRY(hipGetLastError());
+    return PVT_OK;
+}
+
+int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, int device) {
+    if (!x_host || !y_host || n < 0) return fail(PVT_ERR_INVALID, "bad argument");
+    if (n == 0) return PVT_OK;
+    if (pvt_device_count() <= device) return fail(PVT_ERR_NO_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *dx = nullptr, *dy = nullptr;
+    HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dx, x_host, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, fn, dx, dy,
+                       (long long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(y_host, dy, (size_t)n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    return PVT_OK;
+}
+
+int pvt_scene_launch_info(PvtScene* s, int32_t* grid, int32_t* block, int32_t* lds_bytes) {
+    if (!s) return fail(PVT_ERR_INVALID, "null scene");
+    if (grid) *grid = s->last_grid;
+    if (block) *block = kBlock;
+    if (lds_bytes) *lds_bytes = s->last_lds;
+    return PVT_OK;
+}
+
+int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nodes, int32_t* n_leaves,
+                       int32_t* depth_out) {
+    if (!t || node < 0 || node >= t->n_nodes || t->geom_type[node] != PVT_GEOM_MESH)
+        return fail(PVT_ERR_INVALID, "not a mesh node");
+    const int f0 = t->mesh_face_start[node], fc = t->mesh_face_count[node];
+    if (fc <= 0 || f0 < 0 || f0 + fc > t->n_mesh_faces) return fail(PVT_ERR_INVALID, "mesh face range out of bounds");
+    std::vector<pvt::BvhNode> nodes;
+    std::vector<pvt::MeshTri> tris;
+    const int root = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, nodes, tris).add_mesh(f0, fc);
+    if (root != 0 || nodes.empty() || nodes[0].skip != (int)nodes.size()) return fail(PVT_ERR_INVALID, "root skip link");
+    std::vector<int> seen(fc, 0);
+    int leaves = 0, max_depth = 0;
+    // walk the depth-first layout with an explicit ancestor stack (end index of each open subtree)
+    std::vector<int> open_end, open_id;
+    for (int i = 0; i < (int)nodes.size(); i++) {
+        while (!open_end.empty() && open_end.back() <= i) { open_end.pop_back(); open_id.pop_back(); }
+        const pvt::BvhNode& b = nodes[i];
+        if (b.skip <= i || b.skip > (int)nodes.size()) return fail(PVT_ERR_INVALID, "skip link does not move forward");
+        if (!open_end.empty() && b.skip > open_end.back()) return fail(PVT_ERR_INVALID, "subtree leaves its parent");
+        for (int a = 0; a < 3; a++) {
+            if (!(b.lo[a] <= b.hi[a])) return fail(PVT_ERR_INVALID, "empty box");
+            if (!open_id.empty() && (b.lo[a] < nodes[open_id.back()].lo[a] || b.hi[a] > nodes[open_id.back()].hi[a]))
+                return fail(PVT_ERR_INVALID, "child box not inside its parent");
+        }
+        max_depth = std::max(max_depth, (int)open_end.size() + 1);
+        if ((b.leaf & 15) > 0) {
+            if (b.skip != i + 1) return fail(PVT_ERR_INVALID, "leaf with a subtree");
+            leaves += 1;
+            for (int k = 0; k < (b.leaf & 15); k++) {
+                const pvt::MeshTri& tr = tris[(b.leaf >> 4) + k];
+                const long long local = tr.face - f0;
+                if (local < 0 || local >= fc || seen[local]++) return fail(PVT_ERR_INVALID, "face missing or duplicated");
+                for (int c = 0; c < 3; c++)
+                    for (int a = 0; a < 3; a++) {
+                        if (tr.v[3 * c + a] != t->mesh_vertices[3 * (size_t)t->mesh_faces[3 * (size_t)tr.face + c] + a])
+                            return fail(PVT_ERR_INVALID, "gathered vertex differs from the table");
+                        if (tr.v[3 * c + a] < b.lo[a] || tr.v[3 * c + a] > b.hi[a])
+                            return fail(PVT_ERR_INVALID, "triangle outside its leaf box");
+                    }
+            }
+        } else {
+            if (b.skip == i + 1) return fail(PVT_ERR_INVALID, "inner node without children");
+            open_end.push_back(b.skip);
+            open_id.push_back(i);
+        }
+    }
+    for (int k = 0; k < fc; k++) if (seen[k] != 1) return fail(PVT_ERR_INVALID, "face missing from the tree");
+    if (n_bvh_nodes) *n_bvh_nodes = (int32_t)nodes.size();
+    if (n_leaves) *n_leaves = leaves;
+    if (depth_out) *depth_out = max_depth;
+    return PVT_OK;
+}
+
+// Host-buffer entry: the literal stand-in for _kernel.trace_bundle.
+int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitter, const PvtRays* rays,
+                     const PvtTraceParams* p, const PvtTallies* tl, const PvtEventLog* log, int device,
+                     double* kernel_ms) {
+    if (!tables || !p || !tl) return fail(PVT_ERR_INVALID, "null argument");
+    PvtScene* s = nullptr;
+    int rc = pvt_scene_create(tables, device, &s);
+    if (rc != PVT_OK) return rc;
+    struct Guard {
+        PvtScene* s;
+        std::vector<void*> bufs;
+        ~Guard() {
+            for (void* b : bufs) (void)hipFree(b);
+            pvt_scene_destroy(s);
+        }
+    } g{s, {}};
+    if (emitter) {
+        rc = pvt_scene_set_emitter(s, emitter);
+        if (rc != PVT_OK) return rc;
+    }
+    auto dalloc = [&](size_t bytes, void** out) -> hipError_t {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+        if (e == hipSuccess) g.bufs.push_back(*out);
+        return e;
+    };
+    const size_t n = (size_t)p->n_rays;
+    const size_t R = (size_t)(tables->n_recorders > 0 ? tables->n_recorders : 1);
+    const size_t B = (size_t)(tables->total_bins > 0 ? tables->total_bins : 1);
+    PvtRays drays{};
+    if (rays) {
+        void *dp, *dd, *dw;
+        HIP_TRY(dalloc(n * 24, &dp)); HIP_TRY(dalloc(n * 24, &dd)); HIP_TRY(dalloc(n * 8, &dw));
+        HIP_TRY(hipMemcpy(dp, rays->position, n * 24, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dd, rays->direction, n * 24, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dw, rays->wavelength, n * 8, hipMemcpyHostToDevice));
+        drays = PvtRays{(const double*)dp, (const double*)dd, (const double*)dw};
+    }
+    PvtTallies dt{};
+    void *t0, *t1, *t2, *t3;
+    HIP_TRY(dalloc(R * 8, &t0)); HIP_TRY(dalloc(R * 8, &t1)); HIP_TRY(dalloc(R * 64, &t2)); HIP_TRY(dalloc(B * 8, &t3));
+    // the trace ADDS into the caller's tallies: seed the device copies with them
+    HIP_TRY(hipMemcpy(t0, tl->rec_distinct, (size_t)tables->n_recorders * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t1, tl->rec_crossings, (size_t)tables->n_recorders * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t2, tl->rec_sums, (size_t)tables->n_recorders * 64, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t3, tl->rec_bins, (size_t)tables->total_bins * 8, hipMemcpyHostToDevice));
+    dt = PvtTallies{(int64_t*)t0, (int64_t*)t1, (double*)t2, (int64_t*)t3};
+
+    PvtEventLog dl{};
+    size_t nrec = 0, rows = 0;
+    const bool record = p->record_every > 0;
+    if (record) {
+        if (!log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+        nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
+        rows = nrec * (size_t)p->max_events;
+        void* b[13];
+        const size_t sz[13] = {nrec * 4, rows, rows * 4, rows * 4, rows * 4, rows * 4, rows * 4,
+                               rows * 24, rows * 24, rows * 24, rows * 8, rows * 8, rows * 8};
+        for (int i = 0; i < 13; i++) HIP_TRY(dalloc(sz[i], &b[i]));
+        dl = PvtEventLog{(int32_t*)b[0], (uint8_t*)b[1], (int32_t*)b[2], (int32_t*)b[3], (int32_t*)b[4],
+                         (int32_t*)b[5], (int32_t*)b[6], (double*)b[7], (double*)b[8], (double*)b[9],
+                         (double*)b[10], (double*)b[11], (double*)b[12]};
+    }
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, nullptr));
+    rc = pvt_trace_device(s, rays ? &drays : nullptr, p, &dt, record ? &dl : nullptr, nullptr);
+    if (rc != PVT_OK) return rc;
+    HIP_TRY(hipEventRecord(ev1, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+
+    HIP_TRY(hipMemcpy(tl->rec_distinct, t0, (size_t)tables->n_recorders * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tl->rec_crossings, t1, (size_t)tables->n_recorders * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tl->rec_sums, t2, (size_t)tables->n_recorders * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tl->rec_bins, t3, (size_t)tables->total_bins * 8, hipMemcpyDeviceToHost));
+    if (record) {
+        HIP_TRY(hipMemcpy(log->counts, dl.counts, nrec * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->kind, dl.kind, rows, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->hit, dl.hit, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->container, dl.container, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->adjacent, dl.adjacent, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->component, dl.component, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->source, dl.source, rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->position, dl.position, rows * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->direction, dl.direction, rows * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->normal, dl.normal, rows * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->wavelength, dl.wavelength, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->travelled, dl.travelled, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(log->duration, dl.duration, rows * 8, hipMemcpyDeviceToHost));
+    }
+    return PVT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1480 @@
+// pvt_trace_kernel.h -- device side of the photon engine: the scene-record layout shared
+// with the host packer (enums + `Lay` + `KArgs`), the per-ray RNG, table lookups, the emitter
+// and the trace kernel itself.  Included once, by pvt_trace.hip (which holds the design
+// overview, the host-side packing and the C ABI).
+#pragma once
+#include <type_traits>
+// Developer-only ablation switches (timing experiments; results are WRONG when set).
+#ifndef PVT_ABLATE
+#define PVT_ABLATE 0
+#endif
+#ifndef PVT_STATS
+#define PVT_STATS 0
+#endif
+#define ABL(bit) ((PVT_ABLATE >> (bit)) & 1)   // 0 tally, 2 emission wl, 4 merged acos+sincos, 5 depth log, 6 frame/normal
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 wavefronts
+constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
+constexpr int kWaves = kBlock / 64;
+constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
+constexpr int kXSlotsMax = 256;     // photon-state slots in LDS for the per-step regrouping of a workgroup's photons
+// workgroup control words in LDS
+enum { CTL_DONE = 0, CTL_PUB = 4, CTL_WORDS = 16 };   // CTL_PUB: [2 parities][kWaves] published class counts
+constexpr double kEps = 2.220446049250313e-13;       // _kernel.pyx:29
+constexpr double kAlphaZero = 1e-8;                  // :32
+constexpr double kCcm = 2.99792458e10;               // :33
+constexpr double kPi = 3.14159265358979323846;
+constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
+
+// Scene blobs are arrays of fixed-stride RECORDS (one double blob, one int32 blob), so a
+// table element is addressed as base + index*stride + field with compile-time strides
+// and fields; only the eight record bases below live in SGPRs (node records start at 0).
+enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND_RN = 26, ND = 27 };  // node doubles (RN: RN(1/n))
+enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI_ROT, NI };  // node ints (NI_MESH: BVH root, -1 = none;
+                                                                                          // NI_ROT: first node whose world->local rotation has the same bits)
+enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C,
+       CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD_ABS_W, CD_EMS_W, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN;
+                                                            // *_W: the spacing w when additionally xs[i] == xs[0] + i*w bit for bit, else NaN)
+enum { CI_TYPE = 0, CI_PHASE, CI_ABS_X, CI_ABS_Y, CI_ABS_N, CI_EMS_X, CI_EMS_CDF, CI_EMS_N,
+       CI_ABS_G, CI_EMS_GX, CI_EMS_GC, CI_ABS_HIST, CI_EMS_HIST, CI };  // *_G*: guide tables; *_HIST: step tables
+enum { RD_FACET = 0, RD_ATOL = 3, RD = 4 };                                     // recorder
+enum { RI_NODE = 0, RI_EVENT, RI_HAS_FACET, RI_HSTART, RI_HN, RI_SRC_MODE, RI_SRC_ID, RI };
+enum { HD_LO_A = 0, HD_HI_A, HD_LO_B, HD_HI_B, HD_RA, HD_RB, HD };               // histogram (RA/RB: RN(1/(hi-lo)), NaN = divide)
+enum { HI_PA = 0, HI_PB, HI_NA, HI_NB, HI_OFF, HI };
+enum { KD_FACET = 0, KD_LO = 3, KD_HI = 6, KD_REFL = 9, KD = 10 };              // coating
+enum { KI_RMODE = 0, KI_TMODE, KI };
+
+struct Lay {  // record bases (elements) inside the blobs; spectra follow the records and are
+              // addressed by absolute offsets stored in the component records
+    int comp_d, rec_d, hist_d, coat_d;
+    int comp_i, rec_i, hist_i, coat_i;
+    int cand_i;     // (n_nodes*7) x {start, count, bin[6]}: recorders that can fire for a
+                    // (node, selector): a list to walk + facet recorders found by normal bin
+    int cand_list;  // recorder ids, ascending within each (node, selector)
+    int crit_d;     // (n_nodes x n_nodes) critical angles asin(n[a]/n[c]) (+inf where n[a] >= n[c]),
+                    // or -1 when the scene has too many nodes for the table
+};
+
+struct EmitOff {  // emitter blobs (global only; read once per photon)
+    int wl_value, pos_param, dir_param, l2w, spec_x, spec_cdf;         // doubles
+    int wl_type, wl_spec_start, wl_spec_n, pos_type, dir_type;        // int32
+};
+
+struct KArgs {
+    const double* gd;   // scene double blob (HBM)
+    const int* gi;      // scene int blob
+    const double* ed;   // emitter blobs (may be null)
+    const int* ei;
+    const pvt::BvhNode* bvh;    // triangle meshes (null when the scene has none): stay in HBM/L2
+    const pvt::MeshTri* tris;
+    Lay lay;
+    EmitOff eoff;
+    int nd, ni;         // blob lengths
+    int n_nodes, root, n_rec, total_bins, n_coat, n_lights;
+    // rays in (null -> device emission)
+    const double* pos;
+    const double* dir;
+    const double* wl;
+    unsigned int n_rays;
+    unsigned int* cursor;   // [0] ray cursor; (PVT_STATS builds) [2..] u64 counters
+    unsigned long long seed;       // + ray_offset folded in by the host
+    unsigned long long emit_seed;  // + nothing; global index added per ray
+    unsigned long long ray_offset;
+    int maxsteps, max_events, emit_method;
+    long long record_every;
+    // outputs
+    long long* rec_distinct;
+    long long* rec_crossings;
+    double* rec_sums;
+    long long* rec_bins;
+    PvtEventLog log;
+    int bins_in_lds;
+    int xslots;   // photon-state slots in LDS for regrouping the workgroup's photons each step (0 = off)
+};
+
+// ------------------------------------------------------------------ RNG
+struct Rng {
+    unsigned long long s0, s1, s2, s3;
+};
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& st) {
+    st += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void rng_seed(Rng& r, unsigned long long seed) {
+    unsigned long long st = seed;
+    r.s0 = splitmix64(st);
+    r.s1 = splitmix64(st);
+    r.s2 = splitmix64(st);
+    r.s3 = splitmix64(st);
+}
+__device__ __forceinline__ double rng_uniform(Rng& r) {
+    unsigned long long result = r.s0 + r.s3;
+    unsigned long long t = r.s1 << 17;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = (r.s3 << 45) | (r.s3 >> 19);
+    return (double)(result >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------ table access
+// TAB_LDS: divergent reads come from the LDS copy; uniform reads always come
+// from the global blob so the compiler can use scalar loads.
+// Read-only scene blobs viewed through the CONSTANT address space: a load whose
+// address is wave-uniform then becomes an s_load through the scalar cache (SGPR result,
+// no VGPR address arithmetic) instead of a 64-lane global_load of one address.  The
+// blobs are never written while a trace kernel runs, which is what makes this legal.
+typedef const __attribute__((address_space(4))) double* CDoubles;
+typedef const __attribute__((address_space(4))) int* CInts;
+
+template <bool TAB_LDS>
+struct Tables {
+    CDoubles gd;
+    CInts gi;
+    const double* ld;  // LDS copies (== global blobs when !TAB_LDS)
+    const int* li;
+    const double* __restrict__ hd;
+    const int* __restrict__ hi;
+    __device__ __forceinline__ double du(int i) const { return gd[i]; }  // uniform index
+    __device__ __forceinline__ int iu(int i) const { return gi[i]; }
+    __device__ __forceinline__ double dv(int i) const { return TAB_LDS ? ld[i] : hd[i]; }  // per-lane index
+    __device__ __forceinline__ int iv(int i) const { return TAB_LDS ? li[i] : hi[i]; }
+};
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ double dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// RN(x / y) for a divisor known in advance, given z = RN(1/y) computed once on the host:
+// five multiply-adds instead of the ~25-instruction IEEE division expansion.  q1 = RN(x z) is
+// within 1.5 ulp of x/y; one residual correction (r = x - q y, exact up to a rounding that
+// cannot matter at that magnitude) makes q2 the rounding of a value within 2^-52 ulp of x/y, hence
+// a faithful quotient; Markstein's theorem (z correctly rounded, q faithful, residual by FMA)
+// then makes the second correction EXACTLY RN(x/y).  Preconditions: y, z finite non-zero
+// normal, x finite, no underflow of the quotient (durations, indices and bin coordinates are
+// many orders of magnitude inside the normal range).  A zero x may come back with the other
+// sign (every use adds it or truncates it).  `tests/test_gpu_parity.py` checks the sequence
+// against the host's division on random and adversarial operands.
+__device__ __forceinline__ double div_known(double x, double y, double z) {
+    double q = x * z;
+    double r = __builtin_fma(-q, y, x);
+    q = __builtin_fma(r, z, q);
+    r = __builtin_fma(-q, y, x);
+    return __builtin_fma(r, z, q);
+}
+constexpr double kRcpCcm = 1.0 / kCcm;   // correctly rounded by the compiler
+
+// np.interp-like clamped interpolation (_kernel.pyx:219-238).  The reference bisects the
+// whole table for `lo` = the largest index with xs[lo] <= x; that index is unique, so any
+// search that finds it gives identical results.  Here a host-built guide table (n buckets of
+// equal width over [xs[0], xs[n-1]], entry b = largest i with xs[i] <= left edge of bucket b)
+// brackets the answer to a bucket first, the bracket is VALIDATED against the table (falls
+// back to the full range if rounding put x in a neighbouring bucket), and the same bisection
+// runs inside the bracket: typically 0-1 steps instead of ~log2(n) dependent LDS reads.
+// UNI: the descriptor (xs, ys, n, ...) is wave-uniform, so the table ends come through the scalar
+// cache.  `w` (NaN = no): the abscissae are xs[0] + i*w bit for bit AND every interval has the bits
+// of w (both checked by the host), so the reference's index is found by arithmetic — no table
+// walk, no dependent LDS reads — and validated against the (computed) neighbours.  `yw` likewise for
+// the ordinates (the inverse-CDF lookup returns wavelengths of an evenly spaced grid).
+template <bool TAB_LDS, bool UNI>
+__device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n,
+                                                 int guide, double scale, int hist, double rcp,
+                                                 double w = __builtin_nan(""), double yw = __builtin_nan("")) {
+    auto end = [&](int i) { return UNI ? T.du(i) : T.dv(i); };
+    if (n == 1) return end(ys);
+    const double x0 = end(xs), xl = end(xs + n - 1);
+    if (x <= x0) return end(ys);
+    if (hist ? x > xl : x >= xl) return end(ys + n - 1);  // step tables search x == xl (plateaus)
+    if (!hist && w == w) {
+        int i = (int)((x - x0) * rcp);
+        i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+        double xlo = x0 + (double)i * w;
+        if (x < xlo) { i -= 1; xlo = x0 + (double)i * w; }
+        double xhi = x0 + (double)(i + 1) * w;
+        if (!(x < xhi)) { i += 1; xlo = xhi; xhi = x0 + (double)(i + 1) * w; }
+        if (xlo <= x && x < xhi) {   // always, the product being within an ulp or two of the true quotient
+            const double ylo = T.dv(ys + i), yhi = T.dv(ys + i + 1);
+            return ylo + div_known((yhi - ylo) * (x - xlo), xhi - xlo, rcp);
+        }
+    }
+    int b = (int)((x - x0) * scale);
+    b = b < 0 ? 0 : (b > n - 2 ? n - 2 : b);
+    int lo = T.iv(guide + b), hi = T.iv(guide + b + 1) + 1;
+    if (hi > n - 1) hi = n - 1;
+    // the abscissae travel with the indices, so nothing is re-read after the search
+    double xlo = T.dv(xs + lo), xhi = T.dv(xs + hi);
+    if (hist) {
+        // histogram-sampled table (extension; Python Distribution's hist branch): the value of
+        // the first abscissa >= x, i.e. ys[#{xs_i < x}] — same bracket, strict comparison
+        if (!(xlo < x)) lo = 0;          // xs[0] < x is known here
+        if (!(x <= xhi)) hi = n - 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (T.dv(xs + mid) < x) lo = mid; else hi = mid;
+        }
+        return T.dv(ys + hi);
+    }
+    if (!(xlo <= x)) { lo = 0; xlo = x0; }
+    if (!(x < xhi)) { hi = n - 1; xhi = xl; }
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        const double xm = T.dv(xs + mid);
+        if (xm <= x) { lo = mid; xlo = xm; } else { hi = mid; xhi = xm; }
+    }
+    double ylo, yhi;
+    if (yw == yw) {   // ordinates of an evenly spaced grid: computed, same bits as the table's
+        const double y0 = end(ys);
+        ylo = y0 + (double)lo * yw; yhi = y0 + (double)hi * yw;
+    } else {
+        ylo = T.dv(ys + lo); yhi = T.dv(ys + hi);
+    }
+    if (xhi == xlo) return ylo;
+    // evenly spaced abscissae (every interval has the same bits, checked by the host): the
+    // divisor is known in advance, see div_known
+    const double num = (yhi - ylo) * (x - xlo), width = xhi - xlo;
+    return ylo + (rcp == rcp ? div_known(num, width, rcp) : num / width);
+}
+// same, tables in global memory (emitter spectra)
+__device__ __forceinline__ double interp_global(const double* xs, const double* ys, int n, double x) {
+    if (n == 1) return ys[0];
+    if (x <= xs[0]) return ys[0];
+    if (x >= xs[n - 1]) return ys[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xs[mid] <= x) lo = mid; else hi = mid;
+    }
+    if (xs[hi] == xs[lo]) return ys[lo];
+    return ys[lo] + (ys[hi] - ys[lo]) * (x - xs[lo]) / (xs[hi] - xs[lo]);
+}
+
+__device__ __forceinline__ V3 sphere_direction(double theta, double phi) {
+    double st, ct, sp, cp;
+    pvt_sincos(theta, &st, &ct);
+    pvt_sincos(phi, &sp, &cp);
+    return V3{st * cp, st * sp, ct};
+}
+
+// phase functions (_kernel.pyx:455-476); draw order is part of the contract
+__device__ __forceinline__ V3 sample_phase(int type, double param, Rng& rng) {
+    double theta, phi;
+    if (type == PVT_PHASE_HG && pvt_fabs(param) >= kEps) {
+        double g = param;
+        double g1 = rng_uniform(rng);
+        double s = 2.0 * g1 - 1.0;
+        double q = (1.0 - g * g) / (1.0 + g * s);
+        double mu = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
+        phi = 2.0 * kPi * rng_uniform(rng);
+        theta = pvt_acos(mu);
+    } else if (type == PVT_PHASE_CONE) {
+        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+        theta = pvt_asin(pvt_sqrt(g1) * pvt_sin(param));
+        phi = 2.0 * kPi * g2;
+    } else {
+        double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+        phi = 2.0 * kPi * g1;
+        theta = pvt_acos(2.0 * g2 - 1.0);
+    }
+    return sphere_direction(theta, phi);
+}
+
+// ----------------------------------------------------------- emission
+// One ray from its own stream (mirrors oracle pvt_oracle_emit; distributions of
+// reference pvtrace/engine/emit.py:22-89).
+__device__ __forceinline__ void emit_one(const KArgs& A, unsigned long long gi, V3& pos, V3& dir, double& wl) {
+    const double* ed = A.ed;
+    const int* ei = A.ei;
+    const EmitOff& E = A.eoff;
+    Rng rng;
+    rng_seed(rng, (A.emit_seed + gi) ^ kEmitSalt);
+    int li = (int)(gi % (unsigned long long)A.n_lights);
+    if (ei[E.wl_type + li] == PVT_WL_SPECTRUM) {
+        double u = rng_uniform(rng);
+        int s = ei[E.wl_spec_start + li];
+        wl = interp_global(ed + E.spec_cdf + s, ed + E.spec_x + s, ei[E.wl_spec_n + li], u);
+    } else {
+        wl = ed[E.wl_value + li];
+    }
+    V3 lp{0.0, 0.0, 0.0}, ld{0.0, 0.0, 1.0};
+    const double* pp = ed + E.pos_param + li * 3;
+    int pt = ei[E.pos_type + li];
+    if (pt == PVT_POS_RECT) {
+        lp.x = -pp[0] + 2.0 * pp[0] * rng_uniform(rng);
+        lp.y = -pp[1] + 2.0 * pp[1] * rng_uniform(rng);
+    } else if (pt == PVT_POS_CIRCLE) {
+        double ang = 2.0 * kPi * rng_uniform(rng);
+        double rad = pvt_sqrt(rng_uniform(rng)) * pp[0];
+        double s, c;
+        pvt_sincos(ang, &s, &c);
+        lp.x = rad * c;
+        lp.y = rad * s;
+    } else if (pt == PVT_POS_CUBE) {
+        lp.x = -pp[0] + 2.0 * pp[0] * rng_uniform(rng);
+        lp.y = -pp[1] + 2.0 * pp[1] * rng_uniform(rng);
+        lp.z = -pp[2] + 2.0 * pp[2] * rng_uniform(rng);
+    }
+    double prm = ed[E.dir_param + li];
+    int dt = ei[E.dir_type + li];
+    if (dt == PVT_DIR_CONE) ld = sample_phase(PVT_PHASE_CONE, prm, rng);
+    else if (dt == PVT_DIR_ISOTROPIC) ld = sample_phase(PVT_PHASE_ISOTROPIC, 0.0, rng);
+    else if (dt == PVT_DIR_HG) ld = sample_phase(PVT_PHASE_HG, prm, rng);
+    else if (dt == PVT_DIR_LAMBERTIAN) {
+        double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
+        ld = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
+    }
+    const double* m = ed + E.l2w + li * 16;
+    pos.x = m[0] * lp.x + m[1] * lp.y + m[2] * lp.z + m[3];
+    pos.y = m[4] * lp.x + m[5] * lp.y + m[6] * lp.z + m[7];
+    pos.z = m[8] * lp.x + m[9] * lp.y + m[10] * lp.z + m[11];
+    dir.x = m[0] * ld.x + m[1] * ld.y + m[2] * ld.z;
+    dir.y = m[4] * ld.x + m[5] * ld.y + m[6] * ld.z;
+    dir.z = m[8] * ld.x + m[9] * ld.y + m[10] * ld.z;
+}
+
+__global__ void __launch_bounds__(kBlock) emit_kernel(KArgs A, double* opos, double* odir, double* owl) {
+    unsigned int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= A.n_rays) return;
+    V3 p, d;
+    double wl;
+    emit_one(A, A.ray_offset + i, p, d, wl);
+    opos[i * 3] = p.x; opos[i * 3 + 1] = p.y; opos[i * 3 + 2] = p.z;
+    odir[i * 3] = d.x; odir[i * 3 + 1] = d.y; odir[i * 3 + 2] = d.z;
+    owl[i] = wl;
+}
+
+// Self-test hook: evaluates one elementary function per element on the device so the
+// tests can prove the premise of the whole parity scheme (IEEE divide / sqrt and the
+// pvt_math.h functions produce the same bits on gfx950 as on the host).
+__global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, double* y, long long n) {
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double v = x[i], r;
+    switch (fn) {
+        case 0: r = pvt_log(v); break;
+        case 1: r = pvt_sin(v); break;
+        case 2: r = pvt_cos(v); break;
+        case 3: r = pvt_asin(v); break;
+        case 4: r = pvt_acos(v); break;
+        case 5: r = pvt_sqrt(v); break;
+        case 6: r = 1.0 / v; break;
+        case 7: { double s, c; pvt_sincos(v, &s, &c); r = s * c; break; }
+        case 8: { Rng g; rng_seed(g, (unsigned long long)v); rng_uniform(g); r = rng_uniform(g); break; }
+        case 9: r = v / (v + 3.0); break;
+        case 10: r = div_known(v, kCcm, kRcpCcm); break;
+        case 11: r = div_known(v, 1.5, 1.0 / 1.5); break;
+        case 12: r = div_known(v, 800.0 - 400.0, 1.0 / (800.0 - 400.0)); break;
+        default: { double d = v * 0.7310585786300049 + 0.25; r = div_known(v, d, 1.0 / d); break; }
+    }
+    y[i] = r;
+}
+
+// ----------------------------------------------------------- event log
+template <bool RECORD>
+__device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev, int kind, int hit,
+                                        int container, int adjacent, int component, int source,
+                                        const V3& pos, const V3& dir, bool has_normal, const V3& nrm,
+                                        double wl, double travelled, double duration) {
+    if constexpr (RECORD) {
+        if (base < 0 || nev >= A.max_events) return;
+        long long row = base + nev;
+        const PvtEventLog& L = A.log;
+        L.kind[row] = (uint8_t)kind;
+        L.hit[row] = hit;
+        L.container[row] = container;
+        L.adjacent[row] = adjacent;
+        L.component[row] = component;
+        L.source[row] = source;
+        L.position[row * 3] = pos.x; L.position[row * 3 + 1] = pos.y; L.position[row * 3 + 2] = pos.z;
+        L.direction[row * 3] = dir.x; L.direction[row * 3 + 1] = dir.y; L.direction[row * 3 + 2] = dir.z;
+        L.normal[row * 3] = has_normal ? nrm.x : 0.0;
+        L.normal[row * 3 + 1] = has_normal ? nrm.y : 0.0;
+        L.normal[row * 3 + 2] = has_normal ? nrm.z : 0.0;
+        L.wavelength[row] = wl;
+        L.travelled[row] = travelled;
+        L.duration[row] = duration;
+        nev += 1;
+    }
+}
+
+// LDS accumulator layout (per workgroup), after the table copies:
+//   u32 cross[n_rec] | u32 distinct[n_rec] | f64 sums[n_rec*8] | u32 bins[total_bins] (if they fit)
+struct Accum {
+    unsigned int* cross;
+    unsigned int* distinct;
+    double* sums;
+    unsigned int* bins;  // null -> straight to global
+};
+
+template <int SEENW>
+struct Seen {
+    unsigned long long w[SEENW];
+};
+
+// --------------------------------------------------------------- kernel
+// Lane classes after the "where does the ray go" stage of a step; the divergent bodies are keyed on them.
+enum { CLS_NONE = 0, CLS_SURF = 1, CLS_TERM = 2, CLS_ABS = 3 };
+
+// Photon-state words that travel through the LDS exchange buffer (one slot = exchange_words | 1 u64 words):
+//   0-2 position, 3-5 direction, 6 wavelength, 7 pathlength, 8 clock, 9-12 RNG, 13 step count | source,
+//   14 class + pending event ids, 15.. seen-mask words, then (RECORD) log cursor, (MESH) crossed triangle
+template <bool RECORD, int SEENW, bool MESH>
+constexpr int exchange_words() { return 15 + SEENW + (RECORD ? 1 : 0) + (MESH ? 1 : 0); }
+
+// MESH: the scene has triangle-mesh nodes.  The BVH walk costs ~35 VGPRs, so scenes made of
+// analytic shapes run the variant compiled without it (one more wave per SIMD).
+template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
+__global__ void __launch_bounds__(kBlock) trace_kernel(KArgs A) {
+    extern __shared__ double smem[];
+    const Lay L = A.lay;
+    const bool coated = A.n_coat > 0;  // wave-uniform
+
+    // ---- stage tables + zero accumulators --------------------------------
+    double* lds_d = smem;
+    int nd_lds = TAB_LDS ? A.nd : 0;
+    int ni_lds = TAB_LDS ? ((A.ni + 1) & ~1) : 0;  // keep 8-byte alignment after the ints
+    int* lds_i = reinterpret_cast<int*>(lds_d + nd_lds);
+    double* acc_sums = reinterpret_cast<double*>(lds_i + ni_lds);
+    unsigned int* acc_cross = reinterpret_cast<unsigned int*>(acc_sums + A.n_rec * 8);
+    unsigned int* acc_distinct = acc_cross + A.n_rec;
+    unsigned int* acc_bins = acc_distinct + A.n_rec;
+    int* ctl = reinterpret_cast<int*>(acc_bins + ((A.bins_in_lds ? A.total_bins : 0) + 1 & ~1));
+    unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [xslots][exchange_words | 1]
+    if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
+    if constexpr (TAB_LDS) {
+        for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
+        for (int i = threadIdx.x; i < A.ni; i += kBlock) lds_i[i] = A.gi[i];
+    }
+    for (int i = threadIdx.x; i < A.n_rec * 8; i += kBlock) acc_sums[i] = 0.0;
+    for (int i = threadIdx.x; i < A.n_rec * 2; i += kBlock) acc_cross[i] = 0u;
+    if (A.bins_in_lds)
+        for (int i = threadIdx.x; i < A.total_bins; i += kBlock) acc_bins[i] = 0u;
+    __syncthreads();
+
+    Tables<TAB_LDS> T{(CDoubles)A.gd, (CInts)A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi, A.gd, A.gi};
+
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    // ---- per-photon state --------------------------------------------------
+    bool alive = false;
+    V3 pos{0, 0, 0}, dir{0, 0, 1};
+    double wl = 0.0, travelled = 0.0, duration = 0.0;
+    Rng rng{0, 0, 0, 0};
+    int count = 0, source = -1, nev = 0;
+    long long base = -1;
+    long long rec_slot = 0;
+    Seen<SEENW> seen;
+#pragma unroll
+    for (int w = 0; w < SEENW; w++) seen.w[w] = 0ull;
+
+#if PVT_STATS
+    unsigned long long st_iters = 0, st_lane_steps = 0, st_drain_iters = 0, st_drain_lane_steps = 0, st_mark = 0;
+    unsigned long long st_b[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bulk-phase cycles per section (the waves of a SIMD interleave)
+    unsigned long long st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bulk-phase lane counts per section
+#define PVT_MARK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); if (!feeding_over) st_b[k] += now_ - st_mark; st_mark = now_; } while (0)
+#define PVT_COUNT(k, pred) do { unsigned long long b_ = __ballot(pred); if (!feeding_over) st_c[k] += __popcll(b_); } while (0)
+#else
+#define PVT_MARK(k) do {} while (0)
+#define PVT_COUNT(k, pred) do {} while (0)
+#endif
+    // ---- ray supply (all wave-uniform) -------------------------------------------------------------
+    // A wave owns a current window [w_next, w_end) of ray indices and a spare one [x_next, x_end); a
+    // cursor claim (one atomicAdd per 64 rays) is always in flight so that its round trip never stalls
+    // the wave.  Rays are PREFETCHED: right after a regrouping, the lanes that are about to end
+    // (terminal photons, empty lanes) take their next ray index and issue the loads; the data arrives
+    // while the bodies of the step run and is installed at the top of the next step.  Without this the
+    // one wave of a workgroup that holds the ending photons would stall on its loads and, through the
+    // rendezvous, stall the other three.
+    unsigned int w_next = 0, w_end = 0, x_next = 0, x_end = 0;
+    unsigned int claim_reg = 0;          // lane 0: return value of the cursor atomic in flight
+    bool claim_pending = false;
+    bool dry = false;            // this wave has seen the ray cursor run dry
+    bool feeding_over = false;   // cursor dry and every window of the workgroup consumed: photons only die from here on
+    V3 nx_pos{0, 0, 0}, nx_dir{0, 0, 1};
+    double nx_wl = 0.0;
+    unsigned int nx_i = 0;
+    bool nx_have = false;
+    auto service_claims = [&]() {
+        if (claim_pending) {   // issued a step ago: has long arrived
+            const unsigned int b = __builtin_amdgcn_readfirstlane(claim_reg);
+            claim_pending = false;
+            if (b >= A.n_rays) dry = true;
+            else { x_next = b; x_end = (A.n_rays - b < (unsigned int)kChunk) ? A.n_rays : b + kChunk; }
+        }
+        if (w_next >= w_end && x_next < x_end) { w_next = x_next; w_end = x_end; x_next = 0; x_end = 0; }
+        if (!dry && x_next >= x_end) {
+            if (lane == 0) claim_reg = atomicAdd(A.cursor, (unsigned int)kChunk);
+            claim_pending = true;
+        }
+    };
+    auto prefetch = [&](bool wants) {
+        unsigned long long need = __ballot(wants && !nx_have);
+        for (int pass = 0; pass < 2 && need != 0ull; pass++) {
+            if (w_next >= w_end) {
+                if (x_next >= x_end) break;
+                w_next = x_next; w_end = x_end; x_next = 0; x_end = 0;
+            }
+            const unsigned int avail = w_end - w_next;
+            const unsigned int rank = __popcll(need & lane_lt), want = __popcll(need);
+            if (wants && !nx_have && rank < avail) {
+                nx_i = w_next + rank;
+                nx_have = true;
+                if constexpr (!EMIT) {
+                    const unsigned long long i = nx_i;
+                    nx_pos = V3{A.pos[i * 3ull], A.pos[i * 3ull + 1], A.pos[i * 3ull + 2]};
+                    nx_dir = V3{A.dir[i * 3ull], A.dir[i * 3ull + 1], A.dir[i * 3ull + 2]};
+                    nx_wl = A.wl[i];
+                }
+            }
+            w_next += (want < avail) ? want : avail;
+            need = __ballot(wants && !nx_have);
+        }
+    };
+    // Regrouping state (all wave-uniform).  `members`: waves of the workgroup still running; every
+    // member holds the same value (it only changes at the rendezvous below).
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = A.xslots;
+    int members = (1 << kWaves) - 1, parity = 0;
+
+    service_claims();   // first claim ...
+    service_claims();   // ... resolved (the one exposed round trip), second one in flight
+    prefetch(true);
+
+    for (;;) {
+        // ================= install the prefetched rays in the empty lanes ==============================
+        // After a regrouping the dead lanes of a workgroup sit together (the photons that ended last step
+        // were grouped as "terminal"), so most waves skip this block and the others run it with many lanes.
+        if (nx_have) {
+            const unsigned int i = nx_i;
+            nx_have = false;
+            if constexpr (EMIT) {
+                emit_one(A, A.ray_offset + i, pos, dir, wl);
+            } else {
+                pos = nx_pos; dir = nx_dir; wl = nx_wl;
+            }
+            rng_seed(rng, A.seed + (unsigned long long)i);
+            travelled = 0.0;
+            duration = 0.0;
+            count = 0;
+            source = -1;
+            nev = 0;
+#pragma unroll
+            for (int w = 0; w < SEENW; w++) seen.w[w] = 0ull;
+            alive = true;
+            if constexpr (RECORD) {
+                base = -1;
+                if (A.record_every > 0 && (long long)i % A.record_every == 0) {
+                    rec_slot = (long long)i / A.record_every;
+                    base = rec_slot * A.max_events;
+                }
+                log_row<RECORD>(A, base, nev, PVT_EV_GENERATE, -1, -1, -1, -1, source, pos, dir, false,
+                                pos, wl, travelled, duration);
+            }
+        }
+#if PVT_STATS
+        {
+            unsigned long long live = __popcll(__ballot(alive));
+            st_iters += 1; st_lane_steps += live;
+            if (feeding_over) { st_drain_iters += 1; st_drain_lane_steps += live; }
+        }
+#endif
+        PVT_MARK(0);  // install
+        PVT_COUNT(0, alive);
+
+        // ================= stage 1: where does the ray go?  (every live lane) ==================
+        // pending event of this step (written to the log / tallied once, re-converged, at the end)
+        int cls = CLS_NONE;
+        int ev_kind = -1, ev_hit = -1, ev_container = -1, ev_adjacent = -1, ev_component = -1;
+        int t_sel = -1;
+        int tri1 = -1;   // triangle record of the nearest crossing when it lies on a mesh
+        if (alive) {
+            count += 1;
+            bool budget_kill = false;
+            if constexpr (RECORD) budget_kill = (base >= 0 && nev >= A.max_events - 1);
+            if (budget_kill) {
+                // event budget exhausted: KILL row, no tally (_kernel.pyx:658-663)
+                ev_kind = PVT_EV_KILL;
+                cls = CLS_TERM;
+            } else {
+                // ---- intersect every node, fold nearest/second/container ----
+                int nhits = 0, n1 = -1, n2 = -1, cnode = -1;
+                double t1 = INFINITY, t2 = INFINITY, cbest = INFINITY;
+                V3 d{0, 0, 0};
+                double inv[3] = {0, 0, 0};
+                bool inv_ok = false;   // wave-uniform
+                int rot = -1;          // rotation class of `d` (wave-uniform)
+                for (int node = 0; node < A.n_nodes; node++) {
+                    const int m = node * ND + ND_W2L;
+                    V3 o;
+                    o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + T.du(m + 3);
+                    o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + T.du(m + 7);
+                    o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + T.du(m + 11);
+                    // Nodes whose world->local rotations are bit-identical (the host files them under the
+                    // first such node) see the same local direction: it and its reciprocals are reused.
+                    const int rc = T.iu(node * NI + NI_ROT);
+                    if (rc != rot) {
+                        d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
+                        d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
+                        d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
+                        rot = rc;
+                        inv_ok = false;
+                    }
+                    const int gp = node * ND + ND_PARAMS;
+                    const int gt = T.iu(node * NI + NI_GEOM);
+                    // Hits are folded as they are found, in the reference's (node, k)
+                    // order, so no per-ray hit list exists; the tie-breaks equal the
+                    // reference's argmin scans over its hit arrays (:684-714).
+                    int nl = 0;
+                    double tfirst = 0.0;
+                    auto fold = [&](double t) {
+                        if (nl == 0) tfirst = t;
+                        nl += 1;
+                        if (nhits == 0) { t1 = t; n1 = node; }
+                        else if (t < t1) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
+                        else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
+                        nhits += 1;
+                    };
+                    if (MESH && gt == PVT_GEOM_MESH) {
+                        // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
+                        // forward crossing of the node's triangles, found by a stack-free walk of
+                        // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
+                        // (t, face) so the result does not depend on the walk order.
+                        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+                        const double ax = pvt_fabs(d.x), ay = pvt_fabs(d.y), az = pvt_fabs(d.z);
+                        const int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+                        int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+                        auto pick = [](const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
+                        const double dz = pick(dd, kz);
+                        if (dz < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
+                        const double shx = pick(dd, kx) / dz, shy = pick(dd, ky) / dz, shz = 1.0 / dz;
+                        // Box culling only has to be conservative (a false hit costs a triangle test, a
+                        // false miss would lose a crossing).  A ray parallel to a slab gets a huge finite
+                        // reciprocal instead of inf: inside the slab the two plane distances then have
+                        // opposite signs (interval covers everything), outside the same sign (pushed out
+                        // of range, or a harmless false hit), and 0 * inf = NaN can never arise.
+                        double minv[3];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) minv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
+                        long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
+                        int i = T.iu(node * NI + NI_MESH);
+                        const int end = A.bvh[i].skip;
+                        while (i < end) {
+                            const pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
+                            double tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                const double ta = ((double)b.lo[a] - oo[a]) * minv[a], tb = ((double)b.hi[a] - oo[a]) * minv[a];
+                                tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                                tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                            }
+                            if (tmax < tmin || tmax < 0.0) { i = b.skip; continue; }
+                            const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
+                            const pvt::MeshTri* tr = A.tris + tri_start;
+                            for (int k = 0; k < tn; k++, tr++) {
+                                double va[3], vb[3], vc[3];
+#pragma unroll
+                                for (int a = 0; a < 3; a++) {
+                                    va[a] = tr->v[a] - oo[a]; vb[a] = tr->v[3 + a] - oo[a]; vc[a] = tr->v[6 + a] - oo[a];
+                                }
+                                const double az_ = pick(va, kz), bz_ = pick(vb, kz), cz_ = pick(vc, kz);
+                                const double axs = pick(va, kx) - shx * az_, ays = pick(va, ky) - shy * az_;
+                                const double bxs = pick(vb, kx) - shx * bz_, bys = pick(vb, ky) - shy * bz_;
+                                const double cxs = pick(vc, kx) - shx * cz_, cys = pick(vc, ky) - shy * cz_;
+                                const double u = cxs * bys - cys * bxs;
+                                const double v = axs * cys - ays * cxs;
+                                const double w = bxs * ays - bys * axs;
+                                if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) continue;
+                                const double det = u + v + w;
+                                if (det == 0.0) continue;
+                                const double sg = det < 0.0 ? -1.0 : 1.0;
+                                auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
+                                if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) continue;
+                                if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) continue;
+                                if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
+                                const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
+                                if (!(t > kEps)) continue;
+                                const long long face = tr->face;
+                                const int tri = tri_start + k;
+                                if (nl == 0 || t < tfirst) tfirst = t;
+                                nl += 1;
+                                if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
+                                else if (t < t1 || (t == t1 && f1 >= 0 && face < f1)) {
+                                    t2 = t1; n2 = n1; f2 = f1; t1 = t; n1 = node; tri1 = tri; f1 = face;
+                                } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
+                                nhits += 1;
+                            }
+                            i += 1;
+                        }
+                    } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
+                    double tmin = -INFINITY, tmax = INFINITY;
+                    bool miss = false;
+                    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+                    if (!inv_ok) {   // 1/d per axis, shared by consecutive nodes whose rotations have the same bits
+#pragma unroll
+                        for (int a = 0; a < 3; a++) inv[a] = 1.0 / dd[a];   // (inf for a zero component: never used below)
+                        inv_ok = true;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        double sz = T.du(gp + a);
+                        double lo = -0.5 * sz, hi = 0.5 * sz;
+                        if (pvt_fabs(dd[a]) < 1e-300) {
+                            if (oo[a] < lo || oo[a] > hi) miss = true;
+                        } else {
+                            double ta = (lo - oo[a]) * inv[a], tb = (hi - oo[a]) * inv[a];
+                            if (ta > tb) { double tmp = ta; ta = tb; tb = tmp; }
+                            if (ta > tmin) tmin = ta;
+                            if (tb < tmax) tmax = tb;
+                        }
+                    }
+                    if (!miss && !(tmax < tmin)) {
+                        if (tmin > kEps) fold(tmin);
+                        if (tmax > kEps) fold(tmax);
+                    }
+                } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
+                        double radius = T.du(gp);
+                        double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
+                        double disc = b * b - 4.0 * a * c;
+                        if (!(disc < 0.0)) {
+                            double sq = pvt_sqrt(disc);
+                            double t = (-b - sq) / (2.0 * a);
+                            if (t > kEps) fold(t);
+                            t = (-b + sq) / (2.0 * a);
+                            if (t > kEps) fold(t);
+                        }
+                    } else {  // capped z cylinder (:301-345)
+                        double half = 0.5 * T.du(gp), radius = T.du(gp + 1);
+                        double a = d.x * d.x + d.y * d.y;
+                        if (a > 1e-300) {
+                            double b = 2.0 * (o.x * d.x + o.y * d.y);
+                            double c = o.x * o.x + o.y * o.y - radius * radius;
+                            double disc = b * b - 4.0 * a * c;
+                            if (disc >= 0.0) {
+                                double sq = pvt_sqrt(disc);
+                                double t = (-b - sq) / (2.0 * a);
+                                double z = o.z + t * d.z;
+                                if (z > -half && z < half && t > kEps) fold(t);
+                                t = (-b + sq) / (2.0 * a);
+                                z = o.z + t * d.z;
+                                if (z > -half && z < half && t > kEps) fold(t);
+                            }
+                        }
+                        if (pvt_fabs(d.z) > 1e-300) {
+                            double t = (-half - o.z) / d.z;
+                            double x = o.x + t * d.x, y = o.y + t * d.y;
+                            if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                            t = (half - o.z) / d.z;
+                            x = o.x + t * d.x;
+                            y = o.y + t * d.y;
+                            if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                        }
+                    }
+                    if (nl == 1 && tfirst < cbest) { cbest = tfirst; cnode = node; }
+                }
+                if (nhits == 0) {
+                    // nothing ahead: the ray vanishes silently (:681-682)
+                    if constexpr (RECORD) {
+                        if (base >= 0) A.log.counts[rec_slot] = nev;
+                    }
+                    alive = false;
+                } else {
+                    const int hit = n1;
+                    const double t0 = t1;
+                    int container, adjacent;
+                    if (nhits == 1) { container = hit; adjacent = -1; }
+                    else {
+                        container = (cnode >= 0) ? cnode : hit;
+                        adjacent = (container == hit) ? n2 : hit;
+                    }
+                    ev_container = container;
+                    if (count > A.maxsteps) {  // (:716-723)
+                        ev_kind = PVT_EV_KILL;
+                        t_sel = PVT_REC_KILLED;
+                        cls = CLS_TERM;
+                    } else {
+                        const double n_container = T.dv(container * ND + ND_N);
+                        if (hit == A.root) {  // leaves the scene (:728-744)
+                            pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
+                            travelled += t0;
+                            duration += div_known(t0 * n_container, kCcm, kRcpCcm);
+                            ev_kind = PVT_EV_EXIT; ev_hit = hit; ev_adjacent = adjacent;
+                            t_sel = PVT_REC_EXIT;
+                            cls = CLS_TERM;
+                        } else {
+                            // ---- volume absorption (:746-760) ----------------
+                            const int cbase = T.iv(container * NI + NI_CSTART);
+                            const int ccount = T.iv(container * NI + NI_CCOUNT);
+                            // alpha = sum of the components' coefficients; the running partial
+                            // sums ARE the cumulative thresholds the reference recomputes when it
+                            // picks the absorbing component (:768-781), so keep the first four
+                            double alpha = 0.0, pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0;
+                            for (int k = 0; k < ccount; k++) {
+                                const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
+                                alpha += interp_clamped<TAB_LDS, false>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
+                                                                        T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
+                                                                        T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
+                                if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
+                                else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
+                            }
+                            double depth = INFINITY;
+                            if (alpha > kAlphaZero) depth = ABL(5) ? rng_uniform(rng) / alpha : -pvt_log(1.0 - rng_uniform(rng)) / alpha;
+
+                            if (depth < t0) {  // absorbed (:762-832)
+                                pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
+                                travelled += depth;
+                                duration += div_known(depth * n_container, kCcm, kRcpCcm);
+                                const double target = rng_uniform(rng) * alpha;
+                                int comp = cbase;
+                                if (ccount <= 4) {
+                                    if (target <= pre0) comp = cbase;
+                                    else if (ccount > 1 && target <= pre1) comp = cbase + 1;
+                                    else if (ccount > 2 && target <= pre2) comp = cbase + 2;
+                                    else if (ccount > 3 && target <= pre3) comp = cbase + 3;
+                                } else {
+                                    double running = 0.0;
+                                    for (int k = 0; k < ccount; k++) {
+                                        const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
+                                        running += interp_clamped<TAB_LDS, false>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
+                                                                                  T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
+                                                                                  T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
+                                        if (target <= running) { comp = cbase + k; break; }
+                                    }
+                                }
+                                log_row<RECORD>(A, base, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
+                                                dir, false, pos, wl, travelled, duration);
+                                ev_component = comp;
+                                // radiative or not (:783-789): decided here, so that photons about to be re-emitted
+                                // and photons about to be lost can be grouped apart
+                                const int ctype = T.iv(L.comp_i + comp * CI + CI_TYPE);
+                                bool radiative = false;
+                                if (ctype == PVT_COMP_SCATTERER || ctype == PVT_COMP_LUMINOPHORE)
+                                    radiative = rng_uniform(rng) < T.dv(L.comp_d + comp * CD + CD_QY);
+                                if (radiative) {
+                                    cls = CLS_ABS;
+                                } else {
+                                    const double tau = T.dv(L.comp_d + comp * CD + CD_TAU_NR);
+                                    if (ctype == PVT_COMP_REACTOR) { ev_kind = PVT_EV_REACT; t_sel = PVT_REC_REACTED; }
+                                    else { ev_kind = PVT_EV_NONRADIATIVE; t_sel = PVT_REC_LOST; }
+                                    if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;   // the last draw of this history
+                                    cls = CLS_TERM;
+                                }
+                            } else {
+                                // ---- surface interaction (:834-895) ---------
+                                pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
+                                travelled += t0;
+                                duration += div_known(t0 * n_container, kCcm, kRcpCcm);
+                                ev_hit = hit;
+                                if (adjacent < 0) {  // malformed scene (:840-845)
+                                    ev_kind = PVT_EV_KILL;
+                                    cls = CLS_TERM;
+                                } else {
+                                    ev_adjacent = adjacent;
+                                    cls = CLS_SURF;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        PVT_MARK(1);  // intersection + absorption sampling
+
+        // ================= regroup the workgroup's photons by what they need next ===================
+        // In the bulk of a launch every wave holds surface-bound, re-emitting and ending photons side by side
+        // and would pay for all three bodies below with a third to a half of its lanes each.  Which lane
+        // carries a photon never affects its history (RNG stream, seen-mask and log cursor travel with it),
+        // so once per step the waves of a workgroup rendezvous, publish how many photons of each class they
+        // hold, and lay the workgroup's photons out as [surface | terminal | re-emitting | dead] over the lanes
+        // of the member waves: most waves then run ONE body with full lanes, the dead lanes (refilled next
+        // step) sit together, and in the drain phase the survivors pack into the lowest waves while emptied
+        // waves retire.  Only misplaced photons move, through `xslots` LDS slots; every wave evaluates the same
+        // plan from the same published counts.  If the movers exceed the slots the highest waves keep their
+        // mix for this step.
+        if (K > 0 && members != (1 << wave)) {
+            const unsigned long long m_s = __ballot(cls == CLS_SURF), m_t = __ballot(cls == CLS_TERM), m_a = __ballot(cls == CLS_ABS);
+            int* pub = ctl + CTL_PUB + parity * kWaves;   // double-buffered by step parity
+            parity ^= 1;
+            if (lane == 0)
+                pub[wave] = (int)__popcll(m_s) | ((int)__popcll(m_t) << 7) | ((int)__popcll(m_a) << 14) | ((dry ? 1 : 0) << 21) |
+                            ((w_next >= w_end && x_next >= x_end && !claim_pending ? 1 : 0) << 22);
+            __syncthreads();  // A: counts are in
+            int n[kWaves][3];
+            bool any_dry = false, all_empty = true;
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) {
+                int v = 0;
+                if ((members >> w) & 1) {
+                    v = __builtin_amdgcn_readfirstlane(pub[w]);
+                    any_dry = any_dry || ((v >> 21) & 1);
+                    all_empty = all_empty && ((v >> 22) & 1);
+                }
+                n[w][0] = v & 127; n[w][1] = (v >> 7) & 127; n[w][2] = (v >> 14) & 127;
+            }
+            feeding_over = any_dry && all_empty;
+            // the plan: the first `np` member waves take part (np shrinks until the movers fit the slots)
+            int np = __popc((unsigned)members);
+            int stay_me[3] = {0, 0, 0}, def_me[3] = {0, 0, 0}, sbase[3] = {0, 0, 0}, rbase[3] = {0, 0, 0};
+            int movers = 0, live_after[kWaves];
+            bool in_plan = false;
+            for (; np >= 2; np--) {
+                int tot[3] = {0, 0, 0};
+                {
+                    int idx = 0;
+#pragma unroll
+                    for (int w = 0; w < kWaves; w++)
+                        if (((members >> w) & 1) && idx < np) { tot[0] += n[w][0]; tot[1] += n[w][1]; tot[2] += n[w][2]; idx++; }
+                }
+                const int r0 = 0, r1 = tot[0], r2 = tot[0] + tot[1], r3 = tot[0] + tot[1] + tot[2];
+                const int rs[4] = {r0, r1, r2, r3};
+                int exc_tot[3] = {0, 0, 0};
+                int exc_before[3] = {0, 0, 0}, def_before[3] = {0, 0, 0};
+                movers = 0;
+                in_plan = false;
+                int idx = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; w++) {
+                    live_after[w] = n[w][0] + n[w][1] + n[w][2];
+                    if (!(((members >> w) & 1) && idx < np)) continue;
+                    const int lo = idx * 64, hi = lo + 64;
+                    live_after[w] = (r3 < hi ? r3 : hi) - lo;
+                    if (live_after[w] < 0) live_after[w] = 0;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        int cap = (rs[c + 1] < hi ? rs[c + 1] : hi) - (rs[c] > lo ? rs[c] : lo);
+                        if (cap < 0) cap = 0;
+                        const int stay = n[w][c] < cap ? n[w][c] : cap;
+                        const int exc = n[w][c] - stay, def = cap - stay;
+                        if (w == wave) { stay_me[c] = stay; def_me[c] = def; sbase[c] = exc_tot[c]; rbase[c] = def_before[c]; in_plan = true; }
+                        exc_tot[c] += exc;
+                        def_before[c] += def;
+                        movers += exc;
+                    }
+                    idx++;
+                }
+                // pool bases: class c's movers sit after those of the classes before it
+                sbase[1] += exc_tot[0]; rbase[1] += exc_tot[0];
+                sbase[2] += exc_tot[0] + exc_tot[1]; rbase[2] += exc_tot[0] + exc_tot[1];
+                if (movers <= K) break;
+            }
+            if (np < 2) {
+                movers = 0; in_plan = false;
+#pragma unroll
+                for (int w = 0; w < kWaves; w++) live_after[w] = n[w][0] + n[w][1] + n[w][2];
+            }
+            constexpr int XW = exchange_words<RECORD, SEENW, MESH>();
+            constexpr int XS = XW | 1;   // slot stride in words: odd, so that consecutive slots start in different LDS banks
+            bool vacated = false;
+            if (movers > 0) {
+                const int c = cls - 1;   // 0 surface, 1 terminal, 2 re-emitting; -1 none
+                if (in_plan && c >= 0) {
+                    const unsigned long long mc = c == 0 ? m_s : (c == 1 ? m_t : m_a);
+                    const int rank = (int)__popcll(mc & lane_lt);
+                    const int stay = c == 0 ? stay_me[0] : (c == 1 ? stay_me[1] : stay_me[2]);
+                    if (rank >= stay) {
+                        const int slot = (c == 0 ? sbase[0] : (c == 1 ? sbase[1] : sbase[2])) + rank - stay;
+                        unsigned long long* xs = xbuf + slot * XS;
+                        xs[0] = pvt_d2u(pos.x); xs[1] = pvt_d2u(pos.y); xs[2] = pvt_d2u(pos.z);
+                        xs[3] = pvt_d2u(dir.x); xs[4] = pvt_d2u(dir.y); xs[5] = pvt_d2u(dir.z);
+                        xs[6] = pvt_d2u(wl); xs[7] = pvt_d2u(travelled); xs[8] = pvt_d2u(duration);
+                        xs[9] = rng.s0; xs[10] = rng.s1; xs[11] = rng.s2; xs[12] = rng.s3;
+                        xs[13] = (unsigned long long)(unsigned int)count | ((unsigned long long)(unsigned int)source << 32);
+                        xs[14] = (unsigned long long)(unsigned int)(cls | ((ev_kind + 1) << 2) | ((ev_hit + 1) << 6) | ((ev_container + 1) << 14) |
+                                                                                   ((ev_adjacent + 1) << 22)) |
+                                              ((unsigned long long)(unsigned int)((t_sel + 1) | ((ev_component + 1) << 4)) << 32);
+#pragma unroll
+                        for (int w = 0; w < SEENW; w++) xs[15 + w] = seen.w[w];
+                        if constexpr (RECORD)
+                            xs[15 + SEENW] = (unsigned long long)(unsigned int)(base >= 0 ? rec_slot + 1 : 0) | ((unsigned long long)(unsigned int)nev << 32);
+                        if constexpr (MESH) xs[XW - 1] = (unsigned long long)(unsigned int)tri1;
+                        vacated = true;
+                    }
+                }
+                __syncthreads();  // B: the movers are in the slots
+                if (in_plan) {
+                    const bool free_lane = vacated || cls == CLS_NONE;
+                    const int fr = (int)__popcll(__ballot(free_lane) & lane_lt);
+                    if (free_lane) {
+                        int slot = -1;
+                        if (fr < def_me[0]) slot = rbase[0] + fr;
+                        else if (fr < def_me[0] + def_me[1]) slot = rbase[1] + fr - def_me[0];
+                        else if (fr < def_me[0] + def_me[1] + def_me[2]) slot = rbase[2] + fr - def_me[0] - def_me[1];
+                        alive = slot >= 0;
+                        cls = CLS_NONE;
+                        if (alive) {
+                            const unsigned long long* xs = xbuf + slot * XS;
+                            pos = V3{pvt_u2d(xs[0]), pvt_u2d(xs[1]), pvt_u2d(xs[2])};
+                            dir = V3{pvt_u2d(xs[3]), pvt_u2d(xs[4]), pvt_u2d(xs[5])};
+                            wl = pvt_u2d(xs[6]); travelled = pvt_u2d(xs[7]); duration = pvt_u2d(xs[8]);
+                            rng.s0 = xs[9]; rng.s1 = xs[10]; rng.s2 = xs[11]; rng.s3 = xs[12];
+                            const unsigned long long cs_ = xs[13];
+                            count = (int)(unsigned int)cs_;
+                            source = (int)(unsigned int)(cs_ >> 32);
+                            const unsigned long long pw = xs[14];
+                            const unsigned int plo = (unsigned int)pw, phi = (unsigned int)(pw >> 32);
+                            cls = (int)(plo & 3u);
+                            ev_kind = (int)((plo >> 2) & 15u) - 1;
+                            ev_hit = (int)((plo >> 6) & 255u) - 1;
+                            ev_container = (int)((plo >> 14) & 255u) - 1;
+                            ev_adjacent = (int)((plo >> 22) & 255u) - 1;
+                            t_sel = (int)(phi & 15u) - 1;
+                            ev_component = (int)(phi >> 4) - 1;
+#pragma unroll
+                            for (int w = 0; w < SEENW; w++) seen.w[w] = xs[15 + w];
+                            if constexpr (RECORD) {
+                                const unsigned long long rw = xs[15 + SEENW];
+                                const unsigned int rs1 = (unsigned int)rw;
+                                nev = (int)(unsigned int)(rw >> 32);
+                                base = -1;
+                                if (rs1 != 0u) { rec_slot = (long long)rs1 - 1; base = rec_slot * A.max_events; }
+                            }
+                            if constexpr (MESH) tri1 = (int)(unsigned int)xs[XW - 1];
+                        }
+                    }
+                }
+            }
+            // who is still running after this step: once no photon can arrive any more, a wave left
+            // without photons retires (it never waits at a closing barrier: the survivors' rendezvous
+            // would count it)
+            if (feeding_over) {
+                bool retire_me = false;
+#pragma unroll
+                for (int w = 0; w < kWaves; w++)
+                    if (((members >> w) & 1) && live_after[w] == 0) {
+                        members &= ~(1 << w);
+                        if (w == wave) retire_me = true;
+                    }
+                if (retire_me) break;
+            }
+        } else {
+            // last wave standing, or regrouping off (the accumulators alone fill the LDS): free-running
+            feeding_over = dry && w_next >= w_end && x_next >= x_end && !claim_pending;
+            if (feeding_over && __ballot(alive || nx_have) == 0ull) break;
+        }
+        // ---- ray supply for the lanes that end with this step -------------------------------------
+        service_claims();
+        prefetch(cls == CLS_TERM || cls == CLS_NONE);
+        PVT_MARK(2);  // regrouping
+        PVT_COUNT(1, cls == CLS_ABS);
+        PVT_COUNT(3, cls == CLS_SURF);
+        PVT_COUNT(4, cls == CLS_TERM);
+#if PVT_STATS
+        if (!feeding_over) {   // how many waves run each body (st_c[5..7] reused as wave counts)
+            st_c[5] += __ballot(cls == CLS_ABS) != 0ull; st_c[6] += __ballot(cls == CLS_SURF) != 0ull;
+            st_c[7] += __ballot(cls != CLS_NONE && (t_sel >= 0 || cls == CLS_SURF)) != 0ull;
+        }
+#endif
+
+        // ================= stage 2: the bodies =========================================================
+        const bool terminal = cls == CLS_TERM;
+        const bool t_normal = cls == CLS_SURF || (terminal && ev_kind == PVT_EV_EXIT);
+        const bool ev_normal = cls == CLS_SURF;
+        const int t_node = t_normal ? ev_hit : ev_container;
+        double t_angle = 0.0;
+        V3 nrm{0, 0, 0};
+        bool em = false, em_acos = false;   // re-emission pending: acos argument (or theta) and phi
+        double em_x = 0.0, em_phi = 0.0;
+
+        // ---- re-emission: the draws (:790-832) ----------------------------------------------------------
+        if (cls == CLS_ABS) {
+            const int comp = ev_component;
+            const int ci = L.comp_i + comp * CI, cd = L.comp_d + comp * CD;
+            const int ctype = T.iv(ci + CI_TYPE);
+            // phase function (_kernel.pyx:455-476): only the DRAWS happen here, in the
+            // reference's order; acos / sincos run later at the sites shared with the
+            // surface lanes, and the new direction is written before the event is logged
+            const int pt = T.iv(ci + CI_PHASE);
+            const double pp = T.dv(cd + CD_PHASE);
+            if (pt == PVT_PHASE_HG && pvt_fabs(pp) >= kEps) {
+                double g1 = rng_uniform(rng);
+                double sg = 2.0 * g1 - 1.0;
+                double q = (1.0 - pp * pp) / (1.0 + pp * sg);
+                em_x = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
+                em_phi = 2.0 * kPi * rng_uniform(rng);
+                em_acos = true;
+            } else if (pt == PVT_PHASE_CONE) {
+                double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+                em_x = pvt_asin(pvt_sqrt(g1) * pvt_sin(pp));  // theta itself
+                em_phi = 2.0 * kPi * g2;
+            } else {
+                double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
+                em_phi = 2.0 * kPi * g1;
+                em_x = 2.0 * g2 - 1.0;
+                em_acos = true;
+            }
+            em = true;
+            source = comp;
+            double tau = 0.0;
+            if (ctype == PVT_COMP_LUMINOPHORE) {
+                const int ex = T.iv(ci + CI_EMS_X), ec = T.iv(ci + CI_EMS_CDF), en = T.iv(ci + CI_EMS_N);
+                const int eh = T.iv(ci + CI_EMS_HIST);
+                const double ew = T.dv(cd + CD_EMS_W);
+                double p1;
+                if (A.emit_method == PVT_EMIT_FULL) {
+                    p1 = 0.0;
+                } else {
+                    double e_nm = wl;
+                    if (A.emit_method == PVT_EMIT_KT) {
+                        const double kb_ev = 1.380649e-23 / 1.60217662e-19;
+                        double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
+                        e_nm = 1240.0 / e_ev;
+                    }
+                    p1 = ABL(2) ? 0.3 : interp_clamped<TAB_LDS, false>(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(cd + CD_EMS_SCALE_X),
+                                                                       eh, T.dv(cd + CD_EMS_RCP_X), ew);
+                }
+                double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
+                wl = ABL(2) ? 600.0 + 50.0 * gamma
+                            : interp_clamped<TAB_LDS, false>(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(cd + CD_EMS_SCALE_C), eh,
+                                                             T.dv(cd + CD_EMS_RCP_C), __builtin_nan(""), eh ? __builtin_nan("") : ew);
+                tau = T.dv(cd + CD_TAU_RAD);
+                ev_kind = PVT_EV_EMIT;
+            } else {
+                ev_kind = PVT_EV_SCATTER;
+            }
+            // radiative lifetime: the last draw of this step
+            if (tau > 0.0) duration += -pvt_log(1.0 - rng_uniform(rng)) * tau;
+        }
+        PVT_MARK(3);  // re-emission draws
+        PVT_COUNT(2, em);
+
+        // ---- local point + outward world normal of the node the event refers to.
+        // Shared by EXIT and surface events (re-converged: one copy of the code).
+        // Both are pure functions of (t_node, pos, tri1), so the coating / Lambertian code and the
+        // x,y,z histogram axes RECOMPUTE them where needed (same arithmetic, same bits) instead of
+        // keeping 12 VGPRs alive across the transcendental sites, the register-pressure peak.
+        // (UNI: the node index is wave-uniform -> its record comes through the scalar cache)
+        auto local_point_of = [&](auto uni, int node) -> V3 {
+            const int m = node * ND + ND_W2L;
+            auto rd = [&](int i) { return decltype(uni)::value ? T.du(i) : T.dv(i); };
+            return V3{rd(m + 0) * pos.x + rd(m + 1) * pos.y + rd(m + 2) * pos.z + rd(m + 3),
+                      rd(m + 4) * pos.x + rd(m + 5) * pos.y + rd(m + 6) * pos.z + rd(m + 7),
+                      rd(m + 8) * pos.x + rd(m + 9) * pos.y + rd(m + 10) * pos.z + rd(m + 11)};
+        };
+        auto local_normal_of = [&](auto uni, int node, const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
+            auto rd = [&](int i) { return decltype(uni)::value ? T.du(i) : T.dv(i); };
+            const int gp = node * ND + ND_PARAMS;
+            const int gt = decltype(uni)::value ? T.iu(node * NI + NI_GEOM) : T.iv(node * NI + NI_GEOM);
+            if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
+                const pvt::MeshTri* tr = A.tris + tri1;
+                return V3{tr->n[0], tr->n[1], tr->n[2]};
+            }
+            if (gt == PVT_GEOM_BOX) {
+                double best = INFINITY;
+                int baxis = 0;
+                double bsign = 1.0;
+                const double pp[3] = {lp.x, lp.y, lp.z};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    double hs = 0.5 * rd(gp + a);
+                    double dm = pvt_fabs(pp[a] - (-1.0) * hs);
+                    if (dm < best) { best = dm; baxis = a; bsign = -1.0; }
+                    double dp = pvt_fabs(pp[a] - hs);
+                    if (dp < best) { best = dp; baxis = a; bsign = 1.0; }
+                }
+                return V3{(baxis == 0) ? bsign : 0.0, (baxis == 1) ? bsign : 0.0, (baxis == 2) ? bsign : 0.0};
+            }
+            if (gt == PVT_GEOM_SPHERE) {
+                double mag = pvt_sqrt(dot3(lp, lp));
+                return V3{lp.x / mag, lp.y / mag, lp.z / mag};
+            }
+            double half = 0.5 * rd(gp);
+            double tol = 1e-8 + 1e-5 * pvt_fabs(half);
+            if (pvt_fabs(lp.z + half) <= tol) return V3{0.0, 0.0, -1.0};
+            if (pvt_fabs(lp.z - half) <= tol) return V3{0.0, 0.0, 1.0};
+            double r = pvt_sqrt(lp.x * lp.x + lp.y * lp.y);
+            return V3{lp.x / r, lp.y / r, 0.0};
+        };
+        auto local_point = [&]() -> V3 { return local_point_of(std::false_type{}, t_node); };
+        auto local_normal = [&](const V3& lp) -> V3 { return local_normal_of(std::false_type{}, t_node, lp); };
+        if (t_normal) {
+            const V3 nloc = local_normal(local_point());
+            const int q = t_node * ND + ND_L2W;
+            nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
+            nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
+            nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
+        }
+
+        // ---- shared transcendental sites --------------------------------------
+        // Re-emitting lanes (new direction), surface lanes (incidence angle + Fresnel) and
+        // exiting lanes (exit angle) all need an acos, the first two a sincos of its result:
+        // each runs ONCE for whatever mix the wave holds.
+        const bool surf = cls == CLS_SURF;
+        V3 nf = nrm;
+        double ac_arg = em_x;
+        bool need_acos = em && em_acos;
+        if (t_normal) {
+            if (!surf) {
+                double dd = pvt_fabs(dot3(nrm, dir));
+                if (dd > 1.0) dd = 1.0;
+                ac_arg = dd;
+            } else {
+                if (dot3(nf, dir) < 0.0) nf = V3{-nf.x, -nf.y, -nf.z};
+                double ddot = dot3(nf, dir);
+                if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
+                ac_arg = ddot;
+            }
+            need_acos = true;
+        }
+        double ac = 0.0;
+        if (need_acos) ac = ABL(4) ? 1.5 - ac_arg : pvt_acos(ac_arg);
+        if (t_normal) t_angle = ac;
+        const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
+        double s1 = 0.0, c1 = 1.0;
+        if (em || fres) { if (ABL(4)) { s1 = ac * 0.6; c1 = 1.0 - 0.5 * ac * ac * 0.3; } else pvt_sincos(em ? (em_acos ? ac : em_x) : ac, &s1, &c1); }
+        if (em) {
+            double sp, cp;
+            if (ABL(4)) { sp = em_phi * 0.1; cp = 1.0 - sp * sp; } else pvt_sincos(em_phi, &sp, &cp);
+            dir = V3{s1 * cp, s1 * sp, c1};
+        }
+
+        PVT_MARK(4);  // frame + acos + sincos
+        if (surf) {
+            // ---- Fresnel / coating decision at the surface (:865-895) ------------
+            const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
+            const double angle = ac;
+            double r = 0.0, n1 = 0.0, n2 = 0.0, rn2 = 0.0;
+            if (fres) {  // unpolarised Fresnel, 1.0 beyond the critical angle (:406-419)
+                n1 = T.dv(container * ND + ND_N);
+                n2 = T.dv(adjacent * ND + ND_N);
+                rn2 = T.dv(adjacent * ND + ND_RN);
+                // critical angle asin(n2/n1): a function of the node pair, tabulated by the host
+                // with the same pvt_asin (small scenes), else computed here
+                bool tir;
+                if (L.crit_d >= 0) tir = angle > T.dv(L.crit_d + container * A.n_nodes + adjacent);
+                else tir = n2 < n1 && angle > pvt_asin(div_known(n2, n1, T.dv(container * ND + ND_RN)));
+                if (tir) {
+                    r = 1.0;
+                } else {
+                    double q = div_known(n1, n2, rn2) * s1;
+                    double k = pvt_sqrt(1.0 - q * q);
+                    double rs1 = n1 * c1 - n2 * k, rs2 = n1 * c1 + n2 * k;
+                    double rs = (rs1 / rs2) * (rs1 / rs2);
+                    double rp1 = n1 * k - n2 * c1, rp2 = n1 * k + n2 * c1;
+                    double rp = (rp1 / rp2) * (rp1 / rp2);
+                    r = 0.5 * (rs + rp);
+                }
+            }
+            int coat = -1;
+            if (coated && fres) {
+                const int cs = T.iv(hit * NI + NI_KSTART), ce = cs + T.iv(hit * NI + NI_KCOUNT);
+                const V3 lpos = local_point(), nloc = local_normal(lpos);
+                const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
+                for (int c = cs; c < ce && coat < 0; c++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        double f = T.dv(L.coat_d + c * KD + KD_FACET + a);
+                        if (pvt_fabs(nl3[a] - f) > 1e-8 + 1e-5 * pvt_fabs(f)) ok = false;
+                        if (!(pl3[a] > T.dv(L.coat_d + c * KD + KD_LO + a) && pl3[a] < T.dv(L.coat_d + c * KD + KD_HI + a))) ok = false;
+                    }
+                    if (ok) coat = c;
+                }
+                if (coat >= 0) {
+                    // a coating sets the reflectivity -- except beyond the critical angle when it
+                    // transmits by Fresnel refraction: no refracted ray exists there
+                    double cr = T.dv(L.coat_d + coat * KD + KD_REFL);
+                    if (cr >= 0.0 && !(r == 1.0 && T.iv(L.coat_i + coat * KI + KI_TMODE) != 1)) r = cr;
+                }
+            }
+            double u = 1.0;
+            if (r > 0.0) u = rng_uniform(rng);
+            if (u < r) {
+                bool lamb = false;
+                if (coat >= 0) lamb = T.iv(L.coat_i + coat * KI + KI_RMODE) == 1;
+                if (lamb) {
+                    // cosine-weighted about the incoming side's normal, in the node frame
+                    double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
+                    const V3 nloc = local_normal(local_point());
+                    V3 mm{side * nloc.x, side * nloc.y, side * nloc.z};
+                    double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
+                    V3 sd = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
+                    double sign = mm.z < 0.0 ? -1.0 : 1.0;
+                    double a = -1.0 / (sign + mm.z);
+                    double b = mm.x * mm.y * a;
+                    V3 t1v{1.0 + sign * mm.x * mm.x * a, sign * b, -sign * mm.x};
+                    V3 t2v{b, sign + mm.y * mm.y * a, -mm.y};
+                    V3 dl{sd.x * t1v.x + sd.y * t2v.x + sd.z * mm.x, sd.x * t1v.y + sd.y * t2v.y + sd.z * mm.y,
+                          sd.x * t1v.z + sd.y * t2v.z + sd.z * mm.z};
+                    const int q = hit * ND + ND_L2W;
+                    dir.x = T.dv(q + 0) * dl.x + T.dv(q + 1) * dl.y + T.dv(q + 2) * dl.z;
+                    dir.y = T.dv(q + 3) * dl.x + T.dv(q + 4) * dl.y + T.dv(q + 5) * dl.z;
+                    dir.z = T.dv(q + 6) * dl.x + T.dv(q + 7) * dl.y + T.dv(q + 8) * dl.z;
+                } else {  // specular (:422-433): nf is nrm flipped along dir
+                    double dd = dot3(nf, dir);
+                    dir = V3{dir.x - 2.0 * dd * nf.x, dir.y - 2.0 * dd * nf.y, dir.z - 2.0 * dd * nf.z};
+                }
+                ev_kind = PVT_EV_REFLECT;
+                t_sel = (container != hit) ? PVT_REC_REFLECTED : -1;
+            } else {
+                bool matched = false;
+                if (coat >= 0) matched = T.iv(L.coat_i + coat * KI + KI_TMODE) == 1;
+                if (fres && !matched) {  // Snell, vector form (:436-446)
+                    double n = div_known(n1, n2, rn2);
+                    double dd = dot3(dir, nf);
+                    double c = pvt_sqrt(1.0 - n * n * (1.0 - dd * dd));
+                    double sign = dd < 0.0 ? -1.0 : 1.0;
+                    double k = sign * (c - sign * n * dd);
+                    dir = V3{n * dir.x + k * nf.x, n * dir.y + k * nf.y, n * dir.z + k * nf.z};
+                }
+                ev_kind = PVT_EV_TRANSMIT;
+                t_sel = (container == hit) ? PVT_REC_ESCAPING : PVT_REC_ENTERING;
+            }
+        }
+        PVT_MARK(5);  // fresnel / reflect / refract
+        // ================= deferred event: log row + tallies ==============
+        if (cls != CLS_NONE && ev_kind >= 0)
+            log_row<RECORD>(A, base, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
+                            dir, ev_normal, nrm, wl, travelled, duration);
+
+        // Lane-parallel tally.  Each lane walks the (host-precomputed) list of recorders that
+        // can fire for ITS (node, selector) — different lanes handle different recorders in
+        // the same trip — reading the recorder rows from LDS with per-lane addresses and
+        // adding into the workgroup accumulators with per-lane LDS atomics (hardware
+        // serialises same-address lanes; no wave-uniform recorder loop, no scalar-load
+        // chains, no software scan).  Recorder order per lane is ascending, as in the
+        // reference's loop (_kernel.pyx:517-556).
+        if (!ABL(0) && A.n_rec > 0 && __ballot(cls != CLS_NONE && t_sel >= 0) != 0ull) {
+            // Facet recorders whose facets have distinct dominant axes (the usual "one recorder
+            // per box face") are found in O(1): the host files each under the bin (dominant axis,
+            // sign) of its facet, the lane looks up the bin of ITS normal and verifies that one
+            // recorder with the full tolerance test (its first trip).  Everything else is walked.
+            int cs = 0, cn = 0, rbin = -1;
+            if (cls != CLS_NONE && t_sel >= 0) {
+                const int key = L.cand_i + (t_node * 7 + t_sel) * 8;
+                cs = T.iv(key);
+                cn = T.iv(key + 1);
+                if (t_normal) {
+                    const double ax = pvt_fabs(nrm.x), ay = pvt_fabs(nrm.y), az = pvt_fabs(nrm.z);
+                    int b = (ax >= ay && ax >= az) ? (nrm.x > 0.0 ? 1 : 0)
+                          : (ay >= az)             ? (nrm.y > 0.0 ? 3 : 2)
+                                                   : (nrm.z > 0.0 ? 5 : 4);
+                    rbin = T.iv(key + 2 + b);
+                }
+            }
+            // trip t of a lane: its bin recorder first (if any), then its list -- so lanes served by
+            // the bin table and lanes served by a list share the same trips
+            const int nb = rbin >= 0 ? 1 : 0, ntrips = nb + cn;
+            for (int j = 0; __ballot(j < ntrips) != 0ull; j++) {
+                if (j < ntrips) {
+                    const int r = j < nb ? rbin : T.iv(L.cand_list + cs + j - nb);
+                    const int ri = L.rec_i + r * RI;
+                    bool match = true;
+                    const int smode = T.iv(ri + RI_SRC_MODE);  // source filter (extension)
+                    if (smode != 0) {
+                        if (smode == 1) match = source < 0;
+                        else if (smode == 2) match = source >= 0;
+                        else match = source == T.iv(ri + RI_SRC_ID);
+                    }
+                    if (match && T.iv(ri + RI_HAS_FACET) != 0) {
+                        const int rd = L.rec_d + r * RD;
+                        const double atol = T.dv(rd + RD_ATOL);
+                        if (!t_normal) match = false;
+                        else if (pvt_fabs(T.dv(rd + RD_FACET) - nrm.x) > atol) match = false;
+                        else if (pvt_fabs(T.dv(rd + RD_FACET + 1) - nrm.y) > atol) match = false;
+                        else if (pvt_fabs(T.dv(rd + RD_FACET + 2) - nrm.z) > atol) match = false;
+                    }
+                    if (match) {
+                        atomicAdd(&acc_cross[r], 1u);
+                        const unsigned long long bit = 1ull << (r & 63);
+                        bool first;
+                        if constexpr (SEENW == 1) {
+                            first = !(seen.w[0] & bit);
+                            seen.w[0] |= bit;
+                        } else {
+                            const int w = r >> 6;
+                            const unsigned long long cur = w == 0 ? seen.w[0] : w == 1 ? seen.w[1] : w == 2 ? seen.w[2] : seen.w[3];
+                            first = !(cur & bit);
+                            if (w == 0) seen.w[0] |= bit; else if (w == 1) seen.w[1] |= bit;
+                            else if (w == 2) seen.w[2] |= bit; else seen.w[3] |= bit;
+                        }
+                        if (first) {
+                            atomicAdd(&acc_distinct[r], 1u);
+                            double* sp = acc_sums + r * 8;
+                            atomicAdd(&sp[0], wl); atomicAdd(&sp[1], wl * wl);
+                            atomicAdd(&sp[2], t_angle); atomicAdd(&sp[3], t_angle * t_angle);
+                            atomicAdd(&sp[4], duration); atomicAdd(&sp[5], duration * duration);
+                            atomicAdd(&sp[6], travelled); atomicAdd(&sp[7], travelled * travelled);
+                            const int h0 = T.iv(ri + RI_HSTART), h1 = h0 + T.iv(ri + RI_HN);
+                            for (int h = h0; h < h1; h++) {
+                                const int hi_ = L.hist_i + h * HI, hd_ = L.hist_d + h * HD;
+                                const int pa = T.iv(hi_ + HI_PA), pb = T.iv(hi_ + HI_PB);
+                                const int na = T.iv(hi_ + HI_NA), nb = T.iv(hi_ + HI_NB);
+                                auto prop = [&](int pr) -> double {
+                                    if (pr < 4) return pr == 0 ? wl : pr == 1 ? t_angle : pr == 2 ? duration : travelled;
+                                    const V3 lpos = local_point();   // position in the recorder node's frame
+                                    return pr == 4 ? lpos.x : pr == 5 ? lpos.y : lpos.z;
+                                };
+                                const double la = T.dv(hd_ + HD_LO_A), ha = T.dv(hd_ + HD_HI_A);
+                                const double ra = T.dv(hd_ + HD_RA);
+                                const double qa = ra == ra ? div_known(prop(pa) - la, ha - la, ra) : (prop(pa) - la) / (ha - la);
+                                const int ia = (int)(qa * na);
+                                if (ia < 0 || ia >= na) continue;
+                                int slot = T.iv(hi_ + HI_OFF) + ia;
+                                if (pb >= 0) {
+                                    const double lb = T.dv(hd_ + HD_LO_B), hb = T.dv(hd_ + HD_HI_B);
+                                    const double rb = T.dv(hd_ + HD_RB);
+                                    const double qb = rb == rb ? div_known(prop(pb) - lb, hb - lb, rb) : (prop(pb) - lb) / (hb - lb);
+                                    const int ib = (int)(qb * nb);
+                                    if (ib < 0 || ib >= nb) continue;
+                                    slot = T.iv(hi_ + HI_OFF) + ia * nb + ib;
+                                }
+                                if (A.bins_in_lds) atomicAdd(&acc_bins[slot], 1u);
+                                else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + slot, 1ull);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        PVT_MARK(6);  // log + tally
+        if (terminal) {
+            if constexpr (RECORD) {
+                if (base >= 0) A.log.counts[rec_slot] = nev;
+            }
+            alive = false;
+        }
+    }
+
+#if PVT_STATS
+    if (lane == 0) {
+        unsigned long long* c = reinterpret_cast<unsigned long long*>(A.cursor) + 1;
+        atomicAdd(c + 0, st_iters); atomicAdd(c + 1, st_lane_steps);
+        atomicAdd(c + 2, st_drain_iters); atomicAdd(c + 3, st_drain_lane_steps);
+        atomicAdd(c + 4, 1ull);
+        for (int k = 0; k < 8; k++) atomicAdd(c + 16 + k, st_c[k]);
+        for (int k = 0; k < 7; k++) atomicAdd(c + 24 + k, st_b[k]);
+    }
+#endif
+    // ---- flush workgroup accumulators: done by the LAST wave to leave -------
+    // (no closing barrier: retiring waves must never be counted by the rendezvous
+    // barriers of the waves still running)
+    __threadfence_block();
+    int order = 0;
+    if (lane == 0) order = atomicAdd(&ctl[CTL_DONE], 1);
+    order = __builtin_amdgcn_readfirstlane(order);
+    if (order != kWaves - 1) return;
+    __threadfence_block();
+    for (int i = lane; i < A.n_rec; i += 64) {
+        unsigned int c = acc_cross[i], d = acc_distinct[i];
+        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_crossings) + i, (unsigned long long)c);
+        if (d) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_distinct) + i, (unsigned long long)d);
+    }
+    for (int i = lane; i < A.n_rec * 8; i += 64) {
+        double v = acc_sums[i];
+        if (v != 0.0) atomicAdd(A.rec_sums + i, v);
+    }
+    if (A.bins_in_lds)
+        for (int i = lane; i < A.total_bins; i += 64) {
+            unsigned int v = acc_bins[i];
+            if (v) atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + i, (unsigned long long)v);
+        }
+}
+
+}  // namespace
