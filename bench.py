@@ -286,12 +286,19 @@ def main():
                 }
                 per_photon = derived.get("valu_wave_instructions_per_photon")
                 if per_photon:
-                    # the operative ceiling: one wave64 VALU instruction per SIMD every 4 cycles
+                    # the operative ceiling: VALU issue.  Nominal: one wave64 FP64 instruction per SIMD every 4
+                    # cycles at 2.4 GHz.  ACHIEVABLE on this part with the kernel's four waves per SIMD: a pure
+                    # chain of v_fma_f64 issues one per 4.83-5.26 nominal cycles (tools/gpu_fma_peak.hip,
+                    # profiles/r02_fma_peak.txt) -- the kernel is measured against both
                     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-                    peak = cus * 4 * 2.4e9 / 4.0
-                    instruction_side["valu_issue_peak_per_s"] = peak
-                    instruction_side["valu_issue_rate_per_s"] = per_photon * value / world
-                    instruction_side["valu_issue_frac"] = per_photon * value / world / peak
+                    nominal = cus * 4 * 2.4e9 / 4.0
+                    achievable = cus * 4 * 4.85e8          # wave-FMA/s/SIMD at 4 waves x 4 chains: 4.73e8 and 4.96e8 on two boxes
+                    rate = per_photon * value / world
+                    instruction_side["valu_issue_rate_per_s"] = rate
+                    instruction_side["valu_issue_peak_per_s"] = nominal
+                    instruction_side["valu_issue_frac"] = rate / nominal
+                    instruction_side["valu_issue_achievable_per_s"] = achievable
+                    instruction_side["valu_issue_frac_of_achievable"] = rate / achievable
             except Exception:
                 traffic = None
         nrec = compiled.rec_node.shape[0]
