@@ -291,9 +291,13 @@ static void local_normal(const PvtSceneTables* S, int node, int tri, const doubl
 }
 
 /* ---- optics (_kernel.pyx:406-476) --------------------------------------- */
-static double fresnel_reflectivity(const MathSel* M, double angle, double n1, double n2) {
+/* `cosine`: cos(angle) when the caller has it (angle = acos(cosine)); NaN = take it from the angle.
+ * Portable arithmetic evaluates cos(acos(c)) and sin(acos(c)) as compositions (pvt_math.h) */
+static double fresnel_reflectivity(const MathSel* M, double angle, double cosine, double n1, double n2) {
     if (n2 < n1 && angle > m_asin(M, n2 / n1)) return 1.0;
-    double c = m_cos(M, angle), s = m_sin(M, angle);
+    double c, s;
+    if (M->mode && cosine == cosine) { c = cosine; s = pvt_sqrt1m2(cosine); }
+    else { c = m_cos(M, angle); s = m_sin(M, angle); }
     double q = n1 / n2 * s;
     double k = sqrt(1.0 - q * q);
     double rs1 = n1 * c - n2 * k, rs2 = n1 * c + n2 * k;
@@ -322,25 +326,37 @@ static void sphere_direction(const MathSel* M, double theta, double phi, double*
     out[2] = m_cos(M, theta);
 }
 static void sample_phase(const MathSel* M, int type, double param, Rng* rng, double* out) {
-    double theta, phi;
+    /* the polar angle is sampled through its cosine (HG, isotropic) or its sine (cone); libm mode takes
+     * the reference's detour through the angle itself, portable mode the composition (pvt_math.h) */
+    double phi, cos_t = 0.0, sin_t = 0.0;
+    int by_cosine;
     if (type == PVT_PHASE_HG && fabs(param) >= EPS) {
         double g = param;
         double g1 = rng_uniform(rng);
         double s = 2.0 * g1 - 1.0;
         double q = (1.0 - g * g) / (1.0 + g * s);
-        double mu = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
+        cos_t = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
         phi = 2.0 * M_PI * rng_uniform(rng);
-        theta = m_acos(M, mu);
+        by_cosine = 1;
     } else if (type == PVT_PHASE_CONE) {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-        theta = m_asin(M, sqrt(g1) * m_sin(M, param));
+        sin_t = sqrt(g1) * m_sin(M, param);
         phi = 2.0 * M_PI * g2;
+        by_cosine = 0;
     } else {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
         phi = 2.0 * M_PI * g1;
-        theta = m_acos(M, 2.0 * g2 - 1.0);
+        cos_t = 2.0 * g2 - 1.0;
+        by_cosine = 1;
     }
-    sphere_direction(M, theta, phi, out);
+    if (!M->mode) {
+        sphere_direction(M, by_cosine ? acos(cos_t) : asin(sin_t), phi, out);
+        return;
+    }
+    if (by_cosine) sin_t = pvt_sqrt1m2(cos_t); else cos_t = pvt_sqrt1m2(sin_t);
+    out[0] = sin_t * pvt_cos(phi);
+    out[1] = sin_t * pvt_sin(phi);
+    out[2] = cos_t;
 }
 
 /* ---- recorders (_kernel.pyx:482-556) ------------------------------------ */
@@ -662,7 +678,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
         if (fres) {
             n1 = S->refractive_index[container];
             n2 = S->refractive_index[adjacent];
-            r = fresnel_reflectivity(M, angle, n1, n2);
+            r = fresnel_reflectivity(M, angle, ddot, n1, n2);
         }
         int coat = fres ? find_coating(S, hit, nl, lp) : -1;          /* EXTENSION */
         /* a coating sets the reflectivity -- except beyond the critical angle when it transmits by
@@ -877,7 +893,7 @@ void pvt_oracle_math(int fn, int math_mode, const double* x, double* y, long n) 
 /* unit-level access for known-answer tests */
 double pvt_oracle_fresnel_reflectivity(double angle, double n1, double n2, int math_mode) {
     MathSel M = {math_mode};
-    return fresnel_reflectivity(&M, angle, n1, n2);
+    return fresnel_reflectivity(&M, angle, NAN, n1, n2);
 }
 void pvt_oracle_fresnel_refract(const double* d, const double* nflipped, double n1, double n2, double* out) {
     fresnel_refract(d, nflipped, n1, n2, out);

@@ -276,25 +276,31 @@ __device__ __forceinline__ V3 sphere_direction(double theta, double phi) {
 
 // phase functions (_kernel.pyx:455-476); draw order is part of the contract
 __device__ __forceinline__ V3 sample_phase(int type, double param, Rng& rng) {
-    double theta, phi;
+    // the polar angle is sampled through its cosine (HG, isotropic) or its sine (cone); the other one is the
+    // composition sin(acos c) = cos(asin c) = pvt_sqrt1m2(c) (pvt_math.h) -- no acos / asin / sincos of theta
+    double phi, cos_t, sin_t;
     if (type == PVT_PHASE_HG && pvt_fabs(param) >= kEps) {
         double g = param;
         double g1 = rng_uniform(rng);
         double s = 2.0 * g1 - 1.0;
         double q = (1.0 - g * g) / (1.0 + g * s);
-        double mu = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
+        cos_t = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
         phi = 2.0 * kPi * rng_uniform(rng);
-        theta = pvt_acos(mu);
+        sin_t = pvt_sqrt1m2(cos_t);
     } else if (type == PVT_PHASE_CONE) {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-        theta = pvt_asin(pvt_sqrt(g1) * pvt_sin(param));
+        sin_t = pvt_sqrt(g1) * pvt_sin(param);
         phi = 2.0 * kPi * g2;
+        cos_t = pvt_sqrt1m2(sin_t);
     } else {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
         phi = 2.0 * kPi * g1;
-        theta = pvt_acos(2.0 * g2 - 1.0);
+        cos_t = 2.0 * g2 - 1.0;
+        sin_t = pvt_sqrt1m2(cos_t);
     }
-    return sphere_direction(theta, phi);
+    double sp, cp;
+    pvt_sincos(phi, &sp, &cp);
+    return V3{sin_t * cp, sin_t * sp, cos_t};
 }
 
 // ----------------------------------------------------------- emission
@@ -685,8 +691,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         double t_angle = 0.0;
         V3 nrm{0, 0, 0};
         int tri1 = -1;   // triangle record of the nearest crossing when it lies on a mesh
-        bool em = false, em_acos = false;   // re-emission pending: acos argument (or theta) and phi
-        double em_x = 0.0, em_phi = 0.0;
+        bool em = false;   // re-emission pending: sine and cosine of the polar angle, and the azimuth
+        double em_s = 0.0, em_c = 1.0, em_phi = 0.0;
 
         // ---- stage 1: where does the ray go?  (every live lane) ------------------------------------
         // Lane classes for the rest of the step; the divergent bodies below are keyed on them.
@@ -1023,27 +1029,29 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     radiative = rng_uniform(rng) < T.dv(cd + CD_QY);
                 double tau = 0.0;
                 if (radiative) {
-                    // phase function (_kernel.pyx:455-476): only the DRAWS happen here, in the
-                    // reference's order; acos / sincos run later at the sites shared with the
-                    // surface lanes, and the new direction is written before the event is logged
+                    // phase function (_kernel.pyx:455-476): the draws, in the reference's order, give the
+                    // cosine (or sine) of the polar angle; its partner is the composition pvt_sqrt1m2; the
+                    // azimuth's sincos runs at its own site below and the new direction is written before
+                    // the event is logged
                     const int pt = T.iv(ci + CI_PHASE);
                     const double pp = T.dv(cd + CD_PHASE);
                     if (pt == PVT_PHASE_HG && pvt_fabs(pp) >= kEps) {
                         double g1 = rng_uniform(rng);
                         double sg = 2.0 * g1 - 1.0;
                         double q = (1.0 - pp * pp) / (1.0 + pp * sg);
-                        em_x = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
+                        em_c = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
                         em_phi = 2.0 * kPi * rng_uniform(rng);
-                        em_acos = true;
+                        em_s = pvt_sqrt1m2(em_c);
                     } else if (pt == PVT_PHASE_CONE) {
                         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-                        em_x = pvt_asin(pvt_sqrt(g1) * pvt_sin(pp));  // theta itself
+                        em_s = pvt_sqrt(g1) * pvt_sin(pp);
                         em_phi = 2.0 * kPi * g2;
+                        em_c = pvt_sqrt1m2(em_s);
                     } else {
                         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
                         em_phi = 2.0 * kPi * g1;
-                        em_x = 2.0 * g2 - 1.0;
-                        em_acos = true;
+                        em_c = 2.0 * g2 - 1.0;
+                        em_s = pvt_sqrt1m2(em_c);
                     }
                     em = true;
                     source = cu;
@@ -1158,14 +1166,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
 
         PVT_MARK(3);  // frame + normal
-        // ---- shared transcendental sites --------------------------------------
-        // Re-emitting lanes (new direction), surface lanes (incidence angle + Fresnel) and
-        // exiting lanes (exit angle) all need an acos, the first two a sincos of its result:
-        // run each ONCE for the whole wave instead of once per divergent branch.
+        // ---- transcendental sites ---------------------------------------------------
+        // Surface lanes (incidence angle) and exiting lanes (exit angle) share ONE acos -- the angle is what
+        // the tallies record and what is compared with the critical angle; Fresnel's formulas take the
+        // cosine (the dot product itself) and the sine (its composition) directly.  Re-emitting lanes need
+        // one sincos, of the azimuth.
         const bool surf = alive && t_normal && ev_kind != PVT_EV_EXIT;
         V3 nf = nrm;
-        double ac_arg = em_x;
-        bool need_acos = em && em_acos;
+        double ac_arg = 1.0;
         if (alive && t_normal) {
             if (ev_kind == PVT_EV_EXIT) {
                 double dd = pvt_fabs(dot3(nrm, dir));
@@ -1177,18 +1185,16 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
                 ac_arg = ddot;
             }
-            need_acos = true;
         }
         double ac = 0.0;
-        if (need_acos) ac = ABL(4) ? 1.5 - ac_arg : pvt_acos(ac_arg);
+        if (alive && t_normal) ac = ABL(4) ? 1.5 - ac_arg : pvt_acos(ac_arg);
         if (alive && t_normal) t_angle = ac;
         const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
-        double s1 = 0.0, c1 = 1.0;
-        if (em || fres) { if (ABL(4)) { s1 = ac * 0.6; c1 = 1.0 - 0.5 * ac * ac * 0.3; } else pvt_sincos(em ? (em_acos ? ac : em_x) : ac, &s1, &c1); }
+        const double c1 = ac_arg, s1 = fres ? pvt_sqrt1m2(ac_arg) : 0.0;   // cos / sin of the incidence angle
         if (em) {
             double sp, cp;
             if (ABL(4)) { sp = em_phi * 0.1; cp = 1.0 - sp * sp; } else pvt_sincos(em_phi, &sp, &cp);
-            dir = V3{s1 * cp, s1 * sp, c1};
+            dir = V3{em_s * cp, em_s * sp, em_c};
         }
 
         PVT_MARK(4);  // acos + sincos
