@@ -328,7 +328,7 @@ static void sphere_direction(const MathSel* M, double theta, double phi, double*
 static void sample_phase(const MathSel* M, int type, double param, Rng* rng, double* out) {
     /* the polar angle is sampled through its cosine (HG, isotropic) or its sine (cone); libm mode takes
      * the reference's detour through the angle itself, portable mode the composition (pvt_math.h) */
-    double phi, cos_t = 0.0, sin_t = 0.0;
+    double turn, cos_t = 0.0, sin_t = 0.0;   /* azimuth = 2 pi turn */
     int by_cosine;
     if (type == PVT_PHASE_HG && fabs(param) >= EPS) {
         double g = param;
@@ -336,26 +336,28 @@ static void sample_phase(const MathSel* M, int type, double param, Rng* rng, dou
         double s = 2.0 * g1 - 1.0;
         double q = (1.0 - g * g) / (1.0 + g * s);
         cos_t = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
-        phi = 2.0 * M_PI * rng_uniform(rng);
+        turn = rng_uniform(rng);
         by_cosine = 1;
     } else if (type == PVT_PHASE_CONE) {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
         sin_t = sqrt(g1) * m_sin(M, param);
-        phi = 2.0 * M_PI * g2;
+        turn = g2;
         by_cosine = 0;
     } else {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-        phi = 2.0 * M_PI * g1;
+        turn = g1;
         cos_t = 2.0 * g2 - 1.0;
         by_cosine = 1;
     }
     if (!M->mode) {
-        sphere_direction(M, by_cosine ? acos(cos_t) : asin(sin_t), phi, out);
+        sphere_direction(M, by_cosine ? acos(cos_t) : asin(sin_t), 2.0 * M_PI * turn, out);
         return;
     }
     if (by_cosine) sin_t = pvt_sqrt1m2(cos_t); else cos_t = pvt_sqrt1m2(sin_t);
-    out[0] = sin_t * pvt_cos(phi);
-    out[1] = sin_t * pvt_sin(phi);
+    double sp, cp;
+    pvt_sincos2pi(turn, &sp, &cp);
+    out[0] = sin_t * cp;
+    out[1] = sin_t * sp;
     out[2] = cos_t;
 }
 
@@ -885,6 +887,10 @@ void pvt_oracle_math(int fn, int math_mode, const double* x, double* y, long n) 
             case 10: y[i] = x[i] / C_CM_PER_S; break;
             case 11: y[i] = x[i] / 1.5; break;
             case 12: y[i] = x[i] / (800.0 - 400.0); break;
+            /* composed functions (pvt_math.h); libm mode = the reference's two-call composition */
+            case 14: if (M.mode) { double sn, cs; pvt_sincos2pi(x[i], &sn, &cs); y[i] = sn; } else y[i] = sin(2.0 * M_PI * x[i]); break;
+            case 15: if (M.mode) { double sn, cs; pvt_sincos2pi(x[i], &sn, &cs); y[i] = cs; } else y[i] = cos(2.0 * M_PI * x[i]); break;
+            case 16: y[i] = M.mode ? pvt_sqrt1m2(x[i]) : sin(acos(x[i])); break;
             default: { double d = x[i] * 0.7310585786300049 + 0.25; y[i] = x[i] / d; break; }
         }
     }

@@ -261,4 +261,27 @@ PVT_HD_STATIC double pvt_acos(double x) {
 // (one factor is exact for |c| >= 1/2, Sterbenz; < 1.3 ulp overall; NaN for |c| > 1 like acos/asin).
 PVT_HD_STATIC double pvt_sqrt1m2(double c) { return pvt_sqrt((1.0 - c) * (1.0 + c)); }
 
+// sin(2 pi g), cos(2 pi g) for a turn fraction g (an azimuth is sampled as phi = 2 pi u, _kernel.pyx:455-476).
+// The quadrant reduction is EXACT in g (g - n/4 has no rounding for |g| <= 2^20), so no Cody-Waite passes
+// are needed; the reduced angle 2 pi (g - n/4), |.| <= pi/4, is formed as head + tail with two explicitly
+// written fused multiply-adds (v_fma_f64 on the device, the correctly rounded fma() of the C library on the
+// host: the same bits; contraction of everything else stays off).  Error < 1 ulp of the exact sin / cos of
+// 2 pi g -- the reference's phi = RN(2 pi u) alone is already half an ulp of phi away from it.
+PVT_HD_STATIC void pvt_sincos2pi(double g, double* s, double* c) {
+    const double two_pi_hi = 6.28318530717958623200e+00, two_pi_lo = 2.44929359829470641435e-16;
+    const double fn = g * 4.0 + 6755399441055744.0 - 6755399441055744.0;   // nearest quarter turn (1.5 * 2^52 trick)
+    const int n = (int)fn;
+    const double r = g - fn * 0.25;                                          // exact
+    const double t = r * two_pi_hi;
+    const double tail = __builtin_fma(r, two_pi_lo, __builtin_fma(r, two_pi_hi, -t));
+    const double ks = pvt_ksin(t, tail, 1);
+    const double kc = pvt_kcos(t, tail);
+    switch (n & 3) {
+        case 0: *s = ks; *c = kc; break;
+        case 1: *s = kc; *c = -ks; break;
+        case 2: *s = -ks; *c = -kc; break;
+        default: *s = -kc; *c = ks; break;
+    }
+}
+
 #endif  // PVT_MATH_H

@@ -278,28 +278,29 @@ __device__ __forceinline__ V3 sphere_direction(double theta, double phi) {
 __device__ __forceinline__ V3 sample_phase(int type, double param, Rng& rng) {
     // the polar angle is sampled through its cosine (HG, isotropic) or its sine (cone); the other one is the
     // composition sin(acos c) = cos(asin c) = pvt_sqrt1m2(c) (pvt_math.h) -- no acos / asin / sincos of theta
-    double phi, cos_t, sin_t;
+    // (the azimuth is 2 pi `turn`: its sine and cosine come from pvt_sincos2pi, exact quadrant reduction)
+    double turn, cos_t, sin_t;
     if (type == PVT_PHASE_HG && pvt_fabs(param) >= kEps) {
         double g = param;
         double g1 = rng_uniform(rng);
         double s = 2.0 * g1 - 1.0;
         double q = (1.0 - g * g) / (1.0 + g * s);
         cos_t = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
-        phi = 2.0 * kPi * rng_uniform(rng);
+        turn = rng_uniform(rng);
         sin_t = pvt_sqrt1m2(cos_t);
     } else if (type == PVT_PHASE_CONE) {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
         sin_t = pvt_sqrt(g1) * pvt_sin(param);
-        phi = 2.0 * kPi * g2;
+        turn = g2;
         cos_t = pvt_sqrt1m2(sin_t);
     } else {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-        phi = 2.0 * kPi * g1;
+        turn = g1;
         cos_t = 2.0 * g2 - 1.0;
         sin_t = pvt_sqrt1m2(cos_t);
     }
     double sp, cp;
-    pvt_sincos(phi, &sp, &cp);
+    pvt_sincos2pi(turn, &sp, &cp);
     return V3{sin_t * cp, sin_t * sp, cos_t};
 }
 
@@ -388,6 +389,9 @@ __global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, d
         case 10: r = div_known(v, kCcm, kRcpCcm); break;
         case 11: r = div_known(v, 1.5, 1.0 / 1.5); break;
         case 12: r = div_known(v, 800.0 - 400.0, 1.0 / (800.0 - 400.0)); break;
+        case 14: { double sn, cs; pvt_sincos2pi(v, &sn, &cs); r = sn; break; }
+        case 15: { double sn, cs; pvt_sincos2pi(v, &sn, &cs); r = cs; break; }
+        case 16: r = pvt_sqrt1m2(v); break;
         default: { double d = v * 0.7310585786300049 + 0.25; r = div_known(v, d, 1.0 / d); break; }
     }
     y[i] = r;
@@ -691,8 +695,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         double t_angle = 0.0;
         V3 nrm{0, 0, 0};
         int tri1 = -1;   // triangle record of the nearest crossing when it lies on a mesh
-        bool em = false;   // re-emission pending: sine and cosine of the polar angle, and the azimuth
-        double em_s = 0.0, em_c = 1.0, em_phi = 0.0;
+        bool em = false;   // re-emission pending: sine and cosine of the polar angle, and the azimuth in turns
+        double em_s = 0.0, em_c = 1.0, em_turn = 0.0;
 
         // ---- stage 1: where does the ray go?  (every live lane) ------------------------------------
         // Lane classes for the rest of the step; the divergent bodies below are keyed on them.
@@ -1040,16 +1044,16 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         double sg = 2.0 * g1 - 1.0;
                         double q = (1.0 - pp * pp) / (1.0 + pp * sg);
                         em_c = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
-                        em_phi = 2.0 * kPi * rng_uniform(rng);
+                        em_turn = rng_uniform(rng);
                         em_s = pvt_sqrt1m2(em_c);
                     } else if (pt == PVT_PHASE_CONE) {
                         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
                         em_s = pvt_sqrt(g1) * pvt_sin(pp);
-                        em_phi = 2.0 * kPi * g2;
+                        em_turn = g2;
                         em_c = pvt_sqrt1m2(em_s);
                     } else {
                         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
-                        em_phi = 2.0 * kPi * g1;
+                        em_turn = g1;
                         em_c = 2.0 * g2 - 1.0;
                         em_s = pvt_sqrt1m2(em_c);
                     }
@@ -1193,7 +1197,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         const double c1 = ac_arg, s1 = fres ? pvt_sqrt1m2(ac_arg) : 0.0;   // cos / sin of the incidence angle
         if (em) {
             double sp, cp;
-            if (ABL(4)) { sp = em_phi * 0.1; cp = 1.0 - sp * sp; } else pvt_sincos(em_phi, &sp, &cp);
+            if (ABL(4)) { sp = em_turn * 0.1; cp = 1.0 - sp * sp; } else pvt_sincos2pi(em_turn, &sp, &cp);
             dir = V3{em_s * cp, em_s * sp, em_c};
         }
 

@@ -40,7 +40,8 @@ def _division_operands(rng, n, divisor):
 
 
 @pytest.mark.parametrize("fn", ["log", "sin", "cos", "asin", "acos", "sqrt", "rcp",
-                                "sincos_product", "uniform2", "ratio", "div_c", "div_n", "div_hist", "div_any"])
+                                "sincos_product", "uniform2", "ratio", "div_c", "div_n", "div_hist", "div_any",
+                                "sin2pi", "cos2pi", "sqrt1m2"])
 def test_device_arithmetic_is_bit_identical_to_host(fn):
     """The premise of everything below: IEEE divide/sqrt, u64->f64 and pvt_math.h give the
     same bits on gfx950 (hipcc, -ffp-contract=off) as on the host (gcc)."""
@@ -55,6 +56,7 @@ def test_device_arithmetic_is_bit_identical_to_host(fn):
         "div_c": _division_operands(rng, n, 2.99792458e10), "div_n": _division_operands(rng, n, 1.5),
         "div_hist": _division_operands(rng, n, 400.0),
         "div_any": _division_operands(rng, n, lambda q: q * 0.7310585786300049 + 0.25),
+        "sin2pi": rng.random(n), "cos2pi": rng.random(n), "sqrt1m2": rng.random(n) * 2 - 1,
     }[fn]
     if not fn.startswith("div_"):   # (a subnormal quotient is outside div_known's stated domain)
         x = np.concatenate((x, [1.0, 0.5, 1e-300, 0.9999999999999999]))
