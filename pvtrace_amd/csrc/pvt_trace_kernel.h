@@ -3,7 +3,6 @@
 // and the trace kernel itself.  Included once, by pvt_trace.hip (which holds the design
 // overview, the host-side packing and the C ABI).
 #pragma once
-#include <type_traits>
 // Developer-only ablation switches (timing experiments; results are WRONG when set).
 #ifndef PVT_ABLATE
 #define PVT_ABLATE 0
@@ -190,16 +189,15 @@ constexpr double kRcpCcm = 1.0 / kCcm;   // correctly rounded by the compiler
 // brackets the answer to a bucket first, the bracket is VALIDATED against the table (falls
 // back to the full range if rounding put x in a neighbouring bucket), and the same bisection
 // runs inside the bracket: typically 0-1 steps instead of ~log2(n) dependent LDS reads.
-// UNI: the descriptor (xs, ys, n, ...) is wave-uniform, so the table ends come through the scalar
-// cache.  `w` (NaN = no): the abscissae are xs[0] + i*w bit for bit AND every interval has the bits
+// `w` (NaN = no): the abscissae are xs[0] + i*w bit for bit AND every interval has the bits
 // of w (both checked by the host), so the reference's index is found by arithmetic — no table
 // walk, no dependent LDS reads — and validated against the (computed) neighbours.  `yw` likewise for
 // the ordinates (the inverse-CDF lookup returns wavelengths of an evenly spaced grid).
-template <bool TAB_LDS, bool UNI>
+template <bool TAB_LDS>
 __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n,
                                                  int guide, double scale, int hist, double rcp,
                                                  double w = __builtin_nan(""), double yw = __builtin_nan("")) {
-    auto end = [&](int i) { return UNI ? T.du(i) : T.dv(i); };
+    auto end = [&](int i) { return T.dv(i); };
     if (n == 1) return end(ys);
     const double x0 = end(xs), xl = end(xs + n - 1);
     if (x <= x0) return end(ys);
@@ -957,7 +955,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             if (hit != A.root) {
                 for (int k = 0; k < ccount; k++) {
                     const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
-                    alpha += interp_clamped<TAB_LDS, false>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
+                    alpha += interp_clamped<TAB_LDS>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
                                                             T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
                                                             T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
                     if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
@@ -993,7 +991,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         double running = 0.0;
                         for (int k = 0; k < ccount; k++) {
                             const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
-                            running += interp_clamped<TAB_LDS, false>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
+                            running += interp_clamped<TAB_LDS>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
                                                                       T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
                                                                       T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
                             if (target <= running) { comp = cbase + k; break; }
@@ -1073,12 +1071,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                                 double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
                                 e_nm = 1240.0 / e_ev;
                             }
-                            p1 = ABL(2) ? 0.3 : interp_clamped<TAB_LDS, false>(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(cd + CD_EMS_SCALE_X),
+                            p1 = ABL(2) ? 0.3 : interp_clamped<TAB_LDS>(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(cd + CD_EMS_SCALE_X),
                                                                               eh, T.dv(cd + CD_EMS_RCP_X), ew);
                         }
                         double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
                         wl = ABL(2) ? 600.0 + 50.0 * gamma
-                                    : interp_clamped<TAB_LDS, false>(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(cd + CD_EMS_SCALE_C), eh,
+                                    : interp_clamped<TAB_LDS>(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(cd + CD_EMS_SCALE_C), eh,
                                                                     T.dv(cd + CD_EMS_RCP_C), __builtin_nan(""), eh ? __builtin_nan("") : ew);
                         tau = T.dv(cd + CD_TAU_RAD);
                         ev_kind = PVT_EV_EMIT;
@@ -1109,20 +1107,17 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // Both are pure functions of (t_node, pos, tri1), so the coating / Lambertian code and the
         // x,y,z histogram axes RECOMPUTE them where needed (same arithmetic, same bits) instead of
         // keeping 12 VGPRs alive across the transcendental sites, the register-pressure peak.
-        // (UNI: the node index is wave-uniform -> its record comes through the scalar cache)
-        auto local_point_of = [&](auto uni, int node) -> V3 {
-            const int m = node * ND + ND_W2L;
-            auto rd = [&](int i) { return decltype(uni)::value ? T.du(i) : T.dv(i); };
-            if ((decltype(uni)::value ? T.iu(node * NI + NI_IDENT) : T.iv(node * NI + NI_IDENT)) != 0)   // unrotated node
-                return V3{pos.x + rd(m + 3), pos.y + rd(m + 7), pos.z + rd(m + 11)};
-            return V3{rd(m + 0) * pos.x + rd(m + 1) * pos.y + rd(m + 2) * pos.z + rd(m + 3),
-                      rd(m + 4) * pos.x + rd(m + 5) * pos.y + rd(m + 6) * pos.z + rd(m + 7),
-                      rd(m + 8) * pos.x + rd(m + 9) * pos.y + rd(m + 10) * pos.z + rd(m + 11)};
+        auto local_point = [&]() -> V3 {
+            const int m = t_node * ND + ND_W2L;
+            if (T.iv(t_node * NI + NI_IDENT) != 0)   // unrotated node: translate only
+                return V3{pos.x + T.dv(m + 3), pos.y + T.dv(m + 7), pos.z + T.dv(m + 11)};
+            return V3{T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(m + 3),
+                      T.dv(m + 4) * pos.x + T.dv(m + 5) * pos.y + T.dv(m + 6) * pos.z + T.dv(m + 7),
+                      T.dv(m + 8) * pos.x + T.dv(m + 9) * pos.y + T.dv(m + 10) * pos.z + T.dv(m + 11)};
         };
-        auto local_normal_of = [&](auto uni, int node, const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
-            auto rd = [&](int i) { return decltype(uni)::value ? T.du(i) : T.dv(i); };
-            const int gp = node * ND + ND_PARAMS;
-            const int gt = decltype(uni)::value ? T.iu(node * NI + NI_GEOM) : T.iv(node * NI + NI_GEOM);
+        auto local_normal = [&](const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
+            const int gp = t_node * ND + ND_PARAMS;
+            const int gt = T.iv(t_node * NI + NI_GEOM);
             if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
                 const pvt::MeshTri* tr = A.tris + tri1;
                 return V3{tr->n[0], tr->n[1], tr->n[2]};
@@ -1134,7 +1129,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 const double pp[3] = {lp.x, lp.y, lp.z};
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    double hs = 0.5 * rd(gp + a);
+                    double hs = 0.5 * T.dv(gp + a);
                     double dm = pvt_fabs(pp[a] - (-1.0) * hs);
                     if (dm < best) { best = dm; baxis = a; bsign = -1.0; }
                     double dp = pvt_fabs(pp[a] - hs);
@@ -1146,17 +1141,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 double mag = pvt_sqrt(dot3(lp, lp));
                 return V3{lp.x / mag, lp.y / mag, lp.z / mag};
             }
-            double half = 0.5 * rd(gp);
+            double half = 0.5 * T.dv(gp);
             double tol = 1e-8 + 1e-5 * pvt_fabs(half);
             if (pvt_fabs(lp.z + half) <= tol) return V3{0.0, 0.0, -1.0};
             if (pvt_fabs(lp.z - half) <= tol) return V3{0.0, 0.0, 1.0};
             double r = pvt_sqrt(lp.x * lp.x + lp.y * lp.y);
             return V3{lp.x / r, lp.y / r, 0.0};
         };
-        auto local_point = [&]() -> V3 { return local_point_of(std::false_type{}, t_node); };
-        auto local_normal = [&](const V3& lp) -> V3 { return local_normal_of(std::false_type{}, t_node, lp); };
-        // one pass per distinct node of the wave's surface / exit lanes: matrices and shape in SGPRs,
-        // and the shape switch is wave-uniform
         if (alive && t_normal) {
             const V3 nloc = local_normal(local_point());
             if (T.iv(t_node * NI + NI_IDENT) != 0) {
