@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 7
+#define PVT_ABI_VERSION 8
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -188,7 +188,17 @@ typedef struct PvtTraceParams {
     int64_t tally_bundle;
     int64_t tally_stride_i64;
     int64_t tally_stride_f64;
+    int64_t flags;          /* PVT_FLAG_* */
 } PvtTraceParams;
+
+/* PvtTraceParams.flags */
+enum {
+    /* pvt_trace_device: do NOT pre-fill the event log (13 memsets over 117 bytes x rows -- for the reference's
+     * defaults, 128 rows per ray of which a ray writes a dozen, that is most of a history launch).  Rows beyond
+     * counts[j] of recorded ray j are then undefined; only counts[] is cleared.  For callers that read the
+     * written rows only. */
+    PVT_FLAG_NO_LOG_PREFILL = 1
+};
 
 /* initial rays, world frame (exactly trace_bundle's three array arguments) */
 typedef struct PvtRays {

@@ -512,6 +512,7 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
         const size_t nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
         const size_t rows = nrec * (size_t)p->max_events;
         HIP_TRY(hipMemsetAsync(log->counts, 0, nrec * 4, st));
+        if (!(p->flags & PVT_FLAG_NO_LOG_PREFILL)) {
         HIP_TRY(hipMemsetAsync(log->kind, 0, rows, st));
         HIP_TRY(hipMemsetAsync(log->hit, 0xFF, rows * 4, st));
         HIP_TRY(hipMemsetAsync(log->container, 0xFF, rows * 4, st));
@@ -524,6 +525,7 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
         HIP_TRY(hipMemsetAsync(log->wavelength, 0, rows * 8, st));
         HIP_TRY(hipMemsetAsync(log->travelled, 0, rows * 8, st));
         HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
+        }
     }
     {   // the cursor belongs to the stream: two launches can only overlap on different streams
         std::lock_guard<std::mutex> lock(s->slot_mutex);

@@ -247,9 +247,10 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
         starts = np.zeros(n_recorded + 1, dtype=np.int64)
         np.cumsum(data["counts"], out=starts[1:])
         data["row_start"] = starts
+    written = (torch.arange(max_events, device=counts.device, dtype=torch.int32)[None, :]
+               < counts[:, None]).reshape(-1)
+    unwritten_host = None
     if sparse:
-        written = (torch.arange(max_events, device=counts.device, dtype=torch.int32)[None, :]
-                   < counts[:, None]).reshape(-1)
         index = written.nonzero().squeeze(1)
         index_host = index.cpu().numpy()
     for name, dtype, width in native.EVENT_LOG_COLUMNS:
@@ -267,8 +268,14 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
                 host[index_host] = written_rows
             data[name] = host
         else:
+            # most rows are written: move the whole column, then give the unwritten rows the reference's
+            # fill values on the host (the device log is not pre-filled, PVT_FLAG_NO_LOG_PREFILL)
             host = col.cpu().numpy()
-            data[name] = host.reshape(rows, 3) if width == 3 else host
+            host = host.reshape(rows, 3) if width == 3 else host
+            if unwritten_host is None:
+                unwritten_host = (~written).nonzero().squeeze(1).cpu().numpy()
+            host[unwritten_host] = -1 if name in ("hit", "container", "adjacent", "component", "source") else 0
+            data[name] = host
     return data
 
 
@@ -376,7 +383,8 @@ class Session:
                              emit_seed=int(emit_seed or 0), record_every=int(record_every),
                              maxsteps=int(maxsteps), max_events=int(max_events),
                              emit_method=EMIT_METHODS[emit_method], stream=stream.cuda_stream,
-                             workgroups_per_cu=workgroups_per_cu, tally_bundle=int(tally_bundle))
+                             workgroups_per_cu=workgroups_per_cu, tally_bundle=int(tally_bundle),
+                             log_prefill=False)   # `download` reads written rows only (or repairs the rest)
                 stop.record(stream)
         return {"stream": stream, "tallies": tallies, "log": log, "events": (start, stop), "tic": tic,
                 "rays": rays, "sources": sources, "num_rays": num_rays, "record_every": record_every,

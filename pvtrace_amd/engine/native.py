@@ -75,6 +75,7 @@ class PvtTraceParams(C.Structure):
         ("emit_seed", C.c_uint64), ("record_every", C.c_int64), ("maxsteps", C.c_int32),
         ("max_events", C.c_int32), ("emit_method", C.c_int32), ("workgroups_per_cu", C.c_int32),
         ("tally_bundle", C.c_int64), ("tally_stride_i64", C.c_int64), ("tally_stride_f64", C.c_int64),
+        ("flags", C.c_int64),
     ]
 
 
@@ -170,12 +171,12 @@ def emitter_tables_struct(emitter):
 
 
 def trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps, max_events,
-                 emit_method, workgroups_per_cu=0, tally_bundle=0, tally_stride_i64=0, tally_stride_f64=0):
+                 emit_method, workgroups_per_cu=0, tally_bundle=0, tally_stride_i64=0, tally_stride_f64=0, flags=0):
     mask = (1 << 64) - 1
     return PvtTraceParams(
         int(n_rays), int(seed) & mask, int(ray_offset) & mask, int(emit_seed) & mask,
         int(record_every), int(maxsteps), int(max_events), int(emit_method), int(workgroups_per_cu),
-        int(tally_bundle), int(tally_stride_i64), int(tally_stride_f64),
+        int(tally_bundle), int(tally_stride_i64), int(tally_stride_f64), int(flags),
     )
 
 
@@ -238,7 +239,8 @@ ABI_SYMBOLS = (
 )
 
 _lib = None
-ABI_VERSION = 7   # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 8   # include/pvtrace_hip.h PVT_ABI_VERSION
+FLAG_NO_LOG_PREFILL = 1   # PvtTraceParams.flags
 
 
 def library_built():
@@ -427,7 +429,7 @@ class DeviceScene:
 
     def trace(self, rays, n_rays, seed, tallies, log=None, ray_offset=0, emit_seed=0,
               record_every=0, maxsteps=1000, max_events=128, emit_method=0, stream=None,
-              workgroups_per_cu=0, tally_bundle=0):
+              workgroups_per_cu=0, tally_bundle=0, log_prefill=True):
         """Enqueue one bundle (`workgroups_per_cu`: see PvtTraceParams; 0 = the library default).
         `rays` is None (device emission) or a tuple of
         three float64 CUDA tensors (positions (n,3), directions (n,3), wavelengths (n))."""
@@ -442,7 +444,8 @@ class DeviceScene:
         params = trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps,
                               max_events, emit_method, workgroups_per_cu, tally_bundle,
                               tallies.get("stride_i64", 0) if tally_bundle else 0,
-                              tallies.get("stride_f64", 0) if tally_bundle else 0)
+                              tallies.get("stride_f64", 0) if tally_bundle else 0,
+                              0 if log_prefill else FLAG_NO_LOG_PREFILL)
         tl = PvtTallies(
             addr_ptr(tallies["rec_distinct"].data_ptr(), C.c_int64),
             addr_ptr(tallies["rec_crossings"].data_ptr(), C.c_int64),
