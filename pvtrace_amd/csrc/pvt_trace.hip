@@ -88,6 +88,9 @@ struct PvtScene {
     int num_cu = 0;
     int last_grid = 0, last_lds = 0;
     size_t lds_limit = 0;
+    int lazy_root = 0;              // 1 box / 2 sphere root that strictly contains every other node (see the kernel's node loop)
+    double lazy_k = 0.0;            // sphere root: 1 / (2 radius)
+    bool exit_observed = false;     // a recorder listens to (root, exit)
     bool consolidate = true;        // developer switches (environment), read once at scene creation
     double dev_blocks_per_cu = 0.0;
 };
@@ -343,6 +346,50 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     for (int i = 0; i < t->n_abs; i++) { gd[abs_x0 + i] = t->abs_x[i]; gd[abs_y0 + i] = t->abs_y[i]; }
     for (int i = 0; i < t->n_ems; i++) { gd[ems_x0 + i] = t->ems_x[i]; gd[ems_c0 + i] = t->ems_cdf[i]; }
 
+    // Lazy root (kernel node loop): the root is a box or a sphere and every other node lies strictly inside it,
+    // its bounding sphere clearing the root's surface by a margin -- then a ray from inside the root meets every
+    // other node's surface strictly before the root's.
+    int lazy_root = 0;
+    double lazy_k = 0.0;
+    bool exit_observed = false;
+    for (int r = 0; r < R; r++)
+        if (t->rec_node[r] == t->root_id && t->rec_event[r] == PVT_REC_EXIT) exit_observed = true;
+    if (!getenv("PVT_NO_LAZY_ROOT") && (t->geom_type[t->root_id] == PVT_GEOM_BOX || t->geom_type[t->root_id] == PVT_GEOM_SPHERE)) {
+        const int root = t->root_id;
+        const double* w2l = t->world_to_local + root * 16;
+        const double* rp = t->geom_params + root * 4;
+        const bool box = t->geom_type[root] == PVT_GEOM_BOX;
+        const double scale = box ? std::fmax(rp[0], std::fmax(rp[1], rp[2])) : rp[0];
+        const double margin = 1e-6 * scale + 1e-9;
+        bool inside = std::isfinite(scale) && scale > 0.0;
+        for (int n = 0; n < N && inside; n++) {
+            if (n == root) continue;
+            const double* l2w = t->local_to_world + n * 16;
+            const double* gp = t->geom_params + n * 4;
+            double radius;   // of a sphere about the node's origin that holds the whole shape
+            switch (t->geom_type[n]) {
+                case PVT_GEOM_BOX: radius = 0.5 * std::sqrt(gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]); break;
+                case PVT_GEOM_SPHERE: radius = gp[0]; break;
+                case PVT_GEOM_CYLINDER: radius = std::sqrt(gp[1] * gp[1] + 0.25 * gp[0] * gp[0]); break;
+                default: radius = INFINITY; break;   // (mesh scenes never take this path)
+            }
+            radius *= 1.0 + 1e-12;
+            double c[3];   // the node's origin in the root's frame
+            for (int a = 0; a < 3; a++)
+                c[a] = w2l[a * 4] * l2w[3] + w2l[a * 4 + 1] * l2w[7] + w2l[a * 4 + 2] * l2w[11] + w2l[a * 4 + 3];
+            if (box) {
+                for (int a = 0; a < 3; a++)
+                    if (!(0.5 * rp[a] - std::fabs(c[a]) - radius > margin)) inside = false;
+            } else {
+                if (!(rp[0] - std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) - radius > margin)) inside = false;
+            }
+        }
+        if (inside) {
+            lazy_root = box ? 1 : 2;
+            lazy_k = box ? 0.0 : 1.0 / (2.0 * rp[0]);
+        }
+    }
+
     // owned until every upload has succeeded: a failing HIP call must not leak the scene
     struct Owner {
         PvtScene* p;
@@ -358,6 +405,9 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->n_rec = R;
     s->total_bins = t->total_bins;
     s->n_coat = K;
+    s->lazy_root = lazy_root;
+    s->lazy_k = lazy_k;
+    s->exit_observed = exit_observed;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     s->num_cu = prop.multiProcessorCount;
@@ -507,6 +557,9 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     a.rec_sums = tl->rec_sums;
     a.rec_bins = reinterpret_cast<long long*>(tl->rec_bins);
     const bool record = p->record_every > 0;
+    // nobody looks at where a photon leaves the scene: the root's distance is only needed to ORDER crossings
+    a.lazy_root = (!record && !s->exit_observed && !s->d_bvh) ? s->lazy_root : 0;
+    a.lazy_k = s->lazy_k;
     if (record) {
         a.log = *log;
         const size_t nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);

@@ -100,6 +100,10 @@ struct KArgs {
     unsigned int set_size;
     int wgs_per_set;
     long long set_stride_i, set_stride_d;   // elements between consecutive sets in rec_distinct/crossings/bins and rec_sums
+    // The root is visited LAST and only by the lanes that need its exact distance (0 = off; 1 = box root,
+    // 2 = sphere root, `lazy_k` = 1/(2 radius)); see the node loop
+    int lazy_root;
+    double lazy_k;
     int bins_in_lds;
     int xslots;   // photon-state slots in LDS for drain-phase consolidation (0 = off)
 };
@@ -722,7 +726,18 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 double inv[3] = {0, 0, 0};
                 bool inv_ok = false;   // wave-uniform
                 int rot = -1;          // rotation class of `d` (wave-uniform)
-                for (int node = 0; node < A.n_nodes; node++) {
+                // The root last.  Every photon is inside the root, which therefore contributes exactly one
+                // forward crossing, farther than any crossing of a node that lies strictly inside it (the
+                // host has checked that with a margin: no ties, so the visiting order cannot matter).  All the
+                // rest of the step needs from that crossing is its ORDER among the others -- unless it is the
+                // nearest one (the photon leaves the scene) and somebody looks at where it leaves (an event
+                // log, an `exit` recorder), in which case this launch was not given `lazy_root`.  So the lanes
+                // compare the crossings they have with a cheap lower bound of the root's distance -- the
+                // distance to the root's nearest face -- and only the lanes it cannot decide for pay for the
+                // root's intersection; in a typical scene (a 5 cm slab in a 5 m world) none ever does.
+                const int lazy_root = MESH ? 0 : A.lazy_root;   // wave-uniform
+                for (int k = 0; k < A.n_nodes; k++) {
+                    const int node = !lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1));
                     const int m = node * ND + ND_W2L;
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
                     // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,
@@ -757,6 +772,28 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 // reference's argmin scans over its hit arrays (:684-714).
                 int nl = 0;
                 double tfirst = 0.0;
+                bool root_known = false;   // this lane's root crossing is accounted for without its distance
+                if (lazy_root && node == A.root) {
+                    double bound;   // <= distance to the root's surface along any direction
+                    if (lazy_root == 1) {
+                        const double mx = 0.5 * T.du(gp) - pvt_fabs(o.x), my = 0.5 * T.du(gp + 1) - pvt_fabs(o.y),
+                                     mz = 0.5 * T.du(gp + 2) - pvt_fabs(o.z);
+                        bound = mx < my ? (mx < mz ? mx : mz) : (my < mz ? my : mz);
+                    } else {   // (R^2 - |o|^2) / (2R) <= R - |o|
+                        const double radius = T.du(gp);
+                        bound = (radius * radius - dot3(o, o)) * A.lazy_k;
+                    }
+                    const bool undecided = !(bound > 0.0) || (nhits > 0 && !(t1 < bound)) || (nhits >= 2 && !(t2 < bound)) ||
+                                           (cnode >= 0 && !(cbest < bound));
+                    if (!undecided) {
+                        // one more crossing, behind all the others: nearest only if there is no other
+                        if (nhits == 0) { t1 = bound; n1 = node; }
+                        else if (nhits == 1) { t2 = INFINITY; n2 = node; }
+                        nhits += 1;
+                        if (cnode < 0) cnode = node;   // crossed once: it holds the ray unless a nearer node does
+                        root_known = true;
+                    }
+                }
                 auto fold = [&](double t) {
                     if (nl == 0) tfirst = t;
                     nl += 1;
@@ -765,7 +802,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
                     nhits += 1;
                 };
-                if (MESH && gt == PVT_GEOM_MESH) {
+                if (root_known) {
+                    // nothing to intersect
+                } else if (MESH && gt == PVT_GEOM_MESH) {
                     // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
                     // forward crossing of the node's triangles, found by a stack-free walk of
                     // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
@@ -905,7 +944,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // ray when it is crossed an ODD number of times (extension; Mesh.contains semantics,
                     // pvtrace/geometry/mesh.py:29-32)
                     const bool holds = (MESH && gt == PVT_GEOM_MESH) ? (nl & 1) != 0 : nl == 1;
-                    if (holds) {
+                    if (holds && !root_known) {
                         if (tfirst < cbest) {
                             if constexpr (MESH) { c2best = cbest; c2node = cnode; }
                             cbest = tfirst; cnode = node;

@@ -112,6 +112,35 @@ def test_gpu_against_reference_kernel_fixtures(name):
         assert snell > 100
 
 
+@pytest.mark.parametrize("name", ["fresnel_box", "lsc_equivalent", "nested_cylinders", "touching_boxes"])
+def test_tally_mode_rays_that_start_outside_or_on_the_root(name):
+    """In tally mode without an `exit` recorder the kernel visits the root last and only for the lanes that
+    need its exact distance, deciding the others by a lower bound that assumes the photon is INSIDE the
+    root.  Rays that start outside the root, on its surface, or a hair inside it must take the exact path
+    and still match the referee (integer tallies exactly)."""
+    scene = scenes.ALL_SCENES[name]()
+    compiled = compile_scene(scene)
+    assert compiled.rec_node.shape[0] > 0 or name in ("fresnel_box", "touching_boxes")
+    rng = np.random.default_rng(9)
+    n = 4000
+    root_size = compiled.geom_params[compiled.root_id]
+    reach = float(root_size[0]) if compiled.geom_type[compiled.root_id] == 1 else 0.5 * float(max(root_size[:3]))
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    scale = np.concatenate([np.full(n // 4, 1.2), np.full(n // 4, 1.0), np.full(n // 4, 1.0 - 1e-13), rng.random(n - 3 * (n // 4))])
+    pos = u * (reach * scale)[:, None]
+    dirs = -u + 0.3 * rng.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    wl = np.full(n, 555.0)
+    gpu = _kernel.trace_bundle(compiled, pos, dirs, wl, 5, 200, 16, 0, 1, 0)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, 5, 200, 16, 0, 1, 0, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=name)
+    # and with histories (the exact path for every lane) the event logs agree as well
+    gpu = _kernel.trace_bundle(compiled, pos, dirs, wl, 5, 200, 16, 0, 1, 1)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, 5, 200, 16, 0, 1, 1, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=name + " histories")
+
+
 def test_ragged_and_empty_bundles():
     scene = scenes.bench_slab(recorders=True)
     for n in (1, 2, 63, 64, 65, 127, 129, 257, 1000):
