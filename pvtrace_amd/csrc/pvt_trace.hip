@@ -91,6 +91,7 @@ struct PvtScene {
     int lazy_root = 0;              // 1 box / 2 sphere root that strictly contains every other node (see the kernel's node loop)
     double lazy_k = 0.0;            // sphere root: 1 / (2 radius)
     bool exit_observed = false;     // a recorder listens to (root, exit)
+    bool fuse_exit = false;         // see scene_create: photons leaving the only child's surface outwards are done
     bool consolidate = true;        // developer switches (environment), read once at scene creation
     double dev_blocks_per_cu = 0.0;
 };
@@ -389,6 +390,16 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             lazy_k = box ? 0.0 : 1.0 / (2.0 * rp[0]);
         }
     }
+    // Fused exit (kernel surface branch): the scene is ONE unrotated box inside a lazy root whose medium neither
+    // absorbs nor is listened to -- a photon that leaves the box's surface outwards can only leave the scene.
+    bool fuse_exit = false;
+    if (lazy_root && N == 2 && !getenv("PVT_NO_FUSED_EXIT")) {
+        const int child = 1 - t->root_id;
+        bool ok = t->geom_type[child] == PVT_GEOM_BOX && gi[child * NI + NI_IDENT] != 0 && t->comp_count[t->root_id] == 0;
+        for (int r = 0; r < R; r++)
+            if (t->rec_node[r] == t->root_id) ok = false;
+        fuse_exit = ok;
+    }
 
     // owned until every upload has succeeded: a failing HIP call must not leak the scene
     struct Owner {
@@ -408,6 +419,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->lazy_root = lazy_root;
     s->lazy_k = lazy_k;
     s->exit_observed = exit_observed;
+    s->fuse_exit = fuse_exit;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     s->num_cu = prop.multiProcessorCount;
@@ -559,6 +571,7 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     const bool record = p->record_every > 0;
     // nobody looks at where a photon leaves the scene: the root's distance is only needed to ORDER crossings
     a.lazy_root = (!record && !s->exit_observed && !s->d_bvh) ? s->lazy_root : 0;
+    a.fuse_exit = (a.lazy_root && s->fuse_exit) ? 1 : 0;
     a.lazy_k = s->lazy_k;
     if (record) {
         a.log = *log;

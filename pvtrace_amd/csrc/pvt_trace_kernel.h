@@ -104,6 +104,9 @@ struct KArgs {
     // 2 = sphere root, `lazy_k` = 1/(2 radius)); see the node loop
     int lazy_root;
     double lazy_k;
+    // 1: the scene is one unrotated box inside a lazy root with an empty, unobserved medium; a photon that leaves
+    // the box's surface outwards, provably clear of it, is finished (see the surface branch)
+    int fuse_exit;
     int bins_in_lds;
     int xslots;   // photon-state slots in LDS for drain-phase consolidation (0 = off)
 };
@@ -632,7 +635,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 in_regime = false;
                 solo = true;  // last wave standing: no more rendezvous
             } else if (total <= 64 * (nw - 1) && total <= A.xslots) {
-                const int X = A.xslots;
+                constexpr int X = kXSlots;   // (A.xslots is 0 or kXSlots: constant offsets in the LDS instructions)
                 if (alive) {
                     const int slot = before + (int)__popcll(live_mask & lane_lt);
                     xbuf[0 * X + slot] = pvt_d2u(pos.x); xbuf[1 * X + slot] = pvt_d2u(pos.y); xbuf[2 * X + slot] = pvt_d2u(pos.z);
@@ -1322,6 +1325,25 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 }
                 ev_kind = PVT_EV_TRANSMIT;
                 t_sel = (container == hit) ? PVT_REC_ESCAPING : PVT_REC_ENTERING;
+            }
+            // Fused exit (tally launches of a scene that is ONE unrotated box in an empty, unobserved world; the
+            // host sets the flag).  A photon that has just been sent away from the box's surface on the OUTSIDE
+            // can only leave the scene: its next step would find no crossing of the (convex) box, one crossing of
+            // the root, draw nothing (the world has no absorber), log nothing and fire no recorder (nobody
+            // listens to the root) -- so it ends here and its lane is refilled a step earlier.  "No crossing of
+            // the box" is not taken on trust: the reference's slab test would see, on the face's axis, the
+            // distances (h - s*o_a) / |d_a| =: g / dn to the plane the photon stands on (a rounding error that may
+            // have either sign) and a negative one to the plane behind it, so the box's far distance is at most
+            // g / dn -- below kEps, hence ignored (_kernel.pyx:271-276), whenever g <= kEps/2 * dn; g is formed
+            // with the very operations the next step would use (o = pos + t, h = 0.5 * size).  A photon that
+            // cannot be cleared this way (grazing departures) simply takes its next step.
+            if (A.fuse_exit != 0 && !terminal && count < A.maxsteps &&
+                (ev_kind == PVT_EV_REFLECT ? container == A.root : adjacent == A.root)) {
+                const V3 lp = local_point();
+                const int gp = hit * ND + ND_PARAMS;
+                const double h = 0.5 * (pvt_fabs(nrm.x) * T.dv(gp) + pvt_fabs(nrm.y) * T.dv(gp + 1) + pvt_fabs(nrm.z) * T.dv(gp + 2));
+                const double g = h - dot3(nrm, lp), dn = dot3(nrm, dir);
+                if (dn > 0.0 && g <= (0.5 * kEps) * dn) terminal = true;
             }
         }
 

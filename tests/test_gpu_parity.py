@@ -141,6 +141,52 @@ def test_tally_mode_rays_that_start_outside_or_on_the_root(name):
     assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=name + " histories")
 
 
+@pytest.mark.parametrize("world,index", [("box", 1.0), ("sphere", 1.0), ("box", 1.5), ("sphere", 1.05)])
+def test_fused_exit_clears_grazing_departures_exactly(world, index):
+    """One unrotated box in an empty, unobserved world: tally launches end a photon when it is sent away from the
+    box's surface on the outside (its exit step could not be seen by anybody).  The kernel must PROVE that the
+    reference's next slab test would ignore the box; photons leaving at grazing angles, whose rounding error on
+    the face's axis the reference turns into a genuine re-entry (a second crossing of the face), have to take the
+    step.  A third of the rays start just inside a face and head out of it at 1e-9..1e-2 rad, a third start just
+    outside and graze it (near-total Fresnel reflection at index 1.5), the rest are random."""
+    from pvtrace_amd import Box, Material, Node, Scene, Sphere
+    geometry = Box((300.0, 300.0, 300.0), material=Material(refractive_index=1.0)) if world == "box" else \
+        Sphere(radius=200.0, material=Material(refractive_index=1.0))
+    root = Node(name="world", geometry=geometry)
+    slab = Node(name="slab", geometry=Box((2.0, 3.0, 1.0), material=Material(refractive_index=index)), parent=root,
+                recorders=scenes.face_recorders(hist=False))
+    centre = np.array([0.3, -0.2, 0.5])
+    slab.location = tuple(centre)
+    compiled = compile_scene(Scene(root))
+    rng = np.random.default_rng(77)
+    n = 600_000
+    half = np.array([1.0, 1.5, 0.5])
+    local = (rng.random((n, 3)) * 2 - 1) * half * 0.999
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    k = 2 * n // 3
+    axis = rng.integers(0, 3, k)
+    sign = rng.choice([-1.0, 1.0], k)
+    gap = 10.0 ** rng.uniform(-12, -3, k)
+    slope = 10.0 ** rng.uniform(-9, -2, k)
+    inside = np.arange(k) < k // 2
+    rows = np.arange(k)
+    local[rows, axis] = sign * (half[axis] + np.where(inside, -gap, gap))
+    d[rows, axis] = np.where(inside, sign, -sign) * slope      # out of the face from inside, into it from outside
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    pos = local + centre
+    wl = np.full(n, 555.0)
+    gpu = _kernel.trace_bundle(compiled, pos, d, wl, 3, 1000, 16, 0, 1, 0)
+    cpu = O.trace_bundle(compiled, pos, d, wl, 3, 1000, 16, 0, 1, 0, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=world)
+    assert int(gpu["rec_crossings"].sum()) > n // 2
+    # small step budgets: a photon whose NEXT step would be the kill is not ended early either
+    for maxsteps in (1, 2, 3):
+        gpu = _kernel.trace_bundle(compiled, pos[::10], d[::10], wl[::10], 3, maxsteps, 16, 0, 1, 0)
+        cpu = O.trace_bundle(compiled, pos[::10], d[::10], wl[::10], 3, maxsteps, 16, 0, 1, 0, math_mode=O.MATH_PORTABLE)
+        assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=f"{world} maxsteps={maxsteps}")
+
+
 def test_ragged_and_empty_bundles():
     scene = scenes.bench_slab(recorders=True)
     for n in (1, 2, 63, 64, 65, 127, 129, 257, 1000):
