@@ -92,6 +92,7 @@ struct PvtScene {
     double lazy_k = 0.0;            // sphere root: 1 / (2 radius)
     bool exit_observed = false;     // a recorder listens to (root, exit)
     bool fuse_exit = false;         // see scene_create: photons leaving the only child's surface outwards are done
+    bool hist_reads_position = false;   // a histogram axis is x, y or z
     bool consolidate = true;        // developer switches (environment), read once at scene creation
     double dev_blocks_per_cu = 0.0;
 };
@@ -105,6 +106,32 @@ int pvt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// The surface branch asks "is the incidence angle beyond the critical angle?", which the reference evaluates as
+// acos(c) > crit (c = the clamped cosine in [0, 1]).  pvt_acos falls as c grows, so there is a threshold c* with
+// pvt_acos(c) > crit  <=>  c < c*: found here by bisection over the doubles of [0, 1] with the very pvt_acos the
+// device runs, then CHECKED -- pvt_acos is accurate to under an ulp but need not be monotone to the last bit, so
+// the 1024 doubles either side of the boundary are all evaluated; farther away the angle differs from crit by
+// hundreds of ulps (|d acos / dc| >= 1) and the sign of the comparison cannot depend on the rounding.  NaN = no
+// threshold could be proven (the kernel then evaluates the reference's expression); -inf = never total reflection.
+static double cosine_threshold(double crit) {
+    if (!(crit < INFINITY)) return -INFINITY;
+    auto beyond = [&](double c) { return pvt_acos(c) > crit; };
+    if (!beyond(0.0)) return -INFINITY;     // (not reachable for crit = asin(x) < pi/2; kept for safety)
+    if (beyond(1.0)) return NAN;
+    auto bits = [](double v) { uint64_t u; std::memcpy(&u, &v, 8); return u; };
+    auto from = [](uint64_t u) { double v; std::memcpy(&v, &u, 8); return v; };
+    uint64_t lo = bits(0.0), hi = bits(1.0);   // beyond(lo), !beyond(hi); non-negative doubles order like their bits
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (beyond(from(mid))) lo = mid; else hi = mid;
+    }
+    for (uint64_t k = 1; k <= 1024; k++) {
+        if (lo >= k && !beyond(from(lo - k))) return NAN;
+        if (hi + k <= bits(1.0) && beyond(from(hi + k))) return NAN;
+    }
+    return from(hi);   // the smallest cosine that is NOT beyond the critical angle
 }
 
 int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
@@ -138,7 +165,75 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.hist_d = lay.rec_d + R * RD;
     lay.coat_d = lay.hist_d + H * HD;
     const int spec_d = lay.coat_d + K * KD;
-    const int abs_x0 = spec_d, abs_y0 = abs_x0 + t->n_abs, ems_x0 = abs_y0 + t->n_abs, ems_c0 = ems_x0 + t->n_ems;
+    // Spectra, packed per component.  RN(1/spacing) when EVERY interval of the abscissae has the same bits and
+    // the ordinates keep the quotient inside div_known's domain (no -0.0, no extreme magnitudes):
+    auto even_rcp = [](const double* xs, const double* ys, int n) -> double {
+        if (n < 2) return NAN;
+        const double w = xs[1] - xs[0];
+        if (!(w > 1e-100 && w < 1e100)) return NAN;
+        for (int i = 1; i + 1 < n; i++) if (xs[i + 1] - xs[i] != w) return NAN;
+        for (int i = 0; i < n; i++) {
+            if (ys[i] == 0.0 && std::signbit(ys[i])) return NAN;
+            if (!(std::fabs(ys[i]) < 1e100)) return NAN;
+            if (i > 0 && ys[i] != ys[i - 1] && std::fabs(ys[i] - ys[i - 1]) < 1e-100) return NAN;
+        }
+        return 1.0 / w;
+    };
+    // The spacing itself when, additionally, xs[i] == xs[0] + i*w bit for bit AND the kernel's arithmetic
+    // (i = int((x - xs[0]) * rcp), one repair step against the computed neighbours) provably lands on the
+    // reference's bisection index for every x inside the table: the raw index is monotone in x, so it is enough
+    // that every abscissa and its two neighbouring doubles come out right (checked here with the device's own
+    // sequence of operations).  Such a table is stored as its first abscissa alone, without a guide table.
+    auto even_w = [](const double* xs, int n, double rcp) -> double {
+        if (!(rcp == rcp) || n < 2 || n > (1 << 24)) return NAN;
+        const double w = xs[1] - xs[0];
+        auto grid = [&](int i) { volatile double prod = (double)i * w; volatile double at = xs[0] + prod; return (double)at; };
+        for (int i = 0; i < n; i++)
+            if (grid(i) != xs[i]) return NAN;   // two roundings, never contracted
+        auto lands = [&](double x, int want) {
+            volatile double diff = x - xs[0];
+            volatile double quot = diff * rcp;
+            int i = (int)quot;
+            i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+            double xlo = grid(i);
+            if (x < xlo) { i -= 1; xlo = grid(i); }
+            double xhi = grid(i + 1);
+            if (!(x < xhi)) { i += 1; xlo = xhi; xhi = grid(i + 1); }
+            return i == want && xlo <= x && x < xhi;
+        };
+        for (int i = 0; i < n; i++) {   // x0 < x < xl is all the even path ever sees
+            const double below = std::nextafter(xs[i], -INFINITY), above = std::nextafter(xs[i], INFINITY);
+            if (i > 0 && !lands(below, i - 1)) return NAN;
+            if (i > 0 && i < n - 1 && !lands(xs[i], i)) return NAN;
+            if (i < n - 1 && !lands(above, i)) return NAN;
+        }
+        return w;
+    };
+    std::vector<double> c_abs_rcp(C), c_abs_w(C), c_ems_rcp_x(C), c_ems_rcp_c(C), c_ems_w(C);
+    std::vector<int> c_abs_x(C), c_abs_y(C), c_ems_x(C), c_ems_c(C), c_abs_g(C), c_ems_gx(C), c_ems_gc(C);
+    int spec_len = 0, guide_len = 0;
+    for (int c = 0; c < C; c++) {
+        const double* ax = t->abs_x + t->comp_abs_start[c];
+        const double* ay = t->abs_y + t->comp_abs_start[c];
+        const double* ex = t->ems_x + t->comp_ems_start[c];
+        const double* ec = t->ems_cdf + t->comp_ems_start[c];
+        const int an = t->comp_abs_n[c], en = t->comp_ems_n[c];
+        c_abs_rcp[c] = even_rcp(ax, ay, an);
+        c_ems_rcp_x[c] = even_rcp(ex, ec, en);
+        c_ems_rcp_c[c] = even_rcp(ec, ex, en);
+        const bool abs_hist = t->comp_abs_hist && t->comp_abs_hist[c], ems_hist = t->comp_ems_hist && t->comp_ems_hist[c];
+        c_abs_w[c] = abs_hist ? NAN : even_w(ax, an, c_abs_rcp[c]);
+        c_ems_w[c] = ems_hist ? NAN : even_w(ex, en, c_ems_rcp_x[c]);
+        const bool abs_compact = c_abs_w[c] == c_abs_w[c], ems_compact = c_ems_w[c] == c_ems_w[c];
+        c_abs_x[c] = spec_d + spec_len; spec_len += abs_compact ? (an > 0 ? 1 : 0) : an;
+        c_abs_y[c] = spec_d + spec_len; spec_len += an;
+        c_ems_x[c] = spec_d + spec_len; spec_len += ems_compact ? (en > 0 ? 1 : 0) : en;
+        c_ems_c[c] = spec_d + spec_len; spec_len += en;
+        c_abs_g[c] = abs_compact ? -1 : guide_len; guide_len += abs_compact ? 0 : an;
+        c_ems_gx[c] = ems_compact ? -1 : guide_len; guide_len += ems_compact ? 0 : en;
+        c_ems_gc[c] = guide_len; guide_len += en;
+    }
+    const int spec_end = spec_d + spec_len;
     bool index_ok = true;   // refractive indices the known-divisor division is proven for
     for (int n = 0; n < N; n++) {
         const double v = t->refractive_index[n];
@@ -146,13 +241,16 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     }
     if (!index_ok) return fail(PVT_ERR_INVALID, "refractive indices must be finite and positive");
     constexpr int kCritNodes = 16;
-    lay.crit_d = N <= kCritNodes ? ems_c0 + t->n_ems : -1;
-    std::vector<double> gd((size_t)ems_c0 + t->n_ems + (lay.crit_d >= 0 ? (size_t)N * N : 0) + 1, 0.0);
+    lay.crit_d = N <= kCritNodes ? spec_end : -1;
+    lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + N * N : -1;
+    std::vector<double> gd((size_t)spec_end + (lay.crit_d >= 0 ? (size_t)2 * N * N : 0) + 1, 0.0);
     if (lay.crit_d >= 0)
         for (int c = 0; c < N; c++)
             for (int a = 0; a < N; a++) {
                 const double n1 = t->refractive_index[c], n2 = t->refractive_index[a];
-                gd[lay.crit_d + c * N + a] = n2 < n1 ? pvt_asin(n2 / n1) : INFINITY;   // same pvt_asin as the device
+                const double crit = n2 < n1 ? pvt_asin(n2 / n1) : INFINITY;   // same pvt_asin as the device
+                gd[lay.crit_d + c * N + a] = crit;
+                gd[lay.ccrit_d + c * N + a] = cosine_threshold(crit);
             }
     lay.comp_i = N * NI;
     lay.rec_i = lay.comp_i + C * CI;
@@ -161,7 +259,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.cand_i = lay.coat_i + K * KI;
     lay.cand_list = lay.cand_i + N * 7 * 8;
     const int guide0 = lay.cand_list + R;  // guide tables: one entry per table point, per searched array
-    std::vector<int> gi((size_t)guide0 + (size_t)t->n_abs + 2 * (size_t)t->n_ems + 1, 0);
+    std::vector<int> gi((size_t)guide0 + (size_t)guide_len + 1, 0);
     // guide[b] = largest i <= n-2 with xs[i] <= xs[0] + b*(xs[n-1]-xs[0])/(n-1), b = 0..n-1
     auto build_guide = [&](const double* xs, int n, int at, double* scale) {
         *scale = 0.0;
@@ -260,51 +358,36 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         int* q = gi.data() + lay.comp_i + c * CI;
         q[CI_TYPE] = t->comp_type[c];
         q[CI_PHASE] = t->comp_phase_type[c];
-        q[CI_ABS_X] = abs_x0 + t->comp_abs_start[c];   // absolute offsets into the double blob
-        q[CI_ABS_Y] = abs_y0 + t->comp_abs_start[c];
+        q[CI_ABS_X] = c_abs_x[c];   // absolute offsets into the double blob
+        q[CI_ABS_Y] = c_abs_y[c];
         q[CI_ABS_N] = t->comp_abs_n[c];
-        q[CI_EMS_X] = ems_x0 + t->comp_ems_start[c];
-        q[CI_EMS_CDF] = ems_c0 + t->comp_ems_start[c];
+        q[CI_EMS_X] = c_ems_x[c];
+        q[CI_EMS_CDF] = c_ems_c[c];
         q[CI_EMS_N] = t->comp_ems_n[c];
         q[CI_ABS_HIST] = t->comp_abs_hist ? t->comp_abs_hist[c] : 0;
         q[CI_EMS_HIST] = t->comp_ems_hist ? t->comp_ems_hist[c] : 0;
-        q[CI_ABS_G] = guide0 + t->comp_abs_start[c];
-        q[CI_EMS_GX] = guide0 + t->n_abs + t->comp_ems_start[c];
-        q[CI_EMS_GC] = guide0 + t->n_abs + t->n_ems + t->comp_ems_start[c];
-        build_guide(t->abs_x + t->comp_abs_start[c], t->comp_abs_n[c], q[CI_ABS_G], &d[CD_ABS_SCALE]);
-        build_guide(t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GX], &d[CD_EMS_SCALE_X]);
-        build_guide(t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c], q[CI_EMS_GC], &d[CD_EMS_SCALE_C]);
-        // RN(1/spacing) when EVERY interval of the abscissae has the same bits and the ordinates
-        // keep the quotient inside div_known's domain (no -0.0, no extreme magnitudes)
-        auto even_rcp = [](const double* xs, const double* ys, int n) -> double {
-            if (n < 2) return NAN;
-            const double w = xs[1] - xs[0];
-            if (!(w > 1e-100 && w < 1e100)) return NAN;
-            for (int i = 1; i + 1 < n; i++) if (xs[i + 1] - xs[i] != w) return NAN;
-            for (int i = 0; i < n; i++) {
-                if (ys[i] == 0.0 && std::signbit(ys[i])) return NAN;
-                if (!(std::fabs(ys[i]) < 1e100)) return NAN;
-                if (i > 0 && ys[i] != ys[i - 1] && std::fabs(ys[i] - ys[i - 1]) < 1e-100) return NAN;
-            }
-            return 1.0 / w;
-        };
-        // the spacing itself when, additionally, xs[i] == xs[0] + i*w bit for bit (then the kernel finds the
-        // reference's bisection index by arithmetic): evaluated exactly as the device does
-        auto even_w = [](const double* xs, int n, double rcp) -> double {
-            if (!(rcp == rcp) || n < 2) return NAN;
-            const double w = xs[1] - xs[0];
-            for (int i = 0; i < n; i++) {
-                volatile double prod = (double)i * w;   // two roundings, never contracted
-                volatile double at = xs[0] + prod;
-                if (at != xs[i]) return NAN;
-            }
-            return w;
-        };
-        d[CD_ABS_RCP] = even_rcp(t->abs_x + t->comp_abs_start[c], t->abs_y + t->comp_abs_start[c], t->comp_abs_n[c]);
-        d[CD_EMS_RCP_X] = even_rcp(t->ems_x + t->comp_ems_start[c], t->ems_cdf + t->comp_ems_start[c], t->comp_ems_n[c]);
-        d[CD_EMS_RCP_C] = even_rcp(t->ems_cdf + t->comp_ems_start[c], t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c]);
-        d[CD_ABS_W] = even_w(t->abs_x + t->comp_abs_start[c], t->comp_abs_n[c], d[CD_ABS_RCP]);
-        d[CD_EMS_W] = even_w(t->ems_x + t->comp_ems_start[c], t->comp_ems_n[c], d[CD_EMS_RCP_X]);
+        // guide tables only for the arrays that are searched (see even_w); -1 is never dereferenced
+        q[CI_ABS_G] = c_abs_g[c] < 0 ? -1 : guide0 + c_abs_g[c];
+        q[CI_EMS_GX] = c_ems_gx[c] < 0 ? -1 : guide0 + c_ems_gx[c];
+        q[CI_EMS_GC] = guide0 + c_ems_gc[c];
+        const double* ax = t->abs_x + t->comp_abs_start[c];
+        const double* ex = t->ems_x + t->comp_ems_start[c];
+        const double* ec = t->ems_cdf + t->comp_ems_start[c];
+        const int an = t->comp_abs_n[c], en = t->comp_ems_n[c];
+        if (c_abs_g[c] >= 0) build_guide(ax, an, q[CI_ABS_G], &d[CD_ABS_SCALE]);
+        if (c_ems_gx[c] >= 0) build_guide(ex, en, q[CI_EMS_GX], &d[CD_EMS_SCALE_X]);
+        build_guide(ec, en, q[CI_EMS_GC], &d[CD_EMS_SCALE_C]);
+        d[CD_ABS_RCP] = c_abs_rcp[c];
+        d[CD_EMS_RCP_X] = c_ems_rcp_x[c];
+        d[CD_EMS_RCP_C] = c_ems_rcp_c[c];
+        d[CD_ABS_W] = c_abs_w[c];
+        d[CD_EMS_W] = c_ems_w[c];
+        // the tables themselves: a compact table keeps its first abscissa only
+        const bool abs_compact = c_abs_g[c] < 0, ems_compact = c_ems_gx[c] < 0;
+        for (int i = 0; i < (abs_compact ? (an > 0 ? 1 : 0) : an); i++) gd[c_abs_x[c] + i] = ax[i];
+        for (int i = 0; i < an; i++) gd[c_abs_y[c] + i] = t->abs_y[t->comp_abs_start[c] + i];
+        for (int i = 0; i < (ems_compact ? (en > 0 ? 1 : 0) : en); i++) gd[c_ems_x[c] + i] = ex[i];
+        for (int i = 0; i < en; i++) gd[c_ems_c[c] + i] = ec[i];
     }
     for (int r = 0; r < R; r++) {
         double* d = gd.data() + lay.rec_d + r * RD;
@@ -344,8 +427,6 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[KI_RMODE] = t->coat_reflect_mode[k];
         q[KI_TMODE] = t->coat_transmit_mode[k];
     }
-    for (int i = 0; i < t->n_abs; i++) { gd[abs_x0 + i] = t->abs_x[i]; gd[abs_y0 + i] = t->abs_y[i]; }
-    for (int i = 0; i < t->n_ems; i++) { gd[ems_x0 + i] = t->ems_x[i]; gd[ems_c0 + i] = t->ems_cdf[i]; }
 
     // Lazy root (kernel node loop): the root is a box or a sphere and every other node lies strictly inside it,
     // its bounding sphere clearing the root's surface by a margin -- then a ray from inside the root meets every
@@ -420,6 +501,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->lazy_k = lazy_k;
     s->exit_observed = exit_observed;
     s->fuse_exit = fuse_exit;
+    for (int h = 0; h < H; h++)
+        if (t->hist_prop_a[h] >= 4 || t->hist_prop_b[h] >= 4) s->hist_reads_position = true;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     s->num_cu = prop.multiProcessorCount;
@@ -618,9 +701,12 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     const size_t tab_bytes = (size_t)s->nd * 8 + (size_t)((s->ni + 1) & ~1) * 4;
     const size_t bins_bytes = ((size_t)s->total_bins * 4 + 7) & ~(size_t)7;
     const size_t budget = 64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit;  // keep >= 2 workgroups per CU
-    if (acc_bytes > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
-    const bool tab_lds = acc_bytes + tab_bytes <= budget;
-    size_t lds = acc_bytes + (tab_lds ? tab_bytes : 0);
+    // per-wave queues of first crossings awaiting their statistics (kernel: tally_flush)
+    a.tq_pos = s->hist_reads_position ? 1 : 0;
+    const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((a.tq_pos ? 7 : 4) * 8 + 4);
+    if (acc_bytes + tq_bytes > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
+    const bool tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget;
+    size_t lds = acc_bytes + tq_bytes + (tab_lds ? tab_bytes : 0);
     a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
     if (a.bins_in_lds) lds += bins_bytes;
     const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 3 : 0);

@@ -19,6 +19,7 @@ constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
 constexpr int kWaves = kBlock / 64;
 constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
 constexpr int kMaxSets = 1024;       // tally sets (bundles of a stream) one launch may serve
+constexpr int kTallyQ = 64;          // first crossings a wave parks before it computes their statistics together
 constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a draining workgroup (>= 64: the
                                      // last stage packs the survivors into one wave; >= 69 so that the 8 KB of
                                      // per-wave seed pools fit in the same region); small enough that FIVE
@@ -60,6 +61,8 @@ struct Lay {  // record bases (elements) inside the blobs; spectra follow the re
     int cand_list;  // recorder ids, ascending within each (node, selector)
     int crit_d;     // (n_nodes x n_nodes) critical angles asin(n[a]/n[c]) (+inf where n[a] >= n[c]),
                     // or -1 when the scene has too many nodes for the table
+    int ccrit_d;    // same shape: the cosine below which pvt_acos(cosine) exceeds that angle (host-proven
+                    // threshold, NaN where it could not be proven, -inf where there is no critical angle)
 };
 
 struct EmitOff {  // emitter blobs (global only; read once per photon)
@@ -109,6 +112,7 @@ struct KArgs {
     int fuse_exit;
     int bins_in_lds;
     int xslots;   // photon-state slots in LDS for drain-phase consolidation (0 = off)
+    int tq_pos;   // 1: a histogram reads x, y or z -- queued first crossings carry the local position too
 };
 
 // ------------------------------------------------------------------ RNG
@@ -206,20 +210,22 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
                                                  double w = __builtin_nan(""), double yw = __builtin_nan("")) {
     auto end = [&](int i) { return T.dv(i); };
     if (n == 1) return end(ys);
-    const double x0 = end(xs), xl = end(xs + n - 1);
+    // a table on a proven even grid (w, yw) is stored as its first value: the last one is computed, same bits
+    const bool even = !hist && w == w;
+    const double x0 = end(xs), xl = even ? x0 + (double)(n - 1) * w : end(xs + n - 1);
     if (x <= x0) return end(ys);
-    if (hist ? x > xl : x >= xl) return end(ys + n - 1);  // step tables search x == xl (plateaus)
-    if (!hist && w == w) {
+    if (hist ? x > xl : x >= xl) return yw == yw ? end(ys) + (double)(n - 1) * yw : end(ys + n - 1);  // step tables search x == xl (plateaus)
+    if (even) {
+        // the host has checked, with this very sequence of operations, that it lands on the reference's
+        // bisection index for every x of the table (pvt_trace.hip: even_w)
         int i = (int)((x - x0) * rcp);
         i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
         double xlo = x0 + (double)i * w;
         if (x < xlo) { i -= 1; xlo = x0 + (double)i * w; }
         double xhi = x0 + (double)(i + 1) * w;
         if (!(x < xhi)) { i += 1; xlo = xhi; xhi = x0 + (double)(i + 1) * w; }
-        if (xlo <= x && x < xhi) {   // always, the product being within an ulp or two of the true quotient
-            const double ylo = T.dv(ys + i), yhi = T.dv(ys + i + 1);
-            return ylo + div_known((yhi - ylo) * (x - xlo), xhi - xlo, rcp);
-        }
+        const double ylo = T.dv(ys + i), yhi = T.dv(ys + i + 1);
+        return ylo + div_known((yhi - ylo) * (x - xlo), xhi - xlo, rcp);
     }
     int b = (int)((x - x0) * scale);
     b = b < 0 ? 0 : (b > n - 2 ? n - 2 : b);
@@ -466,6 +472,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     unsigned int* acc_bins = acc_distinct + ((A.n_rec + 1) & ~1);   // (keeps what follows 8-byte aligned)
     int* ctl = reinterpret_cast<int*>(acc_bins + ((A.bins_in_lds ? A.total_bins : 0) + 1 & ~1));
     unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [14 + SEENW (+3 when RECORD)][xslots] u64 words
+    // per-wave queue of first crossings awaiting their statistics: [4 (+3 with positions)][kTallyQ] doubles
+    // + [kTallyQ] recorder ids
+    constexpr int kXWords = 14 + SEENW + (RECORD ? 3 : 0);
+    const int tq_doubles = A.tq_pos ? 7 : 4;
+    double* const tq_d = reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + (threadIdx.x >> 6) * (tq_doubles * kTallyQ);
+    int* const tq_r = reinterpret_cast<int*>(reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + kWaves * tq_doubles * kTallyQ)
+                      + (threadIdx.x >> 6) * kTallyQ;
+    int tq_n = 0;   // wave-uniform
     if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
     if constexpr (TAB_LDS) {
         for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
@@ -523,6 +537,51 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     bool counted = false, in_regime = false, solo = false;
     int members = 0, parity = 0;
 
+    // Statistics of the parked first crossings, one lane per record: the recorder's distinct count, the
+    // eight running sums (the angle is acos of the parked cosine; 1.0 -> exactly 0 for events without a
+    // normal) and its histograms.  Runs when the queue cannot take another trip, i.e. with ~60 busy lanes
+    // instead of the handful that cross a recorder in any one step, and once more when the wave retires.
+    auto tally_flush = [&]() {
+        if (lane < tq_n) {
+            const int r = tq_r[lane];
+            const double q_wl = tq_d[lane], q_angle = pvt_acos(tq_d[kTallyQ + lane]);
+            const double q_duration = tq_d[2 * kTallyQ + lane], q_travelled = tq_d[3 * kTallyQ + lane];
+            const int ri = L.rec_i + r * RI;
+            atomicAdd(&acc_distinct[r], 1u);
+            double* sp = acc_sums + r * 8;
+            atomicAdd(&sp[0], q_wl); atomicAdd(&sp[1], q_wl * q_wl);
+            atomicAdd(&sp[2], q_angle); atomicAdd(&sp[3], q_angle * q_angle);
+            atomicAdd(&sp[4], q_duration); atomicAdd(&sp[5], q_duration * q_duration);
+            atomicAdd(&sp[6], q_travelled); atomicAdd(&sp[7], q_travelled * q_travelled);
+            const int h0 = T.iv(ri + RI_HSTART), h1 = h0 + T.iv(ri + RI_HN);
+            for (int h = h0; h < h1; h++) {
+                const int hi_ = L.hist_i + h * HI, hd_ = L.hist_d + h * HD;
+                const int pa = T.iv(hi_ + HI_PA), pb = T.iv(hi_ + HI_PB);
+                const int na = T.iv(hi_ + HI_NA), nb = T.iv(hi_ + HI_NB);
+                auto prop = [&](int pr) -> double {
+                    if (pr < 4) return pr == 0 ? q_wl : pr == 1 ? q_angle : pr == 2 ? q_duration : q_travelled;
+                    return tq_d[pr * kTallyQ + lane];   // x, y, z in the recorder node's frame (A.tq_pos)
+                };
+                const double la = T.dv(hd_ + HD_LO_A), ha = T.dv(hd_ + HD_HI_A);
+                const double ra = T.dv(hd_ + HD_RA);
+                const double qa = ra == ra ? div_known(prop(pa) - la, ha - la, ra) : (prop(pa) - la) / (ha - la);
+                const int ia = (int)(qa * na);
+                if (ia < 0 || ia >= na) continue;
+                int slot = T.iv(hi_ + HI_OFF) + ia;
+                if (pb >= 0) {
+                    const double lb = T.dv(hd_ + HD_LO_B), hb = T.dv(hd_ + HD_HI_B);
+                    const double rb = T.dv(hd_ + HD_RB);
+                    const double qb = rb == rb ? div_known(prop(pb) - lb, hb - lb, rb) : (prop(pb) - lb) / (hb - lb);
+                    const int ib = (int)(qb * nb);
+                    if (ib < 0 || ib >= nb) continue;
+                    slot = T.iv(hi_ + HI_OFF) + ia * nb + ib;
+                }
+                if (A.bins_in_lds) atomicAdd(&acc_bins[slot], 1u);
+                else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i + slot, 1ull);
+            }
+        }
+        tq_n = 0;
+    };
     for (;;) {
         // ================= refill dead lanes ==============================
         unsigned long long need = __ballot(!alive);
@@ -697,7 +756,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         bool ev_normal = false, terminal = false;
         int t_sel = -1, t_node = -1;
         bool t_normal = false;
-        double t_angle = 0.0;
+        double t_cos = 1.0;   // cosine of the angle the tallies record (acos is taken when a recorder needs it)
         V3 nrm{0, 0, 0};
         int tri1 = -1;   // triangle record of the nearest crossing when it lies on a mesh
         bool em = false;   // re-emission pending: sine and cosine of the polar angle, and the azimuth in turns
@@ -1204,10 +1263,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 
         PVT_MARK(3);  // frame + normal
         // ---- transcendental sites ---------------------------------------------------
-        // Surface lanes (incidence angle) and exiting lanes (exit angle) share ONE acos -- the angle is what
-        // the tallies record and what is compared with the critical angle; Fresnel's formulas take the
-        // cosine (the dot product itself) and the sine (its composition) directly.  Re-emitting lanes need
-        // one sincos, of the azimuth.
+        // Fresnel's formulas take the cosine of the incidence angle (the dot product itself) and its sine (the
+        // composition pvt_sqrt1m2); the comparison with the critical angle is a comparison of cosines (host-
+        // proven threshold); the ANGLE is only what recorders accumulate, so its acos is taken when a first
+        // crossing is tallied (a queue of 64 per wave, below).  Re-emitting lanes need one sincos, of the azimuth.
         const bool surf = alive && t_normal && ev_kind != PVT_EV_EXIT;
         V3 nf = nrm;
         double ac_arg = 1.0;
@@ -1223,14 +1282,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 ac_arg = ddot;
             }
         }
-        double ac = 0.0;
-        if (alive && t_normal) ac = ABL(4) ? 1.5 - ac_arg : pvt_acos(ac_arg);
-        if (alive && t_normal) t_angle = ac;
+        if (alive && t_normal) t_cos = ac_arg;
         const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
         const double c1 = ac_arg, s1 = fres ? pvt_sqrt1m2(ac_arg) : 0.0;   // cos / sin of the incidence angle
         if (em) {
             double sp, cp;
-            if (ABL(4)) { sp = em_turn * 0.1; cp = 1.0 - sp * sp; } else pvt_sincos2pi(em_turn, &sp, &cp);
+            pvt_sincos2pi(em_turn, &sp, &cp);
             dir = V3{em_s * cp, em_s * sp, em_c};
         }
 
@@ -1238,7 +1295,6 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         if (surf) {
             // ---- Fresnel / coating decision at the surface (:865-895) ------------
             const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
-            const double angle = ac;
             double r = 0.0, n1 = 0.0, n2 = 0.0, rn2 = 0.0;
             if (fres) {  // unpolarised Fresnel, 1.0 beyond the critical angle (:406-419)
                 n1 = T.dv(container * ND + ND_N);
@@ -1247,8 +1303,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 // critical angle asin(n2/n1): a function of the node pair, tabulated by the host
                 // with the same pvt_asin (small scenes), else computed here
                 bool tir;
-                if (L.crit_d >= 0) tir = angle > T.dv(L.crit_d + container * A.n_nodes + adjacent);
-                else tir = n2 < n1 && angle > pvt_asin(div_known(n2, n1, T.dv(container * ND + ND_RN)));
+                // (the reference compares acos(c1) with the critical angle; the host has turned that into a
+                // comparison of c1 itself wherever it could prove the two agree for every double)
+                const double cc = L.crit_d >= 0 ? T.dv(L.ccrit_d + container * A.n_nodes + adjacent) : __builtin_nan("");
+                if (cc == cc) tir = c1 < cc;
+                else if (L.crit_d >= 0) tir = pvt_acos(c1) > T.dv(L.crit_d + container * A.n_nodes + adjacent);
+                else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(container * ND + ND_RN)));
                 if (tir) {
                     r = 1.0;
                 } else {
@@ -1381,7 +1441,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             // trip t of a lane: its bin recorder first (if any), then its list -- so lanes served by
             // the bin table and lanes served by a list share the same trips
             const int nb = rbin >= 0 ? 1 : 0, ntrips = nb + cn;
-            for (int j = 0; __ballot(j < ntrips) != 0ull; j++) {
+            for (int j = 0;; j++) {
+                const unsigned long long trip = __ballot(j < ntrips);
+                if (trip == 0ull) break;
+                if (tq_n + __popcll(trip) > kTallyQ) tally_flush();   // room for one record per lane of this trip
+                bool push = false;
+                int push_r = 0;
                 if (j < ntrips) {
                     const int r = j < nb ? rbin : T.iv(L.cand_list + cs + j - nb);
                     const int ri = L.rec_i + r * RI;
@@ -1414,42 +1479,24 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             if (w == 0) seen.w[0] |= bit; else if (w == 1) seen.w[1] |= bit;
                             else if (w == 2) seen.w[2] |= bit; else seen.w[3] |= bit;
                         }
-                        if (first) {
-                            atomicAdd(&acc_distinct[r], 1u);
-                            double* sp = acc_sums + r * 8;
-                            atomicAdd(&sp[0], wl); atomicAdd(&sp[1], wl * wl);
-                            atomicAdd(&sp[2], t_angle); atomicAdd(&sp[3], t_angle * t_angle);
-                            atomicAdd(&sp[4], duration); atomicAdd(&sp[5], duration * duration);
-                            atomicAdd(&sp[6], travelled); atomicAdd(&sp[7], travelled * travelled);
-                            const int h0 = T.iv(ri + RI_HSTART), h1 = h0 + T.iv(ri + RI_HN);
-                            for (int h = h0; h < h1; h++) {
-                                const int hi_ = L.hist_i + h * HI, hd_ = L.hist_d + h * HD;
-                                const int pa = T.iv(hi_ + HI_PA), pb = T.iv(hi_ + HI_PB);
-                                const int na = T.iv(hi_ + HI_NA), nb = T.iv(hi_ + HI_NB);
-                                auto prop = [&](int pr) -> double {
-                                    if (pr < 4) return pr == 0 ? wl : pr == 1 ? t_angle : pr == 2 ? duration : travelled;
-                                    const V3 lpos = local_point();   // position in the recorder node's frame
-                                    return pr == 4 ? lpos.x : pr == 5 ? lpos.y : lpos.z;
-                                };
-                                const double la = T.dv(hd_ + HD_LO_A), ha = T.dv(hd_ + HD_HI_A);
-                                const double ra = T.dv(hd_ + HD_RA);
-                                const double qa = ra == ra ? div_known(prop(pa) - la, ha - la, ra) : (prop(pa) - la) / (ha - la);
-                                const int ia = (int)(qa * na);
-                                if (ia < 0 || ia >= na) continue;
-                                int slot = T.iv(hi_ + HI_OFF) + ia;
-                                if (pb >= 0) {
-                                    const double lb = T.dv(hd_ + HD_LO_B), hb = T.dv(hd_ + HD_HI_B);
-                                    const double rb = T.dv(hd_ + HD_RB);
-                                    const double qb = rb == rb ? div_known(prop(pb) - lb, hb - lb, rb) : (prop(pb) - lb) / (hb - lb);
-                                    const int ib = (int)(qb * nb);
-                                    if (ib < 0 || ib >= nb) continue;
-                                    slot = T.iv(hi_ + HI_OFF) + ia * nb + ib;
-                                }
-                                if (A.bins_in_lds) atomicAdd(&acc_bins[slot], 1u);
-                                else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i + slot, 1ull);
-                            }
+                        push = first;
+                        push_r = r;
+                    }
+                }
+                // A first crossing is parked (recorder, wavelength, cosine, times[, local position]); the queue is
+                // wave-private, so plain LDS stores at ranks of a ballot are all it takes.
+                const unsigned long long pm = __ballot(push);
+                if (pm != 0ull) {
+                    const int at = tq_n + __popcll(pm & lane_lt);
+                    if (push) {
+                        tq_r[at] = push_r;
+                        tq_d[at] = wl; tq_d[kTallyQ + at] = t_cos; tq_d[2 * kTallyQ + at] = duration; tq_d[3 * kTallyQ + at] = travelled;
+                        if (A.tq_pos) {
+                            const V3 lpos = local_point();   // position in the recorder node's frame
+                            tq_d[4 * kTallyQ + at] = lpos.x; tq_d[5 * kTallyQ + at] = lpos.y; tq_d[6 * kTallyQ + at] = lpos.z;
                         }
                     }
+                    tq_n += __popcll(pm);
                 }
             }
         }
@@ -1474,6 +1521,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         for (int k = 0; k < 8; k++) atomicAdd(c + 16 + k, st_c[k]);
     }
 #endif
+    tally_flush();   // the first crossings still parked
     // ---- flush workgroup accumulators: done by the LAST wave to leave -------
     // (no closing barrier: retiring waves must never be counted by the drain-phase
     // rendezvous barriers of the waves still running)

@@ -187,6 +187,31 @@ def test_fused_exit_clears_grazing_departures_exactly(world, index):
         assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=f"{world} maxsteps={maxsteps}")
 
 
+@pytest.mark.parametrize("index", [1.5, 1.05, 2.417])
+def test_critical_angle_is_decided_like_the_reference_to_the_last_bit(index):
+    """The reference decides total internal reflection by `acos(cosine) > asin(n2/n1)`; the kernel compares the
+    cosine with a threshold the host derives from the same pvt_acos / pvt_asin and proves over the neighbouring
+    doubles.  Rays that meet the top face of a cube at every double within 3000 ulps of that threshold (and a
+    coarse sweep of the rest) must take the same branch, draw the same numbers and leave the same rows."""
+    from pvtrace_amd import Box, Material, Node, Scene, Sphere
+    root = Node(name="world", geometry=Sphere(radius=20.0, material=Material(refractive_index=1.0)))
+    Node(name="cube", geometry=Box((1.0, 1.0, 1.0), material=Material(refractive_index=index)), parent=root,
+         recorders=scenes.face_recorders(hist=False))
+    compiled = compile_scene(Scene(root))
+    centre = float(np.sqrt(1.0 - 1.0 / index ** 2))        # cosine of the critical angle, to an ulp or so
+    near = centre + np.arange(-3000, 3001) * np.spacing(centre)
+    cz = np.concatenate([near, np.linspace(1e-3, 1.0, 2000)])
+    d = np.column_stack([np.sqrt(np.maximum(0.0, 1.0 - cz * cz)), np.zeros_like(cz), cz])
+    pos = np.tile([0.0, 0.0, 0.0], (len(cz), 1)) - d * 1e-3     # the top face is met first
+    wl = np.full(len(cz), 555.0)
+    for rec_every in (1, 0):
+        gpu = _kernel.trace_bundle(compiled, pos, d, wl, 11, 40, 48, 0, 1, rec_every)
+        cpu = O.trace_bundle(compiled, pos, d, wl, 11, 40, 48, 0, 1, rec_every, math_mode=O.MATH_PORTABLE)
+        assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=f"n={index} rec_every={rec_every}")
+    kinds = gpu["rec_crossings"]
+    assert kinds.sum() > 0
+
+
 def test_ragged_and_empty_bundles():
     scene = scenes.bench_slab(recorders=True)
     for n in (1, 2, 63, 64, 65, 127, 129, 257, 1000):
