@@ -142,7 +142,37 @@ __device__ __forceinline__ double rng_uniform(Rng& r) {
     r.s0 ^= r.s3;
     r.s2 ^= t;
     r.s3 = (r.s3 << 45) | (r.s3 >> 19);
-    return (double)(result >> 11) * (1.0 / 9007199254740992.0);
+    // (double)(result >> 11) * 2^-53, as the reference writes it, is exact at every step (a 53-bit integer,
+    // then a power of two); so is this split into the top 32 and the next 21 bits, one conversion shorter
+    const double hi = (double)(unsigned int)(result >> 32), lo = (double)(unsigned int)((unsigned int)result >> 11);
+    return __builtin_fma(lo, 1.0 / 9007199254740992.0, hi * (1.0 / 4294967296.0));
+}
+
+// RN(1/x) for a finite normal x whose reciprocal is normal too: the compiler's IEEE division sequence
+// (reciprocal estimate, two Newton steps, quotient, residual, final fused correction) without the operand
+// scaling and the special-case fix-up that only matter outside that range -- same intermediate values, same
+// result, four instructions fewer.  Zero, infinities and NaN come out as garbage (callers never use them).
+// RN(x/y) likewise, for finite normal y with a normal reciprocal and x zero or normal with |x| > 1e-280, the
+// quotient neither overflowing nor subnormal (wavelengths, Fresnel amplitudes, free paths: many orders of
+// magnitude inside): three instructions fewer than the general sequence.
+__device__ __forceinline__ double div_normal(double x, double y) {
+    double r = __builtin_amdgcn_rcp(y);
+    double e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = x * r;
+    e = __builtin_fma(-y, q, x);
+    return __builtin_fma(e, r, q);
+}
+__device__ __forceinline__ double rcp_normal(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(e, r, r);
 }
 
 // ------------------------------------------------------------ table access
@@ -403,6 +433,8 @@ __global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, d
         case 14: { double sn, cs; pvt_sincos2pi(v, &sn, &cs); r = sn; break; }
         case 15: { double sn, cs; pvt_sincos2pi(v, &sn, &cs); r = cs; break; }
         case 16: r = pvt_sqrt1m2(v); break;
+        case 17: r = rcp_normal(v); break;
+        case 18: r = div_normal(v, v * 0.7310585786300049 + 0.25); break;
         default: { double d = v * 0.7310585786300049 + 0.25; r = div_known(v, d, 1.0 / d); break; }
     }
     y[i] = r;
@@ -943,7 +975,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
                 if (!inv_ok) {   // 1/d per axis, shared by consecutive nodes whose rotations have the same bits
 #pragma unroll
-                    for (int a = 0; a < 3; a++) inv[a] = 1.0 / dd[a];   // (inf for a zero component: never used below)
+                    for (int a = 0; a < 3; a++) inv[a] = rcp_normal(dd[a]);   // 1/d (garbage below 1e-300: never used)
                     inv_ok = true;
                 }
 #pragma unroll
@@ -1076,7 +1108,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 cls = CLS_EXIT;
             } else {
                 double depth = INFINITY;
-                if (alpha > kAlphaZero) depth = ABL(5) ? rng_uniform(rng) / alpha : -pvt_log(1.0 - rng_uniform(rng)) / alpha;
+                if (alpha > kAlphaZero) depth = div_normal(-pvt_log(1.0 - rng_uniform(rng)), alpha);
                 if (depth < t0) {  // absorbed (:762-832)
                     pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
                     travelled += depth;
@@ -1169,8 +1201,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             double e_nm = wl;
                             if (A.emit_method == PVT_EMIT_KT) {
                                 const double kb_ev = 1.380649e-23 / 1.60217662e-19;
-                                double e_ev = 1240.0 / e_nm + 1.5 * kb_ev * 300.0;
-                                e_nm = 1240.0 / e_ev;
+                                double e_ev = div_normal(1240.0, e_nm) + 1.5 * kb_ev * 300.0;
+                                e_nm = div_normal(1240.0, e_ev);
                             }
                             p1 = ABL(2) ? 0.3 : interp_clamped<TAB_LDS>(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(cd + CD_EMS_SCALE_X),
                                                                               eh, T.dv(cd + CD_EMS_RCP_X), ew);
@@ -1315,9 +1347,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     double q = div_known(n1, n2, rn2) * s1;
                     double k = pvt_sqrt(1.0 - q * q);
                     double rs1 = n1 * c1 - n2 * k, rs2 = n1 * c1 + n2 * k;
-                    double rs = (rs1 / rs2) * (rs1 / rs2);
+                    const double as = div_normal(rs1, rs2);   // (the reference writes each quotient twice)
+                    double rs = as * as;
                     double rp1 = n1 * k - n2 * c1, rp2 = n1 * k + n2 * c1;
-                    double rp = (rp1 / rp2) * (rp1 / rp2);
+                    const double ap = div_normal(rp1, rp2);
+                    double rp = ap * ap;
                     r = 0.5 * (rs + rp);
                 }
             }

@@ -41,7 +41,7 @@ def _division_operands(rng, n, divisor):
 
 @pytest.mark.parametrize("fn", ["log", "sin", "cos", "asin", "acos", "sqrt", "rcp",
                                 "sincos_product", "uniform2", "ratio", "div_c", "div_n", "div_hist", "div_any",
-                                "sin2pi", "cos2pi", "sqrt1m2"])
+                                "sin2pi", "cos2pi", "sqrt1m2", "rcp_normal", "div_normal"])
 def test_device_arithmetic_is_bit_identical_to_host(fn):
     """The premise of everything below: IEEE divide/sqrt, u64->f64 and pvt_math.h give the
     same bits on gfx950 (hipcc, -ffp-contract=off) as on the host (gcc)."""
@@ -56,8 +56,18 @@ def test_device_arithmetic_is_bit_identical_to_host(fn):
         "div_c": _division_operands(rng, n, 2.99792458e10), "div_n": _division_operands(rng, n, 1.5),
         "div_hist": _division_operands(rng, n, 400.0),
         "div_any": _division_operands(rng, n, lambda q: q * 0.7310585786300049 + 0.25),
-        "sin2pi": rng.random(n), "cos2pi": rng.random(n), "sqrt1m2": rng.random(n) * 2 - 1,
+        "sin2pi": rng.random(n), "cos2pi": rng.random(n), "sqrt1m2": rng.random(n) * 2 - 1, "div_normal": rng.random(n),
+        # the slab test's 1/d without operand scaling and fix-up: every normal operand with a normal reciprocal,
+        # with the awkward mantissas (all ones, one above a power of two, powers of two)
+        "rcp_normal": np.concatenate((
+            rng.normal(size=n) * 10.0 ** rng.uniform(-299, 299, n), rng.random(n) * 2 - 1,
+            np.ldexp(np.nextafter(2.0, 0.0), rng.integers(-996, 1000, 2000)), np.ldexp(np.nextafter(1.0, 2.0), rng.integers(-996, 1000, 2000)),
+            np.ldexp(1.0, np.arange(-996, 1000)), -np.ldexp(np.nextafter(2.0, 0.0), rng.integers(-996, 1000, 2000)))),
     }[fn]
+    if fn == "div_normal":    # x / (0.73 x + 0.25): quotients from 1e-280 to 1.37, both signs of x below the pole
+        x = np.concatenate((rng.random(n) * 100, rng.random(n), 10.0 ** rng.uniform(-280, 2, n), -rng.random(n) * 0.3, [0.0]))
+    if fn == "rcp_normal":
+        x = x[(np.abs(x) >= 1e-300) & (np.abs(x) <= 1e300)]
     if not fn.startswith("div_"):   # (a subnormal quotient is outside div_known's stated domain)
         x = np.concatenate((x, [1.0, 0.5, 1e-300, 0.9999999999999999]))
     dev = native.selftest_math(O.MATH_FN[fn], x)
