@@ -165,9 +165,12 @@ def main():
     pipe = BundlePipeline(dscene, depth=args.streams, distributed=distributed, reduce=args.reduce)
     pipe.wait_for_inputs()
 
-    def step(k, timed):
+    # the last bundle of a window is submitted as the job's tail (full launch width: +1 %, BundlePipeline.submit)
+    tail_wide = int(os.environ.get("PVT_TAIL_WIDE", "1"))
+
+    def step(k, timed, tail=False):
         pipe.submit(ray_sets[k % nbuf], n, seed=12345 + k * world * n, ray_offset=rank * n, maxsteps=1000,
-                    max_events=128, emit_method=0, timed=timed)
+                    max_events=128, emit_method=0, timed=timed, tail=tail)
 
     def fence():
         pipe.synchronize()
@@ -191,7 +194,7 @@ def main():
     fence()
     tic = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + k, True)
+        step(args.warmup + k, True, tail=k >= args.steps - tail_wide)
     pipe.reduce_totals()   # fold the streams' totals; RCCL all-reduce over the ranks (reduce="end")
     fence()
     elapsed = time.perf_counter() - tic
@@ -209,7 +212,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         for k in range(steps):
-            step(first_step + k, timed_events)
+            step(first_step + k, timed_events, tail=k >= steps - tail_wide)
         pipe.reduce_totals()
         fence()
         dt = time.perf_counter() - t0
@@ -248,7 +251,7 @@ def main():
         while at < hi:
             m = min(n, hi - at)
             pipe.submit(tuple(t[:m] for t in ray_sets[k % nbuf]), m, seed=777, ray_offset=at, maxsteps=1000,
-                        max_events=128, emit_method=0, timed=False)
+                        max_events=128, emit_method=0, timed=False, tail=at + m >= hi)
             at += m
             k += 1
         pipe.reduce_totals()

@@ -47,8 +47,10 @@ class BundlePipeline:
         self.wait_for_inputs()   # the zero-fills above ran on the current stream
 
     def submit(self, rays, n_rays, seed, ray_offset=0, emit_seed=0, maxsteps=1000, max_events=128,
-               emit_method=0, timed=True):
-        """Enqueue one tally-mode bundle (record_every=0) on the next stream; returns its slot."""
+               emit_method=0, timed=True, tail=False):
+        """Enqueue one tally-mode bundle (record_every=0) on the next stream; returns its slot.
+        `tail`: nothing will follow this bundle soon (the last one of a job): it is launched at the full width
+        of a lone launch, so that its own end does not run at the reduced width chosen for overlapping bundles."""
         torch = self.torch
         if self._reduced and self.distributed and self.reduce == "end":
             raise RuntimeError("totals already reduced over the ranks; call reset_totals() before submitting more bundles")
@@ -66,7 +68,7 @@ class BundlePipeline:
             self.dscene.trace(rays, n_rays, seed=seed, tallies=tallies, ray_offset=ray_offset,
                               emit_seed=emit_seed, record_every=0, maxsteps=maxsteps,
                               max_events=max_events, emit_method=emit_method,
-                              stream=stream.cuda_stream, workgroups_per_cu=self.workgroups_per_cu)
+                              stream=stream.cuda_stream, workgroups_per_cu=4 if tail else self.workgroups_per_cu)
             if timed:
                 ev[1].record(stream)
                 self.events.append(ev)
@@ -169,7 +171,7 @@ def trace_stream(scene, num_rays, bundle, seed, emit_seed=0, maxsteps=1000, max_
                 n = min(bundle, num_rays - traced)
                 pipe.submit(None, n, seed=int(seed), ray_offset=traced, emit_seed=int(emit_seed),
                             maxsteps=maxsteps, max_events=max_events,
-                            emit_method=EMIT_METHODS[emit_method], timed=False)
+                            emit_method=EMIT_METHODS[emit_method], timed=False, tail=traced + n >= num_rays)
                 traced += n
             data = pipe.totals_host()
             elapsed = time.perf_counter() - tic
