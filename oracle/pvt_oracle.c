@@ -891,6 +891,7 @@ void pvt_oracle_math(int fn, int math_mode, const double* x, double* y, long n) 
             case 14: if (M.mode) { double sn, cs; pvt_sincos2pi(x[i], &sn, &cs); y[i] = sn; } else y[i] = sin(2.0 * M_PI * x[i]); break;
             case 15: if (M.mode) { double sn, cs; pvt_sincos2pi(x[i], &sn, &cs); y[i] = cs; } else y[i] = cos(2.0 * M_PI * x[i]); break;
             case 16: y[i] = M.mode ? pvt_sqrt1m2(x[i]) : sin(acos(x[i])); break;
+            case 19: y[i] = sqrt(x[i]); break;   /* the device's short square-root sequence must equal IEEE sqrt */
             case 17: y[i] = 1.0 / x[i]; break;   /* the device's short reciprocal sequence must equal IEEE division */
             default: { double d = x[i] * 0.7310585786300049 + 0.25; y[i] = x[i] / d; break; }
         }

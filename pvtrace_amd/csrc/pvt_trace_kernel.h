@@ -165,6 +165,23 @@ __device__ __forceinline__ double div_normal(double x, double y) {
     e = __builtin_fma(-y, q, x);
     return __builtin_fma(e, r, q);
 }
+// RN(sqrt(x)) for x zero, or normal and not below 2^-767 (NaN for negative x, like the library): the compiler's
+// IEEE square-root sequence (reciprocal-root estimate, one coupled Newton step, two fused residual corrections,
+// zeros and +inf passed through) without the scaling of tiny operands.  The operands here are 1 - c^2 and
+// (1 - c)(1 + c) for cosines and sines: zero, or 2^-53 and above.
+__device__ __forceinline__ double sqrt_normal(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;   // -0, +0, +inf
+}
+__device__ __forceinline__ double sqrt1m2_normal(double c) { return sqrt_normal((1.0 - c) * (1.0 + c)); }   // pvt_sqrt1m2
 __device__ __forceinline__ double rcp_normal(double x) {
     double r = __builtin_amdgcn_rcp(x);
     double e = __builtin_fma(-x, r, 1.0);
@@ -435,6 +452,7 @@ __global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, d
         case 16: r = pvt_sqrt1m2(v); break;
         case 17: r = rcp_normal(v); break;
         case 18: r = div_normal(v, v * 0.7310585786300049 + 0.25); break;
+        case 19: r = sqrt_normal(v); break;
         default: { double d = v * 0.7310585786300049 + 0.25; r = div_known(v, d, 1.0 / d); break; }
     }
     y[i] = r;
@@ -1176,17 +1194,17 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         double q = (1.0 - pp * pp) / (1.0 + pp * sg);
                         em_c = 1.0 / (2.0 * pp) * (1.0 + pp * pp - q * q);
                         em_turn = rng_uniform(rng);
-                        em_s = pvt_sqrt1m2(em_c);
+                        em_s = sqrt1m2_normal(em_c);
                     } else if (pt == PVT_PHASE_CONE) {
                         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
                         em_s = pvt_sqrt(g1) * pvt_sin(pp);
                         em_turn = g2;
-                        em_c = pvt_sqrt1m2(em_s);
+                        em_c = sqrt1m2_normal(em_s);
                     } else {
                         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
                         em_turn = g1;
                         em_c = 2.0 * g2 - 1.0;
-                        em_s = pvt_sqrt1m2(em_c);
+                        em_s = sqrt1m2_normal(em_c);
                     }
                     em = true;
                     source = cu;
@@ -1316,7 +1334,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
         if (alive && t_normal) t_cos = ac_arg;
         const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
-        const double c1 = ac_arg, s1 = fres ? pvt_sqrt1m2(ac_arg) : 0.0;   // cos / sin of the incidence angle
+        const double c1 = ac_arg, s1 = fres ? sqrt1m2_normal(ac_arg) : 0.0;   // cos / sin of the incidence angle
         if (em) {
             double sp, cp;
             pvt_sincos2pi(em_turn, &sp, &cp);
@@ -1345,7 +1363,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     r = 1.0;
                 } else {
                     double q = div_known(n1, n2, rn2) * s1;
-                    double k = pvt_sqrt(1.0 - q * q);
+                    double k = sqrt_normal(1.0 - q * q);
                     double rs1 = n1 * c1 - n2 * k, rs2 = n1 * c1 + n2 * k;
                     const double as = div_normal(rs1, rs2);   // (the reference writes each quotient twice)
                     double rs = as * as;
@@ -1412,7 +1430,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (fres && !matched) {  // Snell, vector form (:436-446)
                     double n = div_known(n1, n2, rn2);
                     double dd = dot3(dir, nf);
-                    double c = pvt_sqrt(1.0 - n * n * (1.0 - dd * dd));
+                    double c = sqrt_normal(1.0 - n * n * (1.0 - dd * dd));
                     double sign = dd < 0.0 ? -1.0 : 1.0;
                     double k = sign * (c - sign * n * dd);
                     dir = V3{n * dir.x + k * nf.x, n * dir.y + k * nf.y, n * dir.z + k * nf.z};

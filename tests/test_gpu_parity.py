@@ -41,7 +41,7 @@ def _division_operands(rng, n, divisor):
 
 @pytest.mark.parametrize("fn", ["log", "sin", "cos", "asin", "acos", "sqrt", "rcp",
                                 "sincos_product", "uniform2", "ratio", "div_c", "div_n", "div_hist", "div_any",
-                                "sin2pi", "cos2pi", "sqrt1m2", "rcp_normal", "div_normal"])
+                                "sin2pi", "cos2pi", "sqrt1m2", "rcp_normal", "div_normal", "sqrt_normal"])
 def test_device_arithmetic_is_bit_identical_to_host(fn):
     """The premise of everything below: IEEE divide/sqrt, u64->f64 and pvt_math.h give the
     same bits on gfx950 (hipcc, -ffp-contract=off) as on the host (gcc)."""
@@ -57,6 +57,11 @@ def test_device_arithmetic_is_bit_identical_to_host(fn):
         "div_hist": _division_operands(rng, n, 400.0),
         "div_any": _division_operands(rng, n, lambda q: q * 0.7310585786300049 + 0.25),
         "sin2pi": rng.random(n), "cos2pi": rng.random(n), "sqrt1m2": rng.random(n) * 2 - 1, "div_normal": rng.random(n),
+        # squares and their neighbours (ties and near-ties of the final rounding), the whole range, 0 and +inf
+        "sqrt_normal": np.concatenate((
+            rng.random(n), rng.random(n) * 10.0 ** rng.uniform(-200, 200, n), 1.0 - rng.random(n) ** 2,
+            np.nextafter((rng.random(20000) * 3) ** 2, 0.0), np.nextafter((rng.random(20000) * 3) ** 2, 9.0),
+            (rng.integers(1, 2 ** 26, 20000).astype(np.float64) * 2.0 ** -26) ** 2, [0.0, np.inf, 4.0, 2.0 ** -700, -1.0])),
         # the slab test's 1/d without operand scaling and fix-up: every normal operand with a normal reciprocal,
         # with the awkward mantissas (all ones, one above a power of two, powers of two)
         "rcp_normal": np.concatenate((
@@ -66,10 +71,12 @@ def test_device_arithmetic_is_bit_identical_to_host(fn):
     }[fn]
     if fn == "div_normal":    # x / (0.73 x + 0.25): quotients from 1e-280 to 1.37, both signs of x below the pole
         x = np.concatenate((rng.random(n) * 100, rng.random(n), 10.0 ** rng.uniform(-280, 2, n), -rng.random(n) * 0.3, [0.0]))
-    if fn == "rcp_normal":
-        x = x[(np.abs(x) >= 1e-300) & (np.abs(x) <= 1e300)]
     if not fn.startswith("div_"):   # (a subnormal quotient is outside div_known's stated domain)
         x = np.concatenate((x, [1.0, 0.5, 1e-300, 0.9999999999999999]))
+    if fn == "rcp_normal":
+        x = x[(np.abs(x) >= 1e-300) & (np.abs(x) <= 1e300)]
+    if fn == "sqrt_normal":
+        x = x[(x <= 0.0) | (x >= 1e-200)]
     dev = native.selftest_math(O.MATH_FN[fn], x)
     host = O.math(fn, x, math_mode=O.MATH_PORTABLE)
     assert np.array_equal(dev, host, equal_nan=True), int(np.sum(dev != host))
