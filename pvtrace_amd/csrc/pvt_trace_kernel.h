@@ -666,9 +666,19 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if constexpr (EMIT) {
                     emit_one(A, A.ray_offset + i, pos, dir, wl);
                 } else {
-                    pos = V3{A.pos[i * 3ull], A.pos[i * 3ull + 1], A.pos[i * 3ull + 2]};
-                    dir = V3{A.dir[i * 3ull], A.dir[i * 3ull + 1], A.dir[i * 3ull + 2]};
-                    wl = A.wl[i];
+                    // The three ray pointers are read from the kernel-argument segment HERE, through a pointer
+                    // the compiler cannot trace back to it: kept as loop invariants they would sit in six
+                    // scalar registers the loop is short of (spilled to VGPR lanes, each use a VALU
+                    // v_readlane); scalar loads cost the vector pipe nothing.
+                    const __attribute__((address_space(4))) KArgs* ak =
+                        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ak));
+                    const double* rp = ak->pos;
+                    const double* rd = ak->dir;
+                    const double* rw = ak->wl;
+                    pos = V3{rp[i * 3ull], rp[i * 3ull + 1], rp[i * 3ull + 2]};
+                    dir = V3{rd[i * 3ull], rd[i * 3ull + 1], rd[i * 3ull + 2]};
+                    wl = rw[i];
                 }
                 if (seed_pool) {
                     const int k = pool_at + (int)(il - w_base);

@@ -149,7 +149,12 @@ def _sphere(theta, phi):
 def _to_world(local, matrix, translate):
     """(n,3) local rows -> world rows; skips the matrix product for axis-aligned lights."""
     rot = matrix[:3, :3]
-    out = local if np.array_equal(rot, np.eye(3)) else local @ rot.T
+    if np.array_equal(rot, np.eye(3)):
+        out = local
+    elif np.array_equal(rot, np.diag(np.diag(rot))):
+        out = local * np.diag(rot)        # axis flips / scalings: x*r + 0*y + 0*z, the matrix product's own bits up to a zero's sign
+    else:
+        out = local @ rot.T
     if translate and np.any(matrix[:3, 3] != 0.0):
         out = out + matrix[:3, 3]
     return out
