@@ -3,14 +3,10 @@
 // and the trace kernel itself.  Included once, by pvt_trace.hip (which holds the design
 // overview, the host-side packing and the C ABI).
 #pragma once
-// Developer-only ablation switches (timing experiments; results are WRONG when set).
-#ifndef PVT_ABLATE
-#define PVT_ABLATE 0
-#endif
+// Developer-only counters (tools/: -DPVT_STATS=1 builds print per-launch lane statistics; off in the product).
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
-#define ABL(bit) ((PVT_ABLATE >> (bit)) & 1)   // 0 tally, 2 emission wl, 4 merged acos+sincos, 5 depth log, 6 frame/normal
 
 namespace {
 
@@ -1232,12 +1228,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                                 double e_ev = div_normal(1240.0, e_nm) + 1.5 * kb_ev * 300.0;
                                 e_nm = div_normal(1240.0, e_ev);
                             }
-                            p1 = ABL(2) ? 0.3 : interp_clamped<TAB_LDS>(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(cd + CD_EMS_SCALE_X),
+                            p1 = interp_clamped<TAB_LDS>(T, e_nm, ex, ec, en, T.iv(ci + CI_EMS_GX), T.dv(cd + CD_EMS_SCALE_X),
                                                                               eh, T.dv(cd + CD_EMS_RCP_X), ew);
                         }
                         double gamma = p1 + (1.0 - p1) * rng_uniform(rng);
-                        wl = ABL(2) ? 600.0 + 50.0 * gamma
-                                    : interp_clamped<TAB_LDS>(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(cd + CD_EMS_SCALE_C), eh,
+                        wl = interp_clamped<TAB_LDS>(T, gamma, ec, ex, en, T.iv(ci + CI_EMS_GC), T.dv(cd + CD_EMS_SCALE_C), eh,
                                                                     T.dv(cd + CD_EMS_RCP_C), __builtin_nan(""), eh ? __builtin_nan("") : ew);
                         tau = T.dv(cd + CD_TAU_RAD);
                         ev_kind = PVT_EV_EMIT;
@@ -1284,19 +1279,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 return V3{tr->n[0], tr->n[1], tr->n[2]};
             }
             if (gt == PVT_GEOM_BOX) {
-                double best = INFINITY;
-                int baxis = 0;
-                double bsign = 1.0;
-                const double pp[3] = {lp.x, lp.y, lp.z};
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    double hs = 0.5 * T.dv(gp + a);
-                    double dm = pvt_fabs(pp[a] - (-1.0) * hs);
-                    if (dm < best) { best = dm; baxis = a; bsign = -1.0; }
-                    double dp = pvt_fabs(pp[a] - hs);
-                    if (dp < best) { best = dp; baxis = a; bsign = 1.0; }
-                }
-                return V3{(baxis == 0) ? bsign : 0.0, (baxis == 1) ? bsign : 0.0, (baxis == 2) ? bsign : 0.0};
+                // The reference scans -x, +x, -y, +y, -z, +z for the face nearest to the point, a later face
+                // winning only when strictly nearer (_kernel.pyx:359-377).  Per axis that is the smaller of
+                // |p + h| and |p - h| (the + face only when strictly smaller), and across axes the first
+                // smallest: the same six distances and the same comparisons, without the running triple.
+                const double hx = 0.5 * T.dv(gp), hy = 0.5 * T.dv(gp + 1), hz = 0.5 * T.dv(gp + 2);
+                const double mx = pvt_fabs(lp.x - (-1.0) * hx), px = pvt_fabs(lp.x - hx);
+                const double my = pvt_fabs(lp.y - (-1.0) * hy), py = pvt_fabs(lp.y - hy);
+                const double mz = pvt_fabs(lp.z - (-1.0) * hz), pz = pvt_fabs(lp.z - hz);
+                const double cx = px < mx ? px : mx, cy = py < my ? py : my, cz = pz < mz ? pz : mz;
+                const bool use_y = cy < cx;
+                const double cxy = use_y ? cy : cx;
+                const bool use_z = cz < cxy;
+                const double sx = px < mx ? 1.0 : -1.0, sy = py < my ? 1.0 : -1.0, sz = pz < mz ? 1.0 : -1.0;
+                return V3{(!use_y && !use_z) ? sx : 0.0, (use_y && !use_z) ? sy : 0.0, use_z ? sz : 0.0};
             }
             if (gt == PVT_GEOM_SPHERE) {
                 double mag = pvt_sqrt(dot3(lp, lp));
@@ -1336,8 +1332,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (dd > 1.0) dd = 1.0;
                 ac_arg = dd;
             } else {
-                if (dot3(nf, dir) < 0.0) nf = V3{-nf.x, -nf.y, -nf.z};
                 double ddot = dot3(nf, dir);
+                if (ddot < 0.0) {   // flip the normal along the ray; its dot product is then the negation, bit for bit
+                    nf = V3{-nf.x, -nf.y, -nf.z};
+                    ddot = -ddot;
+                }
                 if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
                 ac_arg = ddot;
             }
@@ -1482,7 +1481,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // serialises same-address lanes; no wave-uniform recorder loop, no scalar-load
         // chains, no software scan).  Recorder order per lane is ascending, as in the
         // reference's loop (_kernel.pyx:517-556).
-        if (!ABL(0) && A.n_rec > 0) {
+        if (A.n_rec > 0) {
             // Facet recorders whose facets have distinct dominant axes (the usual "one recorder
             // per box face") are found in O(1): the host files each under the bin (dominant axis,
             // sign) of its facet, the lane looks up the bin of ITS normal and verifies that one
