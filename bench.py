@@ -180,6 +180,14 @@ def main():
 
     # Clocks: an idle MI355X needs tens of milliseconds of work to reach its sustained clocks, far more
     # than `--warmup` steps of ~0.5 ms provide; spin the same path up first (untimed, not counted).
+    # First uses first: the first timed launch (HIP events with timestamps) and the first full-width launch each
+    # stall the queue for tens of milliseconds once per process; paid here, BEFORE the clocks are spun up, so that
+    # the --warmup steps below run on a warm pipeline at sustained clocks like the timed ones.
+    if args.spinup_s > 0:
+        for k in range(max(2, tail_wide + 1)):
+            step(2_000_000 + k, True, tail=k >= 1)
+        pipe.reduce_totals()
+        pipe.synchronize()
     t_spin = time.perf_counter()
     k_spin = 0
     while time.perf_counter() - t_spin < args.spinup_s:
@@ -188,7 +196,7 @@ def main():
             k_spin += 1
         pipe.synchronize()
     for k in range(args.warmup):
-        step(k, True)      # same path as the timed steps (events included); reset below
+        step(k, True, tail=k >= args.warmup - tail_wide)   # same path as the timed steps (events and the tail launch included); reset below
     pipe.reduce_totals()   # also warms the RCCL communicator up (its first collective is slow)
     pipe.reset_totals()
     fence()

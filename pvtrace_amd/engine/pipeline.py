@@ -58,26 +58,31 @@ class BundlePipeline:
         k = self.submitted % self.depth
         self.submitted += 1
         stream, tallies, total = self.streams[k], self.slots[k], self.totals[k]
+        # The kernel ADDS its tallies to the buffers it is given (atomics, once per workgroup), so a bundle can be
+        # traced straight into its stream's running totals: no zero-fill and no accumulate kernels per bundle.
+        # Only per-bundle all-reduces need the bundle's own numbers.
+        per_bundle = self.distributed and self.reduce == "bundle"
         with torch.cuda.stream(stream):
-            tallies["_ints"].zero_()
-            tallies["_sums"].zero_()
+            if per_bundle:
+                tallies["_ints"].zero_()
+                tallies["_sums"].zero_()
             ev = None
             if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(stream)
-            self.dscene.trace(rays, n_rays, seed=seed, tallies=tallies, ray_offset=ray_offset,
+            self.dscene.trace(rays, n_rays, seed=seed, tallies=tallies if per_bundle else total, ray_offset=ray_offset,
                               emit_seed=emit_seed, record_every=0, maxsteps=maxsteps,
                               max_events=max_events, emit_method=emit_method,
                               stream=stream.cuda_stream, workgroups_per_cu=4 if tail else self.workgroups_per_cu)
             if timed:
                 ev[1].record(stream)
                 self.events.append(ev)
-            if self.distributed and self.reduce == "bundle":
+            if per_bundle:
                 from pvtrace_amd.engine.distributed import all_reduce_tallies
 
                 all_reduce_tallies(tallies, group=self.group)
-            total["_ints"] += tallies["_ints"]
-            total["_sums"] += tallies["_sums"]
+                total["_ints"] += tallies["_ints"]
+                total["_sums"] += tallies["_sums"]
         return k
 
     def wait_for_inputs(self):
