@@ -261,12 +261,14 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
     if (even) {
         // the host has checked, with this very sequence of operations, that it lands on the reference's
         // bisection index for every x of the table (pvt_trace.hip: even_w)
-        int i = (int)((x - x0) * rcp);
-        i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
-        double xlo = x0 + (double)i * w;
-        if (x < xlo) { i -= 1; xlo = x0 + (double)i * w; }
-        double xhi = x0 + (double)(i + 1) * w;
-        if (!(x < xhi)) { i += 1; xlo = xhi; xhi = x0 + (double)(i + 1) * w; }
+        int i = (int)((x - x0) * rcp);   // in [0, n-1] for x0 < x < xl; n-1 (x a rounding below xl) is repaired below
+        double xlo = x0 + (double)i * w, xhi = x0 + (double)(i + 1) * w;
+        // the product is within an ulp or two of the true quotient: only an x within rounding of a grid point can
+        // come out one interval off, and the wave skips the repair unless one of its lanes holds such an x
+        if (__ballot(x < xlo || !(x < xhi)) != 0ull) {
+            if (x < xlo) { i -= 1; xhi = xlo; xlo = x0 + (double)i * w; }
+            else if (!(x < xhi)) { i += 1; xlo = xhi; xhi = x0 + (double)(i + 1) * w; }
+        }
         const double ylo = T.dv(ys + i), yhi = T.dv(ys + i + 1);
         return ylo + div_known((yhi - ylo) * (x - xlo), xhi - xlo, rcp);
     }
@@ -287,8 +289,10 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
         }
         return T.dv(ys + hi);
     }
-    if (!(xlo <= x)) { lo = 0; xlo = x0; }
-    if (!(x < xhi)) { hi = n - 1; xhi = xl; }
+    if (__ballot(!(xlo <= x) || !(x < xhi)) != 0ull) {   // (rounding put some lane's x in a neighbouring bucket: rare)
+        if (!(xlo <= x)) { lo = 0; xlo = x0; }
+        if (!(x < xhi)) { hi = n - 1; xhi = xl; }
+    }
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         const double xm = T.dv(xs + mid);
@@ -896,7 +900,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (lazy_root == 1) {
                         const double mx = 0.5 * T.du(gp) - pvt_fabs(o.x), my = 0.5 * T.du(gp + 1) - pvt_fabs(o.y),
                                      mz = 0.5 * T.du(gp + 2) - pvt_fabs(o.z);
-                        bound = mx < my ? (mx < mz ? mx : mz) : (my < mz ? my : mz);
+                        bound = __builtin_fmin(__builtin_fmin(mx, my), mz);
                     } else {   // (R^2 - |o|^2) / (2R) <= R - |o|
                         const double radius = T.du(gp);
                         bound = (radius * radius - dot3(o, o)) * A.lazy_k;
@@ -1002,6 +1006,17 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     for (int a = 0; a < 3; a++) inv[a] = rcp_normal(dd[a]);   // 1/d (garbage below 1e-300: never used)
                     inv_ok = true;
                 }
+                // a ray parallel to a pair of faces (a direction component below 1e-300) takes the reference's
+                // inside/outside test for that axis; the wave only runs the general form when a lane holds one
+                if (__ballot(pvt_fabs(dd[0]) < 1e-300 || pvt_fabs(dd[1]) < 1e-300 || pvt_fabs(dd[2]) < 1e-300) == 0ull) {
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const double sz = T.du(gp + a);
+                        const double ta = (-0.5 * sz - oo[a]) * inv[a], tb = (0.5 * sz - oo[a]) * inv[a];
+                        tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                        tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                    }
+                } else
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
                     double sz = T.du(gp + a);
@@ -1009,10 +1024,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (pvt_fabs(dd[a]) < 1e-300) {
                         if (oo[a] < lo || oo[a] > hi) miss = true;
                     } else {
-                        double ta = (lo - oo[a]) * inv[a], tb = (hi - oo[a]) * inv[a];
-                        if (ta > tb) { double tmp = ta; ta = tb; tb = tmp; }
-                        if (ta > tmin) tmin = ta;
-                        if (tb < tmax) tmax = tb;
+                        // (the reference swaps ta, tb into order and keeps the largest entry / smallest exit
+                        // distance: min and max of finite numbers, which is what these are)
+                        const double ta = (lo - oo[a]) * inv[a], tb = (hi - oo[a]) * inv[a];
+                        tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                        tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
                     }
                 }
                 if (!miss && !(tmax < tmin)) {
@@ -1287,9 +1303,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 const double mx = pvt_fabs(lp.x - (-1.0) * hx), px = pvt_fabs(lp.x - hx);
                 const double my = pvt_fabs(lp.y - (-1.0) * hy), py = pvt_fabs(lp.y - hy);
                 const double mz = pvt_fabs(lp.z - (-1.0) * hz), pz = pvt_fabs(lp.z - hz);
-                const double cx = px < mx ? px : mx, cy = py < my ? py : my, cz = pz < mz ? pz : mz;
+                const double cx = __builtin_fmin(px, mx), cy = __builtin_fmin(py, my), cz = __builtin_fmin(pz, mz);   // (no NaNs here)
                 const bool use_y = cy < cx;
-                const double cxy = use_y ? cy : cx;
+                const double cxy = __builtin_fmin(cy, cx);
                 const bool use_z = cz < cxy;
                 const double sx = px < mx ? 1.0 : -1.0, sy = py < my ? 1.0 : -1.0, sz = pz < mz ? 1.0 : -1.0;
                 return V3{(!use_y && !use_z) ? sx : 0.0, (use_y && !use_z) ? sy : 0.0, use_z ? sz : 0.0};
@@ -1328,17 +1344,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         double ac_arg = 1.0;
         if (alive && t_normal) {
             if (ev_kind == PVT_EV_EXIT) {
-                double dd = pvt_fabs(dot3(nrm, dir));
-                if (dd > 1.0) dd = 1.0;
-                ac_arg = dd;
+                ac_arg = __builtin_fmin(pvt_fabs(dot3(nrm, dir)), 1.0);
             } else {
                 double ddot = dot3(nf, dir);
                 if (ddot < 0.0) {   // flip the normal along the ray; its dot product is then the negation, bit for bit
                     nf = V3{-nf.x, -nf.y, -nf.z};
                     ddot = -ddot;
                 }
-                if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
-                ac_arg = ddot;
+                ac_arg = __builtin_fmin(ddot, 1.0);   // (non-negative after the flip; the reference also clamps at -1)
             }
         }
         if (alive && t_normal) t_cos = ac_arg;
