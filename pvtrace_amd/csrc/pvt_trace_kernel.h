@@ -1138,21 +1138,23 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
         int comp = -1;
         if (pend) {
+            // free path in the container (no draw when the photon leaves the scene or the medium is clear), then
+            // ONE advance for all three outcomes: to the absorption point if that comes first, else to the surface
+            double depth = INFINITY;
+            if (hit != A.root && alpha > kAlphaZero) depth = div_normal(-pvt_log(1.0 - rng_uniform(rng)), alpha);
+            {
+                const double adv = __builtin_fmin(depth, t0);   // (depth == t0 is a surface event: same value)
+                pos.x = pos.x + dir.x * adv; pos.y = pos.y + dir.y * adv; pos.z = pos.z + dir.z * adv;
+                travelled += adv;
+                duration += div_known(adv * n_container, kCcm, kRcpCcm);
+            }
             if (hit == A.root) {  // leaves the scene (:728-744)
-                pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
-                travelled += t0;
-                duration += div_known(t0 * n_container, kCcm, kRcpCcm);
                 ev_kind = PVT_EV_EXIT; ev_hit = hit; ev_adjacent = adjacent;
                 terminal = true;
                 t_sel = PVT_REC_EXIT; t_node = hit; t_normal = true;
                 cls = CLS_EXIT;
             } else {
-                double depth = INFINITY;
-                if (alpha > kAlphaZero) depth = div_normal(-pvt_log(1.0 - rng_uniform(rng)), alpha);
                 if (depth < t0) {  // absorbed (:762-832)
-                    pos.x = pos.x + dir.x * depth; pos.y = pos.y + dir.y * depth; pos.z = pos.z + dir.z * depth;
-                    travelled += depth;
-                    duration += div_known(depth * n_container, kCcm, kRcpCcm);
                     const double target = rng_uniform(rng) * alpha;
                     comp = cbase;
                     if (ccount <= 4) {
@@ -1176,9 +1178,6 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     cls = CLS_ABS;
                 } else {
                     // ---- surface interaction (:834-895) ---------
-                    pos.x = pos.x + dir.x * t0; pos.y = pos.y + dir.y * t0; pos.z = pos.z + dir.z * t0;
-                    travelled += t0;
-                    duration += div_known(t0 * n_container, kCcm, kRcpCcm);
                     ev_hit = hit;
                     if (adjacent < 0) {  // malformed scene (:840-845)
                         ev_kind = PVT_EV_KILL;
