@@ -137,12 +137,48 @@ class EmitterTables:
         self.spec_cdf = np.array(sc, dtype=np.float64)
 
 
+_POOL = None
+
+
+def _chunked(fn, n, min_rows=200_000):
+    """Run `fn(lo, hi)` over row ranges covering [0, n): on a few worker threads when the bundle is large
+    (numpy's elementwise kernels release the GIL).  The draws themselves stay sequential, so the result does
+    not depend on the split."""
+    if n < 2 * min_rows:
+        fn(0, n)
+        return
+    global _POOL
+    import concurrent.futures
+    import os
+
+    workers = max(1, min(8, (os.cpu_count() or 1), n // min_rows))
+    if _POOL is None:
+        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=8, thread_name_prefix="pvt-emit")
+    edges = np.linspace(0, n, workers + 1).astype(np.int64)
+    list(_POOL.map(lambda k: fn(int(edges[k]), int(edges[k + 1])), range(workers)))
+
+
 def _sphere(theta, phi):
     out = np.empty((theta.shape[0], 3))
-    st = np.sin(theta)
-    np.multiply(st, np.cos(phi), out=out[:, 0])
-    np.multiply(st, np.sin(phi), out=out[:, 1])
-    np.cos(theta, out=out[:, 2])
+
+    def rows(lo, hi):
+        st = np.sin(theta[lo:hi])
+        np.multiply(st, np.cos(phi[lo:hi]), out=out[lo:hi, 0])
+        np.multiply(st, np.sin(phi[lo:hi]), out=out[lo:hi, 1])
+        np.cos(theta[lo:hi], out=out[lo:hi, 2])
+
+    _chunked(rows, theta.shape[0])
+    return out
+
+
+def _map(fn, x):
+    """Elementwise `fn` over a 1-D array, chunked like `_sphere`."""
+    out = np.empty_like(x)
+
+    def rows(lo, hi):
+        out[lo:hi] = fn(x[lo:hi])
+
+    _chunked(rows, x.shape[0])
     return out
 
 
@@ -182,13 +218,13 @@ def _sample_light(tab, i, n, uniform):
         pos = np.zeros((n, 3))
     kind, prm = tab.dir_type[i], tab.dir_param[i]
     if kind == DIR_CONE:
-        theta = np.arcsin(np.sqrt(uniform(n)) * np.sin(prm))
+        theta = _map(lambda u: np.arcsin(np.sqrt(u) * np.sin(prm)), uniform(n))
         direc = _sphere(theta, 2 * np.pi * uniform(n))
     elif kind == DIR_ISOTROPIC:
         phi = 2 * np.pi * uniform(n)
-        direc = _sphere(np.arccos(2 * uniform(n) - 1), phi)
+        direc = _sphere(_map(lambda u: np.arccos(2 * u - 1), uniform(n)), phi)
     elif kind == DIR_LAMBERTIAN:
-        theta = np.arcsin(np.sqrt(uniform(n)))
+        theta = _map(lambda u: np.arcsin(np.sqrt(u)), uniform(n))
         direc = _sphere(theta, 2 * np.pi * uniform(n))
     elif kind == DIR_HG:
         s = 2 * uniform(n) - 1

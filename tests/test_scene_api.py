@@ -147,6 +147,21 @@ def test_emit_bundle_matches_reference_distributions():
     assert np.array_equal(a, b)
 
 
+def test_large_bundles_emitted_on_worker_threads_equal_the_single_threaded_arrays(monkeypatch):
+    """Bundles of 4e5 rays and more evaluate their trigonometry in row chunks on a few threads; the draws stay
+    sequential, so the arrays must not depend on the split."""
+    from pvtrace_amd.engine import emit as E
+    from tests import scenes as S
+
+    for scene in (S.lsc_equivalent(), S.hello_world(), S.lambertian_sheet()):
+        threaded = E.emit_bundle(scene, 450_000, seed=11)
+        with monkeypatch.context() as m:
+            m.setattr(E, "_chunked", lambda fn, n, min_rows=0: fn(0, n))
+            single = E.emit_bundle(scene, 450_000, seed=11)
+        for a, b in zip(threaded[:3], single[:3]):
+            assert np.array_equal(a, b)
+
+
 def test_emit_falls_back_for_custom_delegates_and_device_mode_refuses():
     w = Node(name="w", geometry=Sphere(5.0, material=Material(1.0)))
     Node(name="l", parent=w, light=Light(direction=lambda: (0.0, 1.0, 0.0), name="odd"))
