@@ -857,7 +857,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 // compare the crossings they have with a cheap lower bound of the root's distance -- the
                 // distance to the root's nearest face -- and only the lanes it cannot decide for pay for the
                 // root's intersection; in a typical scene (a 5 cm slab in a 5 m world) none ever does.
-                const int lazy_root = MESH ? 0 : A.lazy_root;   // wave-uniform
+                const int lazy_root = (MESH || RECORD) ? 0 : A.lazy_root;   // wave-uniform (tally launches only)
                 for (int k = 0; k < A.n_nodes; k++) {
                     const int node = !lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1));
                     const int m = node * ND + ND_W2L;
@@ -1470,7 +1470,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             // g / dn -- below kEps, hence ignored (_kernel.pyx:271-276), whenever g <= kEps/2 * dn; g is formed
             // with the very operations the next step would use (o = pos + t, h = 0.5 * size).  A photon that
             // cannot be cleared this way (grazing departures) simply takes its next step.
-            if (A.fuse_exit != 0 && !terminal && count < A.maxsteps &&
+            if (!RECORD && !MESH && A.fuse_exit != 0 && !terminal && count < A.maxsteps &&
                 (ev_kind == PVT_EV_REFLECT ? container == A.root : adjacent == A.root)) {
                 const V3 lp = local_point();
                 const int gp = hit * ND + ND_PARAMS;
