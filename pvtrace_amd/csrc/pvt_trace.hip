@@ -19,7 +19,15 @@
 //     re-converged block at the end of the step instead of being emitted from
 //     each divergent branch;
 //   * recorders accumulate in LDS (integer + f64 atomics) and are flushed with
-//     one global atomic per slot per workgroup;
+//     one global atomic per slot per workgroup; the statistics of first
+//     crossings (angle, sums, histograms) are parked 64 per wave and computed
+//     together;
+//   * what the host can prove about a scene is decided once, not per photon:
+//     arithmetic table indices on even grids (the abscissae are not even stored),
+//     cosine thresholds for total internal reflection, the world node visited
+//     lazily, photons that can only leave the scene ended where they leave the
+//     last box (tally launches; each with a proof obligation checked per lane
+//     where one is needed);
 //   * all arithmetic is FP64 with FMA contraction off and the transcendental
 //     functions of pvt_math.h, so a photon's whole history is bit-identical to
 //     the CPU referee (oracle/pvt_oracle.c, math_mode 1).
