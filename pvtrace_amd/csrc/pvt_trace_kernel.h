@@ -1118,9 +1118,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // wave walks them: node and component records then come through the scalar cache as SGPR
         // operands instead of chains of dependent per-lane LDS reads.
         // alpha = sum of the components' coefficients; the running partial sums ARE the cumulative
-        // thresholds the reference recomputes when it picks the absorbing component (:768-781), so
-        // keep the first four
-        double alpha = 0.0, pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0, n_container = 1.0;
+        // thresholds the reference recomputes when it picks the absorbing component (:768-781): the first
+        // one is kept (it decides for containers of two components; more are re-walked when a lane needs it)
+        double alpha = 0.0, pre0 = 0.0, n_container = 1.0;
         int cbase = 0, ccount = 0;
         if (pend) {
             n_container = T.dv(container * ND + ND_N);
@@ -1131,8 +1131,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     alpha += interp_clamped<TAB_LDS>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
                                                             T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
                                                             T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
-                    if (k == 0) pre0 = alpha; else if (k == 1) pre1 = alpha;
-                    else if (k == 2) pre2 = alpha; else if (k == 3) pre3 = alpha;
+                    if (k == 0) pre0 = alpha;
                 }
             }
         }
@@ -1157,11 +1156,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (depth < t0) {  // absorbed (:762-832)
                     const double target = rng_uniform(rng) * alpha;
                     comp = cbase;
-                    if (ccount <= 4) {
-                        if (target <= pre0) comp = cbase;
-                        else if (ccount > 1 && target <= pre1) comp = cbase + 1;
-                        else if (ccount > 2 && target <= pre2) comp = cbase + 2;
-                        else if (ccount > 3 && target <= pre3) comp = cbase + 3;
+                    if (ccount <= 2) {
+                        // (the reference walks the cumulative coefficients; with two components the first
+                        // partial sum decides, and the last component takes what is left, :768-781)
+                        comp = (ccount == 2 && !(target <= pre0)) ? cbase + 1 : cbase;
                     } else {
                         double running = 0.0;
                         for (int k = 0; k < ccount; k++) {
