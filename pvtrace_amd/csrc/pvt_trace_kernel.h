@@ -819,8 +819,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         double t_cos = 1.0;   // cosine of the angle the tallies record (acos is taken when a recorder needs it)
         V3 nrm{0, 0, 0};
         int tri1 = -1;   // triangle record of the nearest crossing when it lies on a mesh
-        bool em = false;   // re-emission pending: sine and cosine of the polar angle, and the azimuth in turns
-        double em_s = 0.0, em_c = 1.0, em_turn = 0.0;
+        bool em = false;   // re-emitted in this step
 
         // ---- stage 1: where does the ray go?  (every live lane) ------------------------------------
         // Lane classes for the rest of the step; the divergent bodies below are keyed on them.
@@ -1203,8 +1202,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (radiative) {
                     // phase function (_kernel.pyx:455-476): the draws, in the reference's order, give the
                     // cosine (or sine) of the polar angle; its partner is the composition pvt_sqrt1m2; the
-                    // azimuth's sincos runs at its own site below and the new direction is written before
-                    // the event is logged
+                    // azimuth is 2 pi `em_turn` (pvt_sincos2pi); the new direction is written here, before the
+                    // event is logged at the end of the step
+                    double em_s, em_c, em_turn;
                     const int pt = T.iv(ci + CI_PHASE);
                     const double pp = T.dv(cd + CD_PHASE);
                     if (pt == PVT_PHASE_HG && pvt_fabs(pp) >= kEps) {
@@ -1224,6 +1224,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         em_turn = g1;
                         em_c = 2.0 * g2 - 1.0;
                         em_s = sqrt1m2_normal(em_c);
+                    }
+                    {
+                        double sp, cp;
+                        pvt_sincos2pi(em_turn, &sp, &cp);
+                        dir = V3{em_s * cp, em_s * sp, em_c};
                     }
                     em = true;
                     source = cu;
@@ -1354,11 +1359,6 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         if (alive && t_normal) t_cos = ac_arg;
         const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
         const double c1 = ac_arg, s1 = fres ? sqrt1m2_normal(ac_arg) : 0.0;   // cos / sin of the incidence angle
-        if (em) {
-            double sp, cp;
-            pvt_sincos2pi(em_turn, &sp, &cp);
-            dir = V3{em_s * cp, em_s * sp, em_c};
-        }
 
         PVT_MARK(4);  // acos + sincos
         if (surf) {
