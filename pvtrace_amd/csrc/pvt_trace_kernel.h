@@ -544,7 +544,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     Tables<TAB_LDS> T{(CDoubles)A.gd, (CInts)A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi, A.gd, A.gi};
 
     const int lane = threadIdx.x & 63;
-    const unsigned long long lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // rank of this lane among the set bits of a wave mask: the bits below it, counted by the mbcnt pair
+    auto rank_in = [](unsigned long long mask) -> unsigned int {
+        return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+    };
 
     // ---- the rays this workgroup draws from: the whole launch, or its tally set (wave-uniform) ------
     const unsigned int set = A.set_size ? blockIdx.x / (unsigned int)A.wgs_per_set : 0u;
@@ -658,7 +661,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 }
             }
             unsigned int avail = w_end - w_next;
-            unsigned int rank = __popcll(need & lane_lt);
+            unsigned int rank = rank_in(need);
             unsigned int want = __popcll(need);
             if (!alive && rank < avail) {
                 const unsigned int il = w_next + rank;   // index within the set
@@ -756,7 +759,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             } else if (total <= 64 * (nw - 1) && total <= A.xslots) {
                 constexpr int X = kXSlots;   // (A.xslots is 0 or kXSlots: constant offsets in the LDS instructions)
                 if (alive) {
-                    const int slot = before + (int)__popcll(live_mask & lane_lt);
+                    const int slot = before + (int)rank_in(live_mask);
                     xbuf[0 * X + slot] = pvt_d2u(pos.x); xbuf[1 * X + slot] = pvt_d2u(pos.y); xbuf[2 * X + slot] = pvt_d2u(pos.z);
                     xbuf[3 * X + slot] = pvt_d2u(dir.x); xbuf[4 * X + slot] = pvt_d2u(dir.y); xbuf[5 * X + slot] = pvt_d2u(dir.z);
                     xbuf[6 * X + slot] = pvt_d2u(wl); xbuf[7 * X + slot] = pvt_d2u(travelled); xbuf[8 * X + slot] = pvt_d2u(duration);
@@ -1342,15 +1345,16 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // proven threshold); the ANGLE is only what recorders accumulate, so its acos is taken when a first
         // crossing is tallied (a queue of 64 per wave, below).  Re-emitting lanes need one sincos, of the azimuth.
         const bool surf = alive && t_normal && ev_kind != PVT_EV_EXIT;
-        V3 nf = nrm;
+        bool flip = false;       // the normal is used flipped along the ray (nf = -nrm)
+        double ddot = 0.0;       // nf . dir, before the clamp
         double ac_arg = 1.0;
         if (alive && t_normal) {
             if (ev_kind == PVT_EV_EXIT) {
                 ac_arg = __builtin_fmin(pvt_fabs(dot3(nrm, dir)), 1.0);
             } else {
-                double ddot = dot3(nf, dir);
+                ddot = dot3(nrm, dir);
                 if (ddot < 0.0) {   // flip the normal along the ray; its dot product is then the negation, bit for bit
-                    nf = V3{-nf.x, -nf.y, -nf.z};
+                    flip = true;
                     ddot = -ddot;
                 }
                 ac_arg = __builtin_fmin(ddot, 1.0);   // (non-negative after the flip; the reference also clamps at -1)
@@ -1437,8 +1441,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     dir.x = T.dv(q + 0) * dl.x + T.dv(q + 1) * dl.y + T.dv(q + 2) * dl.z;
                     dir.y = T.dv(q + 3) * dl.x + T.dv(q + 4) * dl.y + T.dv(q + 5) * dl.z;
                     dir.z = T.dv(q + 6) * dl.x + T.dv(q + 7) * dl.y + T.dv(q + 8) * dl.z;
-                } else {  // specular (:422-433): nf is nrm flipped along dir
-                    double dd = dot3(nf, dir);
+                } else {  // specular (:422-433): nf is nrm flipped along dir, dd their dot product (formed above)
+                    const V3 nf{flip ? -nrm.x : nrm.x, flip ? -nrm.y : nrm.y, flip ? -nrm.z : nrm.z};
+                    const double dd = ddot;
                     dir = V3{dir.x - 2.0 * dd * nf.x, dir.y - 2.0 * dd * nf.y, dir.z - 2.0 * dd * nf.z};
                 }
                 ev_kind = PVT_EV_REFLECT;
@@ -1448,7 +1453,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (coat >= 0) matched = T.iv(L.coat_i + coat * KI + KI_TMODE) == 1;
                 if (fres && !matched) {  // Snell, vector form (:436-446)
                     double n = div_known(n1, n2, rn2);
-                    double dd = dot3(dir, nf);
+                    const V3 nf{flip ? -nrm.x : nrm.x, flip ? -nrm.y : nrm.y, flip ? -nrm.z : nrm.z};
+                    const double dd = ddot;   // dir . nf
                     double c = sqrt_normal(1.0 - n * n * (1.0 - dd * dd));
                     double sign = dd < 0.0 ? -1.0 : 1.0;
                     double k = sign * (c - sign * n * dd);
@@ -1558,7 +1564,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 // wave-private, so plain LDS stores at ranks of a ballot are all it takes.
                 const unsigned long long pm = __ballot(push);
                 if (pm != 0ull) {
-                    const int at = tq_n + __popcll(pm & lane_lt);
+                    const int at = tq_n + (int)rank_in(pm);
                     if (push) {
                         tq_r[at] = push_r;
                         tq_d[at] = wl; tq_d[kTallyQ + at] = t_cos; tq_d[2 * kTallyQ + at] = duration; tq_d[3 * kTallyQ + at] = travelled;
