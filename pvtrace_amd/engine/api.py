@@ -247,11 +247,14 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
         starts = np.zeros(n_recorded + 1, dtype=np.int64)
         np.cumsum(data["counts"], out=starts[1:])
         data["row_start"] = starts
-    written = (torch.arange(max_events, device=counts.device, dtype=torch.int32)[None, :]
-               < counts[:, None]).reshape(-1)
     unwritten_host = None
     if sparse:
-        index = written.nonzero().squeeze(1)
+        # rows written = event k < counts[j] of recorded ray j, i.e. row j*max_events + k: built from the counts
+        # (one entry per written row), not by scanning a mask over every row of the log
+        counts64 = counts.to(torch.int64)
+        first = torch.cumsum(counts64, 0) - counts64                     # first packed position of each ray
+        ray = torch.repeat_interleave(torch.arange(n_recorded, device=counts.device), counts64, output_size=used)
+        index = ray * max_events + (torch.arange(used, device=counts.device) - first[ray])
         index_host = index.cpu().numpy()
     for name, dtype, width in native.EVENT_LOG_COLUMNS:
         col = log[name][: rows * width]
@@ -273,6 +276,8 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
             host = col.cpu().numpy()
             host = host.reshape(rows, 3) if width == 3 else host
             if unwritten_host is None:
+                written = (torch.arange(max_events, device=counts.device, dtype=torch.int32)[None, :]
+                           < counts[:, None]).reshape(-1)
                 unwritten_host = (~written).nonzero().squeeze(1).cpu().numpy()
             host[unwritten_host] = -1 if name in ("hit", "container", "adjacent", "component", "source") else 0
             data[name] = host
