@@ -1339,11 +1339,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
 
         PVT_MARK(3);  // frame + normal
-        // ---- transcendental sites ---------------------------------------------------
+        // ---- incidence geometry -----------------------------------------------------
         // Fresnel's formulas take the cosine of the incidence angle (the dot product itself) and its sine (the
         // composition pvt_sqrt1m2); the comparison with the critical angle is a comparison of cosines (host-
         // proven threshold); the ANGLE is only what recorders accumulate, so its acos is taken when a first
-        // crossing is tallied (a queue of 64 per wave, below).  Re-emitting lanes need one sincos, of the azimuth.
+        // crossing is tallied (a queue of 64 per wave, below).
         const bool surf = alive && t_normal && ev_kind != PVT_EV_EXIT;
         bool flip = false;       // the normal is used flipped along the ray (nf = -nrm)
         double ddot = 0.0;       // nf . dir, before the clamp
@@ -1364,7 +1364,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
         const double c1 = ac_arg, s1 = fres ? sqrt1m2_normal(ac_arg) : 0.0;   // cos / sin of the incidence angle
 
-        PVT_MARK(4);  // acos + sincos
+        PVT_MARK(4);  // cosines of the incidence / exit angle
         if (surf) {
             // ---- Fresnel / coating decision at the surface (:865-895) ------------
             const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
