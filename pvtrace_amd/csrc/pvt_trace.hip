@@ -1005,6 +1005,9 @@ int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables*
     for (int g = 0; g < n_devices; g++)
         if (devices[g] < 0 || devices[g] >= ndev) return fail(PVT_ERR_NO_DEVICE, "no such HIP device in the device list");
     if (n_devices == 1) return pvt_trace_bundle(tables, emitter, rays, p, tl, log, devices[0], kernel_ms);
+    // the shards below own ONE tally set each (R / B / R*8 elements) and shard edges ignore bundle boundaries
+    if (p->tally_bundle > 0)
+        return fail(PVT_ERR_INVALID, "tally_bundle is not supported over a device list; trace the group on one device");
 
     const size_t R = (size_t)(tables->n_recorders > 0 ? tables->n_recorders : 1);
     const size_t B = (size_t)(tables->total_bins > 0 ? tables->total_bins : 1);

@@ -343,6 +343,8 @@ class Session:
 
         if emit_method not in EMIT_METHODS:
             raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
+        if tally_bundle and int(record_every) != 0:
+            raise ValueError("tally_bundle needs record_every == 0 (one tally set per bundle, no event log)")
         device, dscene = self.device, self.dscene
         with torch.cuda.device(device):
             if host_rays is not None:
@@ -401,6 +403,8 @@ class Session:
         host wall time around launch + completion when `wall_clock`."""
         import torch
 
+        if pending.get("tally_bundle"):
+            raise ValueError("this launch was submitted with tally_bundle: use collect_bundles() (one result per bundle)")
         with torch.cuda.device(self.device):
             pending["stream"].synchronize()
             wall = time.perf_counter() - pending["tic"]
@@ -451,6 +455,8 @@ class Session:
         """Trace one bundle -> `EngineResult` (submit + collect)."""
         import torch
 
+        if kwargs.get("tally_bundle"):
+            raise ValueError("run() returns ONE result; submit(..., tally_bundle=m) + collect_bundles() for a group")
         torch.cuda.synchronize(self.device)
         return self.collect(self.submit(num_rays, seed, **kwargs), wall_clock=True)
 
@@ -543,8 +549,10 @@ def _simulate_on_devices(scene, num_rays, seed, devices, maxsteps, max_events, e
 
     if not devices:
         raise ValueError("`devices` is empty")
-    sessions = [Session(scene, device=d, emission=emission) for d in devices]
+    sessions = []
     try:
+        for d in devices:   # one at a time: a failure on the k-th device must not leak the first k-1 resident scenes
+            sessions.append(Session(scene, device=d, emission=emission))
         host = None
         if sessions[0].emission == "host":   # the lights are sampled once, in the reference's global order
             host = emit_mod.emit_bundle(scene, num_rays, seed=emit_seed)
@@ -595,9 +603,8 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
     emission = kwargs.pop("emission", "auto")
     # one resident scene per GPU; bundle b goes to GPU b mod N, two bundles in flight per GPU, results are
     # yielded in bundle order
-    sessions = [Session(scene, device=d, emission=emission) for d in (devices if devices is not None else [device])]
-    if sessions[0].emission == "device" and emit_seed is None:
-        emit_seed = np.random.randint(0, 2 ** 31 - 1)
+    sessions = []
+    state = {"emit_seed": emit_seed}
 
     # Tally mode: a launch serves a GROUP of consecutive bundles (one tally set each), about a million
     # photons' worth -- a 50 000-photon bundle alone leaves most of an MI355X idle and pays the launch and
@@ -613,25 +620,29 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
         if session.emission == "device":
             # one emission stream for the whole job: ray i of the job is the same photon
             # whatever the bundle size
-            return session, session.submit(n, int(seed), emit_seed=emit_seed, ray_offset=base_offset + traced,
+            return session, session.submit(n, int(seed), emit_seed=state["emit_seed"], ray_offset=base_offset + traced,
                                            workgroups_per_cu=3, **group, **kwargs), n     # two launches in flight
         if per_group > 1:   # the lights are sampled bundle by bundle, in the reference's order, then traced together
             from pvtrace_amd.engine import emit as emit_mod
 
             parts = [emit_mod.emit_bundle(scene, min(bundle, n - at),
-                                          seed=None if emit_seed is None else int(emit_seed) + traced + at)
+                                          seed=None if state["emit_seed"] is None else int(state["emit_seed"]) + traced + at)
                      for at in range(0, n, bundle)]
             host = tuple(np.concatenate([p[k] for p in parts]) for k in range(3)) + ([x for p in parts for x in p[3]],)
             return session, session.submit(n, int(seed) + traced, ray_offset=base_offset, workgroups_per_cu=3,
                                            host_rays=host, **group, **kwargs), n
-        bundle_emit_seed = None if emit_seed is None else int(emit_seed) + traced
+        bundle_emit_seed = None if state["emit_seed"] is None else int(state["emit_seed"]) + traced
         return session, session.submit(n, int(seed) + traced, emit_seed=bundle_emit_seed, ray_offset=base_offset,
                                        workgroups_per_cu=3, **kwargs), n
 
     in_flight = collections.deque()
-    window = 2 * len(sessions)
     submitted, index, traced = 0, 0, 0
     try:
+        for d in (devices if devices is not None else [device]):   # inside the try: a failing k-th Session must not
+            sessions.append(Session(scene, device=d, emission=emission))   # leak the k-1 resident scenes before it
+        if sessions[0].emission == "device" and state["emit_seed"] is None:
+            state["emit_seed"] = np.random.randint(0, 2 ** 31 - 1)
+        window = 2 * len(sessions)
         while traced < num_rays or in_flight:
             # launches k+1 .. are traced while the consumer works on the bundles of launch k
             while submitted < num_rays and len(in_flight) < window:

@@ -439,8 +439,12 @@ class DeviceScene:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         if tally_bundle:
             need = -(-int(n_rays) // int(tally_bundle))
+            if record_every > 0:
+                raise ValueError("tally_bundle needs record_every == 0")
             if tallies.get("sets", 1) < need:
                 raise ValueError(f"{need} tally sets needed, the buffers hold {tallies.get('sets', 1)}")
+            if need > 1 and not ("stride_i64" in tallies and "stride_f64" in tallies):
+                raise ValueError("tally_bundle needs the buffers of new_tallies(sets=...) (stride_i64 / stride_f64)")
         params = trace_params(n_rays, seed, ray_offset, emit_seed, record_every, maxsteps,
                               max_events, emit_method, workgroups_per_cu, tally_bundle,
                               tallies.get("stride_i64", 0) if tally_bundle else 0,

@@ -26,6 +26,7 @@ class BundlePipeline:
             raise ValueError("reduce must be 'end' or 'bundle'")
         self.reduce = reduce
         self._reduced = False
+        self._unordered = set()   # streams whose totals were zero-filled on streams[0] by the last reduce_totals()
 
         self.torch = torch
         self.dscene = dscene
@@ -54,10 +55,15 @@ class BundlePipeline:
         torch = self.torch
         if self._reduced and self.distributed and self.reduce == "end":
             raise RuntimeError("totals already reduced over the ranks; call reset_totals() before submitting more bundles")
-        self._reduced = False
         k = self.submitted % self.depth
         self.submitted += 1
         stream, tallies, total = self.streams[k], self.slots[k], self.totals[k]
+        if k in self._unordered:
+            # reduce_totals() zero-filled totals[k] on streams[0]: this launch adds into that buffer from
+            # another stream and must be ordered after the zero-fill, or its tallies could be wiped
+            stream.wait_stream(self.streams[0])
+            self._unordered.discard(k)
+        self._reduced = False
         # The kernel ADDS its tallies to the buffers it is given (atomics, once per workgroup), so a bundle can be
         # traced straight into its stream's running totals: no zero-fill and no accumulate kernels per bundle.
         # Only per-bundle all-reduces need the bundle's own numbers.
@@ -103,6 +109,7 @@ class BundlePipeline:
             t["_sums"].zero_()
         self.events = []
         self._reduced = False
+        self._unordered = set()
         self.wait_for_inputs()   # the zero-fills ran on the current stream
 
     def reduce_totals(self):
@@ -121,6 +128,7 @@ class BundlePipeline:
                 self.totals[0]["_sums"] += t["_sums"]
                 t["_ints"].zero_()
                 t["_sums"].zero_()
+            self._unordered = set(range(1, self.depth))
             if self.distributed and self.reduce == "end":
                 from pvtrace_amd.engine.distributed import all_reduce_tallies
 

@@ -174,6 +174,39 @@ def make_lsc_tallies():
          rec_sums=ref["rec_sums"], rec_bins=ref["rec_bins"], **table_dump(compiled))
 
 
+# Reference-kernel tallies at 10^6 photons for the other configs the reference kernel can run
+# (VERDICT r2 #1): BASELINE configs[3] nested_cylinders (examples/nested_cylinders.py:21-64), configs[0]
+# hello_world and the reference's own benchmark slab (benchmarks/benchmark_engine.py:26-55), same recipe
+# as the headline file.  hello_world has no recorders in the example; whole-surface recorders are attached
+# here so that there is something to tally.
+TALLY_SCENES = {
+    "nested_cylinders": dict(scene="nested_cylinders", emit_seed=4104, seed=5, emit_method=0),
+    "hello_world": dict(scene="hello_world_recorded", emit_seed=4105, seed=6, emit_method=0),
+    "bench_slab": dict(scene="bench_slab_recorded", emit_seed=4106, seed=7, emit_method=1),
+}
+
+
+def make_config_tallies():
+    from oracle import oracle as O
+    from pvtrace_amd.engine import compile_scene
+    from pvtrace_amd.engine.emit import emit_bundle
+    from tests import scenes
+
+    for name, spec in TALLY_SCENES.items():
+        scene = scenes.TALLY_SCENES[spec["scene"]]()
+        compiled = compile_scene(scene)
+        n = 1_000_000
+        pos, dirs, wl, _ = emit_bundle(scene, n, seed=spec["emit_seed"])
+        ref = O.reference_trace_bundle(compiled, pos, dirs, wl, spec["seed"], 1000, 128, spec["emit_method"],
+                                       os.cpu_count(), 0)
+        checksum = np.array([pos.sum(), dirs.sum(), wl.sum(), np.abs(dirs).sum()])
+        save(f"tallies_{name}_1e6.npz", n=np.int64(n), emit_seed=np.int64(spec["emit_seed"]),
+             seed=np.int64(spec["seed"]), emit_method=np.int64(spec["emit_method"]),
+             input_checksum=checksum, recorder_names=np.array(compiled.recorder_names),
+             rec_distinct=ref["rec_distinct"], rec_crossings=ref["rec_crossings"],
+             rec_sums=ref["rec_sums"], rec_bins=ref["rec_bins"], **table_dump(compiled))
+
+
 def make_hist_spectra():
     """Histogram-sampled Distribution (hist=True) known answers from the reference class."""
     dist = ref_module("pvtrace.material.distribution")
@@ -196,6 +229,7 @@ if __name__ == "__main__":
     make_transforms()
     make_traces()
     make_lsc_tallies()
+    make_config_tallies()
     make_hist_spectra()
 
 

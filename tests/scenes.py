@@ -423,6 +423,26 @@ EXTENSION_SCENES = {   # need an extension: coatings, hist spectra, meshes
 ALL_SCENES = dict(REFERENCE_SCENES, **EXTENSION_SCENES)
 
 
+def hello_world_recorded():
+    """hello_world with whole-surface recorders on the ball and an exit recorder on the world (the example has
+    none; the 10^6-photon reference tallies need something to count)."""
+    scene = hello_world()
+    world = scene.root
+    ball = [n for n in world.children if n.geometry is not None][0]
+    ball.recorders = [Recorder("ball-entering", event="entering"), Recorder("ball-escaping", event="escaping"),
+                      Recorder("ball-reflected", event="reflected",
+                               histograms=[Histogram("angle", 0.0, np.pi / 2, 18)])]
+    world.recorders = [Recorder("exit", event="exit", histograms=[Histogram("angle", 0.0, np.pi / 2, 18)])]
+    return scene
+
+
+TALLY_SCENES = {   # reference-kernel tallies at 10^6 photons (tests/golden/tallies_<name>_1e6.npz)
+    "nested_cylinders": nested_cylinders,
+    "hello_world_recorded": hello_world_recorded,
+    "bench_slab_recorded": lambda: bench_slab(recorders=True),
+}
+
+
 def bose_fluro_red_sample(depth=0.26):
     """The FULLSPECTRUM validation sample (reference examples/Validation.ipynb cell 6 and
     tests/test_3D_flux_comparison.py:11-64): 4.8 x 1.8 x `depth` cm plate, Fluro Red dye

@@ -1,0 +1,88 @@
+"""BASELINE configs other than the headline, pinned to the REFERENCE kernel at 10^6 photons.
+
+tests/golden/tallies_{nested_cylinders,hello_world,bench_slab}_1e6.npz hold the reference kernel's own
+tallies (made by tests/golden/make_golden.py::make_config_tallies with the recipe of the headline file).
+The reference's scheme for engine statistics is tests/test_engine.py:139-166 (Welch comparison of per-ray
+means); north_star's bar is 3 sigma per recorder at 10^6 photons.
+
+* libm mode of the CPU referee reproduces every integer tally EXACTLY (same rays, same seeds).
+* portable mode -- the arithmetic the GPU runs, bit for bit -- stays within 3 sigma per recorder on the same
+  rays, and on independently seeded rays too.  nested_cylinders is the scene with the index-matched A/B
+  interface where ~0.7 % of the histories take a different course in portable arithmetic: this is
+  the at-size statistical check of that deviation.
+
+The GPU versions of these checks are in tests/test_gpu_full_size.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pvtrace_amd.engine import compile_scene
+from pvtrace_amd.engine.emit import emit_bundle
+from tests import scenes
+from tests.util import assert_same_tables, load_golden, three_sigma
+
+CONFIGS = {   # golden file stem -> scene builder in tests/scenes.py
+    "nested_cylinders": "nested_cylinders",
+    "hello_world": "hello_world_recorded",
+    "bench_slab": "bench_slab_recorded",
+}
+
+
+def golden_case(name):
+    g = load_golden(f"tallies_{name}_1e6.npz")
+    scene = scenes.TALLY_SCENES[CONFIGS[name]]()
+    compiled = compile_scene(scene)
+    assert_same_tables(compiled, g)
+    return g, scene, compiled
+
+
+def assert_within_three_sigma(got, n_got, g, what):
+    """Per recorder: distinct-ray fraction and crossings per ray within 3 sigma of the reference's, and the
+    per-ray means of wavelength / angle / duration / pathlength within 3 standard errors (Welch)."""
+    n_ref = int(g["n"])
+    for r, name in enumerate(g["recorder_names"]):
+        pa, pb = got["rec_distinct"][r] / n_got, g["rec_distinct"][r] / n_ref
+        assert abs(pa - pb) <= three_sigma(pa, pb, n_got, n_ref) + 1e-12, (what, str(name), pa, pb)
+        ka, kb = int(got["rec_distinct"][r]), int(g["rec_distinct"][r])
+        if min(ka, kb) < 1000:
+            continue
+        for q, prop in enumerate(("wavelength", "angle", "duration", "pathlength")):
+            ma, mb = got["rec_sums"][r, q, 0] / ka, g["rec_sums"][r, q, 0] / kb
+            va = max(got["rec_sums"][r, q, 1] / ka - ma * ma, 0.0)
+            vb = max(g["rec_sums"][r, q, 1] / kb - mb * mb, 0.0)
+            se = np.sqrt(va / ka + vb / kb)
+            assert abs(ma - mb) <= 3.0 * se + 1e-9 * max(abs(mb), 1e-30), (what, str(name), prop, ma, mb, se)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_libm_mode_reproduces_the_reference_tallies_exactly(name):
+    g, scene, compiled = golden_case(name)
+    n = int(g["n"])
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=int(g["emit_seed"]))
+    checksum = np.array([pos.sum(), dirs.sum(), wl.sum(), np.abs(dirs).sum()])
+    if not np.array_equal(checksum, g["input_checksum"]):
+        pytest.skip("numpy here samples the lights differently from the numpy that made the fixture")
+    libm = O.trace_bundle(compiled, pos, dirs, wl, int(g["seed"]), 1000, 128, int(g["emit_method"]), 8, 0,
+                          math_mode=O.MATH_LIBM)
+    for key in ("rec_distinct", "rec_crossings", "rec_bins"):
+        assert np.array_equal(libm[key], g[key]), (name, key)
+    assert np.allclose(libm["rec_sums"], g["rec_sums"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_portable_mode_within_three_sigma_of_the_reference(name):
+    g, scene, compiled = golden_case(name)
+    n = int(g["n"])
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=int(g["emit_seed"]))
+    port = O.trace_bundle(compiled, pos, dirs, wl, int(g["seed"]), 1000, 128, int(g["emit_method"]), 8, 0,
+                          math_mode=O.MATH_PORTABLE)
+    assert_within_three_sigma(port, n, g, name + " same rays")
+    # same rays, so in fact far closer than sampling noise: the histories that part ways are few
+    worst = np.abs(port["rec_distinct"].astype(np.int64) - g["rec_distinct"]).max()
+    assert worst <= {"nested_cylinders": 200}.get(name, 5), (name, int(worst))   # measured: 31 / 0 / 0
+    # independent photons (other light samples, other streams)
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=int(g["emit_seed"]) + 1000)
+    other = O.trace_bundle(compiled, pos, dirs, wl, int(g["seed"]) + 5_000_000, 1000, 128, int(g["emit_method"]),
+                           8, 0, math_mode=O.MATH_PORTABLE)
+    assert_within_three_sigma(other, n, g, name + " independent rays")
