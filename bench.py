@@ -1,7 +1,8 @@
 """Headline benchmark: photons/s on the 5x5x1 cm Lumogen-F-Red LSC (BASELINE.json
 configs[1]), one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                          # 1 GPU, default steps
+    python bench.py --gpus N                 # re-executes itself under torch.distributed.run with N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -16,17 +17,24 @@ convention (api.py:230-245 times only the trace).  With N>1 each rank traces its
 own 10^6-photon index range per step (weak scaling) and the tallies are summed
 with an RCCL all-reduce inside the timed region.
 
-Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` is
-for the trace kernel: achieved = 56 algorithmic bytes/photon x photons per launch
-/ mean launch duration (HIP events on the launch stream).  This path is NOT
-HBM-bound: the fraction is reported because the metric asks
-for it, next to instruction-side numbers that actually bound it.
+Rank 0 prints ONE JSON line; see the task contract for the fields.  `value` is the
+MEDIAN of `1 + --repeats` independent, identically fenced windows of --steps steps
+(`repeats` holds min / max / the first window).  `roofline` is for the trace kernel:
+achieved = 56 algorithmic bytes/photon x photons per launch / mean launch duration
+(HIP events on the launch stream).  This path is NOT HBM-bound (DESIGN.md
+§Roofline): the fraction is reported because the metric asks for it, next to the
+instruction-side numbers that actually bound it.  `configs` holds the same
+measurement for BASELINE configs[3] (nested_cylinders) and configs[4] (coated slab +
+scatterer) at 10^7 photons per GPU, pipelined, device-side emission.
 `cpu_baseline` times the CPU referee (a port of the reference kernel, proven
 bit-identical to it) on this box's host cores on a bounded sample.
 """
 import argparse
+import datetime
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,6 +57,21 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return cores
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """N ranks share the granted host cores: give each rank its own slice of the affinity mask (a submit loop is
+    one busy Python thread; eight of them must not migrate over each other).  Returns the slice."""
+    if not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    per = max(1, len(allowed) // local_world)
+    mine = allowed[(local_rank * per) % len(allowed):][:per] or allowed
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
 
 
 def cpu_baseline(compiled, pos, dirs, wl, budget_s=(9.0, 6.0)):
@@ -84,7 +107,7 @@ def cpu_baseline(compiled, pos, dirs, wl, budget_s=(9.0, 6.0)):
     }
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -99,8 +122,9 @@ def main():
                     help="distinct resident ray sets the steps rotate through (7 x 56 MB = 392 MB: past the "
                          "256 MiB Infinity Cache, so the ray stream of a step comes from HBM)")
     ap.add_argument("--repeats", type=int, default=15,
-                    help="extra, independent timed windows of --steps steps after the headline one (spread estimate)")
-    ap.add_argument("--sustained-s", type=float, default=1.2,
+                    help="extra, independent timed windows of --steps steps after the first one; `value` is the "
+                         "median of all of them")
+    ap.add_argument("--sustained-s", type=float, default=12.0,
                     help="length of the sustained leg (back-to-back bundles) in seconds of GPU work; 0 = skip")
     ap.add_argument("--total-photons", type=int, default=100_000_000,
                     help="strong-scaling leg (BASELINE configs[2]): ONE job of this many photons split over the "
@@ -108,139 +132,253 @@ def main():
     ap.add_argument("--reduce", choices=("end", "bundle"), default="end",
                     help="multi-GPU: all-reduce the tallies once per job, inside the timed region "
                          "(default), or after every bundle")
-    args = ap.parse_args()
+    ap.add_argument("--config", choices=("cfg2", "cfg4", "cfg5"), default="cfg2",
+                    help="scene of the main loop (developer flag for profiles; the contract's metric is cfg2). "
+                         "cfg4/cfg5 use device-side emission")
+    ap.add_argument("--extra-configs", default="cfg4,cfg5",
+                    help="comma list of further configs timed after the cfg2 legs ('none' = skip)")
+    ap.add_argument("--config-photons", type=int, default=10_000_000,
+                    help="photons per GPU per window of an extra config (BASELINE: 10^7)")
+    ap.add_argument("--rccl-timeout-s", type=float, default=180.0)
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU
+    (the driver's own launch line, with a free port on 127.0.0.1)."""
+    import __graft_entry__ as entry
+    from pvtrace_amd.engine import native
+
+    if not native.library_built():
+        entry.build()   # once, before N ranks would race to build it
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def load_pmc(name, value_per_gpu, cus):
+    """Instruction-side numbers of a config from the last committed PMC passes of this same command
+    (tools/gpu_pmc.sh -> profiles/pmc_summary[_cfgN].json), scaled by the measured rate."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json" if name == "cfg2" else f"pmc_summary_{name}.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        summary = json.load(open(path))
+        derived = summary.get("derived", {})
+        side = {
+            "source": os.path.relpath(path, ROOT) + " (" + str(summary.get("stage", "")) + ")",
+            "valu_wave_instructions_per_photon": derived.get("valu_wave_instructions_per_photon"),
+            "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
+            "wait_fraction_of_wave_cycles": derived.get("wait_any_fraction_of_wave_cycles"),
+            # measured with counters, for ONE launch of this shape alone (rocprofv3 serialises
+            # dispatches while sampling): 4*SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8)
+            "valu_busy_measured_single_launch": derived.get("valu_busy_measured"),
+        }
+        per_photon = derived.get("valu_wave_instructions_per_photon")
+        if per_photon:
+            # the operative ceiling: VALU issue.  Nominal: one wave64 FP64 instruction per SIMD every 4
+            # cycles at 2.4 GHz.  ACHIEVABLE on this part with the kernel's four waves per SIMD: a pure
+            # chain of v_fma_f64 issues one per 4.83-5.26 nominal cycles (tools/gpu_fma_peak.hip,
+            # profiles/r02_fma_peak.txt) -- the kernel is measured against both
+            nominal = cus * 4 * 2.4e9 / 4.0
+            achievable = cus * 4 * 4.85e8
+            rate = per_photon * value_per_gpu
+            side.update(valu_issue_rate_per_s=rate, valu_issue_peak_per_s=nominal, valu_issue_frac=rate / nominal,
+                        valu_issue_achievable_per_s=achievable, valu_issue_frac_of_achievable=rate / achievable)
+        return summary.get("hbm_bytes_per_launch"), side
+    except Exception:
+        return None, None
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
 
     import __graft_entry__ as entry
+    from benchmarks.configs import CONFIGS
     from pvtrace_amd.engine import compile_scene, native
+    from pvtrace_amd.engine.compiler import EMIT_METHODS
+    from pvtrace_amd.engine.emit import EmitterTables, emit_bundle
     from pvtrace_amd.engine.pipeline import BundlePipeline
-    from pvtrace_amd.engine.emit import emit_bundle
-    from tests import scenes
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    def die(msg):
+        if rank == 0:
+            print(json.dumps({"error": msg, "n_gpus": world}), flush=True)
+        sys.exit(msg)
+
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        die(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks (python bench.py --gpus N does it itself)")
+    cores_pinned = pin_rank_to_cores(local_rank, local_world)
     distributed = world > 1 or os.environ.get("PVT_BENCH_FORCE_DIST") == "1"  # (1-rank RCCL self-test)
     if not native.library_built():
         if world > 1:
-            sys.exit("libpvtrace_hip.so is not built; run __graft_entry__.build() once before a multi-rank launch")
+            die("libpvtrace_hip.so is not built; run __graft_entry__.build() once before a multi-rank launch")
         entry.build()
     if not native.is_available():
-        sys.exit("no MI355X visible: the engine has no CPU path (build ok, nothing to measure)")
-    local_rank %= torch.cuda.device_count()   # (self-test: several ranks on a 1-GPU box, gloo backend)
+        die("no MI355X visible: the engine has no CPU path (build ok, nothing to measure)")
+    backend = os.environ.get("PVT_BENCH_BACKEND", "nccl")   # nccl = RCCL on ROCm
+    n_devices = torch.cuda.device_count()
+    if distributed and backend == "nccl" and local_world > n_devices:
+        die(f"{local_world} ranks on {n_devices} visible GPU(s): RCCL needs one GPU per rank")
+    local_rank %= n_devices   # (self-test: several ranks on a 1-GPU box, gloo backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = None
     if distributed:
         import torch.distributed as dist
 
-        backend = os.environ.get("PVT_BENCH_BACKEND", "nccl")   # nccl = RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+        timeout = datetime.timedelta(seconds=args.rccl_timeout_s)
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=timeout)
+            else:
+                dist.init_process_group(backend=backend, timeout=timeout)
+            # a real collective before anything is timed: every rank contributes 1, the sum is what RCCL saw
+            ones = torch.ones(1, dtype=torch.int64, device=dev)
+            dist.all_reduce(ones)
+            torch.cuda.synchronize(dev)
+            rccl_ranks = int(ones.item())
+        except Exception as exc:   # noqa: BLE001 -- say WHICH step failed, on the one line the driver reads
+            die(f"process group ({backend}, {world} ranks) failed on rank {rank}: {type(exc).__name__}: {exc}")
+        if rccl_ranks != world:
+            die(f"all-reduce saw {rccl_ranks} ranks, expected {world}")
 
     n = args.photons
-    scene = scenes.lsc_equivalent()
-    compiled = compile_scene(scene)
-    # each rank's shard: global indices [rank*n, (rank+1)*n); emission seeded per shard and per buffer.
-    # The steps rotate through `--ray-buffers` distinct ray sets so that a step's input does not sit in
-    # the Infinity Cache from the previous step.
     nbuf = max(1, args.ray_buffers)
-    ray_sets = []
-    for b in range(nbuf):
-        p_, d_, w_, _ = emit_bundle(scene, n, seed=1000 + rank + 7919 * b)
-        if b == 0:
-            pos, dirs, wl = p_, d_, w_
-        ray_sets.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (p_, d_, w_)))
-    dscene = native.DeviceScene(compiled, device=local_rank)
-    # Steps are independent bundles; like any streaming consumer of the engine they go
-    # through the product's BundlePipeline (engine/pipeline.py): bundle k+1 is enqueued on a
-    # second HIP stream while bundle k drains, every bundle is fully traced and accumulated; the
-    # totals are summed over the ranks before the closing fence.  --streams 1 gives the strictly serial schedule.
-    pipe = BundlePipeline(dscene, depth=args.streams, distributed=distributed, reduce=args.reduce)
-    pipe.wait_for_inputs()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    tail_wide = int(os.environ.get("PVT_TAIL_WIDE", "1"))   # the last bundle of a window at full launch width
 
-    # the last bundle of a window is submitted as the job's tail (full launch width: +1 %, BundlePipeline.submit)
-    tail_wide = int(os.environ.get("PVT_TAIL_WIDE", "1"))
-
-    def step(k, timed, tail=False):
-        pipe.submit(ray_sets[k % nbuf], n, seed=12345 + k * world * n, ray_offset=rank * n, maxsteps=1000,
-                    max_events=128, emit_method=0, timed=timed, tail=tail)
-
-    def fence():
+    def fence(pipe):
         pipe.synchronize()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Clocks: an idle MI355X needs tens of milliseconds of work to reach its sustained clocks, far more
-    # than `--warmup` steps of ~0.5 ms provide; spin the same path up first (untimed, not counted).
-    # First uses first: the first timed launch (HIP events with timestamps) and the first full-width launch each
-    # stall the queue for tens of milliseconds once per process; paid here, BEFORE the clocks are spun up, so that
-    # the --warmup steps below run on a warm pipeline at sustained clocks like the timed ones.
-    if args.spinup_s > 0:
-        for k in range(max(2, tail_wide + 1)):
-            step(2_000_000 + k, True, tail=k >= 1)
-        pipe.reduce_totals()
-        pipe.synchronize()
-    t_spin = time.perf_counter()
-    k_spin = 0
-    while time.perf_counter() - t_spin < args.spinup_s:
-        for _ in range(20):
-            step(1_000_000 + k_spin, False)
-            k_spin += 1
-        pipe.synchronize()
-    for k in range(args.warmup):
-        step(k, True, tail=k >= args.warmup - tail_wide)   # same path as the timed steps (events and the tail launch included); reset below
-    pipe.reduce_totals()   # also warms the RCCL communicator up (its first collective is slow)
-    pipe.reset_totals()
-    fence()
-    tic = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k, True, tail=k >= args.steps - tail_wide)
-    pipe.reduce_totals()   # fold the streams' totals; RCCL all-reduce over the ranks (reduce="end")
-    fence()
-    elapsed = time.perf_counter() - tic
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = pipe.kernel_ms()
-    mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    totals = pipe.totals_host()
-
-    def window(first_step, steps, timed_events=False):
-        """One more independent window of `steps` steps, fenced like the headline one -> seconds (max over ranks)."""
-        pipe.reset_totals()
-        fence()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            step(first_step + k, timed_events, tail=k >= steps - tail_wide)
-        pipe.reduce_totals()
-        fence()
-        dt = time.perf_counter() - t0
+    def max_over_ranks(dt):
         if distributed:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
         return dt
 
+    class Leg:
+        """One config resident on this rank's GPU with its pipeline.  cfg2 is traced from rays resident in HBM
+        (array-input mode, the reference's three arrays); the other configs sample their lights on the device."""
+
+        def __init__(self, name, photons):
+            spec = CONFIGS[name]
+            self.name, self.spec, self.n = name, spec, photons
+            self.scene = spec["build"]()
+            self.compiled = compile_scene(self.scene)
+            self.method = EMIT_METHODS[spec["emit_method"]]
+            self.array_input = name == "cfg2"
+            self.ray_sets, self.host_rays = [None], None
+            if self.array_input:
+                # each rank's shard: global indices [rank*n, (rank+1)*n); emission seeded per shard and per
+                # buffer.  The steps rotate through `--ray-buffers` distinct ray sets so that a step's input
+                # does not sit in the Infinity Cache from the previous step.
+                self.ray_sets = []
+                for b in range(nbuf):
+                    p_, d_, w_, _ = emit_bundle(self.scene, photons, seed=1000 + rank + 7919 * b)
+                    if b == 0:
+                        self.host_rays = (p_, d_, w_)
+                    self.ray_sets.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (p_, d_, w_)))
+                self.dscene = native.DeviceScene(self.compiled, device=local_rank)
+            else:
+                self.dscene = native.DeviceScene(self.compiled, device=local_rank,
+                                                 emitter=EmitterTables(self.scene, strict=True))
+            # Steps are independent bundles; like any streaming consumer of the engine they go through the
+            # product's BundlePipeline (engine/pipeline.py): bundle k+1 is enqueued on another HIP stream while
+            # bundle k drains, every bundle is fully traced and accumulated; the totals are summed over the ranks
+            # before the closing fence.  --streams 1 gives the strictly serial schedule.
+            self.pipe = BundlePipeline(self.dscene, depth=args.streams, distributed=distributed, reduce=args.reduce)
+            self.pipe.wait_for_inputs()
+
+        def step(self, k, timed, tail=False, m=None, offset=None, seed=None):
+            m = self.n if m is None else m
+            rays = self.ray_sets[k % len(self.ray_sets)]
+            if rays is not None and m != self.n:
+                rays = tuple(t[:m] for t in rays)
+            self.pipe.submit(rays, m, seed=12345 + k * world * self.n if seed is None else seed,
+                             ray_offset=rank * self.n if offset is None else offset, emit_seed=4242 + k * world * self.n,
+                             maxsteps=1000, max_events=128, emit_method=self.method, timed=timed, tail=tail)
+
+        def window(self, first_step, steps, timed_events=False):
+            """One independent window of `steps` steps, fenced on both sides -> seconds (max over ranks)."""
+            self.pipe.reset_totals()
+            fence(self.pipe)
+            t0 = time.perf_counter()
+            for k in range(steps):
+                self.step(first_step + k, timed_events, tail=k >= steps - tail_wide)
+            self.pipe.reduce_totals()   # fold the streams' totals; RCCL all-reduce over the ranks (reduce="end")
+            fence(self.pipe)
+            return max_over_ranks(time.perf_counter() - t0)
+
+        def spin_up(self, seconds, warmup):
+            # Clocks: an idle MI355X needs tens of milliseconds of work to reach its sustained clocks, far more
+            # than `--warmup` steps of ~0.5 ms provide; spin the same path up first (untimed, not counted).
+            # First uses first: the first timed launch (HIP events with timestamps) and the first full-width
+            # launch each stall the queue for tens of milliseconds once per process; paid here, BEFORE the clocks
+            # are spun up, so that the --warmup steps run on a warm pipeline at sustained clocks like the timed ones.
+            if seconds > 0:
+                for k in range(max(2, tail_wide + 1)):
+                    self.step(2_000_000 + k, True, tail=k >= 1)
+                self.pipe.reduce_totals()
+                self.pipe.synchronize()
+            t_spin, k_spin = time.perf_counter(), 0
+            while time.perf_counter() - t_spin < seconds:
+                for _ in range(20):
+                    self.step(1_000_000 + k_spin, False)
+                    k_spin += 1
+                self.pipe.synchronize()
+            for k in range(warmup):   # same path as the timed steps (events and the tail launch included)
+                self.step(k, True, tail=k >= warmup - tail_wide)
+            self.pipe.reduce_totals()   # also warms the RCCL communicator up (its first collective is slow)
+
+        def fractions(self, photons):
+            totals = self.pipe.totals_host()
+            names = self.compiled.recorder_names
+            return {names[i]: float(totals["rec_distinct"][i]) / photons for i in range(len(names))}
+
+        def close(self):
+            self.dscene.close()
+
+    # ------------------------------------------------------------------ main loop (the contract's K steps)
+    leg = Leg(args.config, n)
+    leg.spin_up(args.spinup_s, args.warmup)
+    first_dt = leg.window(args.warmup, args.steps, timed_events=True)
+    kernel_ms = leg.pipe.kernel_ms()
+    mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    fractions = leg.fractions(n * world * args.steps)
+    launch = leg.dscene.launch_info()
     next_step = args.warmup + args.steps
-    repeat_values = []
-    for r in range(max(0, args.repeats)):
-        dt = window(next_step, args.steps)
+    window_dts = [first_dt]
+    for _ in range(max(0, args.repeats)):
+        window_dts.append(leg.window(next_step, args.steps))
         next_step += args.steps
-        repeat_values.append(n * world * args.steps / dt)
+    ordered = sorted(window_dts)
+    median_dt = ordered[(len(ordered) - 1) // 2]   # median (the slower of the two middle ones for an even count)
+    per_window = n * world * args.steps
+    value = per_window / median_dt
+
     sustained = None
     if args.sustained_s > 0:
-        est = elapsed / args.steps                      # seconds per step, from the headline window
-        sus_steps = max(args.steps, int(args.sustained_s / est))
-        dt = window(next_step, sus_steps)
+        sus_steps = max(args.steps, int(args.sustained_s / (median_dt / args.steps)))
+        dt = leg.window(next_step, sus_steps)
         next_step += sus_steps
         sustained = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt,
                      "value": n * world * sus_steps / dt}
@@ -252,70 +390,69 @@ def main():
         from pvtrace_amd.engine.distributed import shard_range
 
         lo, hi = shard_range(args.total_photons, rank, world)
-        pipe.reset_totals()
-        fence()
+        leg.pipe.reset_totals()
+        fence(leg.pipe)
         t0 = time.perf_counter()
         at, k = lo, 0
         while at < hi:
             m = min(n, hi - at)
-            pipe.submit(tuple(t[:m] for t in ray_sets[k % nbuf]), m, seed=777, ray_offset=at, maxsteps=1000,
-                        max_events=128, emit_method=0, timed=False, tail=at + m >= hi)
+            leg.step(k, False, tail=at + m >= hi, m=m, offset=at, seed=777)
             at += m
             k += 1
-        pipe.reduce_totals()
-        fence()
-        dt = time.perf_counter() - t0
-        if distributed:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        st = pipe.totals_host()
+        leg.pipe.reduce_totals()
+        fence(leg.pipe)
+        dt = max_over_ranks(time.perf_counter() - t0)
+        st = leg.pipe.totals_host()
+        names = list(leg.compiled.recorder_names)
+        tallied = None
+        if "entering" in names and "reflected" in names:
+            tallied = int(st["rec_distinct"][names.index("entering")] + st["rec_distinct"][names.index("reflected")])
         strong = {"scaling": "strong", "total_photons": args.total_photons, "seconds": dt,
-                  "value": args.total_photons / dt,
-                  "photons_tallied": int(st["rec_distinct"][list(compiled.recorder_names).index("entering")]
-                                         + st["rec_distinct"][list(compiled.recorder_names).index("reflected")])}
+                  "value": args.total_photons / dt, "photons_tallied": tallied}
+        if sustained is not None:
+            # What to expect at N GPUs: a rank traces total/(N n) bundles at the sustained step time, plus the part
+            # of a job that does not shrink with N -- the ramp and the drain of its last bundles, the fold of the
+            # streams' totals, the all-reduce and the fences -- measured here as what a --steps window costs beyond
+            # its steps at the sustained rate.
+            t_step = sustained["seconds"] / sustained["steps"]
+            t_fixed = max(median_dt - args.steps * t_step, 0.0)
+            bundles = args.total_photons / n
+            strong["predicted"] = {
+                "model": "T(N) = bundles/N * t_step + t_fixed; efficiency = T(1) / (N T(N))",
+                "t_step_ms": t_step * 1e3, "t_fixed_ms": t_fixed * 1e3,
+                "efficiency": {str(g): (bundles * t_step + t_fixed) / (g * (bundles / g * t_step + t_fixed))
+                               for g in (2, 4, 8)},
+            }
+
+    # ------------------------------------------------------------------ the other configs, same measurement
+    extra = {}
+    wanted = [c for c in args.extra_configs.split(",") if c and c != "none"] if args.config == "cfg2" else []
+    for name in wanted:
+        bundles = max(1, args.config_photons // n)
+        other = Leg(name, n)
+        other.spin_up(min(args.spinup_s, 0.1), 2)
+        dts, kms = [], []
+        for w in range(5):
+            dts.append(other.window(100 + w * bundles, bundles, timed_events=True))
+            kms += other.pipe.kernel_ms()
+        frac = other.fractions(n * world * bundles)
+        dts.sort()
+        photons = n * world * bundles
+        v = photons / dts[len(dts) // 2]
+        _, side = load_pmc(name, v / world, cus)
+        extra[name] = {
+            "workload": CONFIGS[name]["workload"], "photons_per_gpu": n * bundles, "bundles": bundles,
+            "emission": "device (in the trace kernel)", "bundles_in_flight": args.streams,
+            "value": v, "unit": "photons/s", "windows": len(dts), "min": photons / dts[-1], "max": photons / dts[0],
+            "ms_per_window": dts[len(dts) // 2] * 1e3, "kernel_ms_mean": sum(kms) / len(kms),
+            "launch": other.dscene.launch_info(), "instruction_side": side, "tallies": frac,
+        }
+        other.close()
 
     if rank == 0:
-        total_photons = n * world * args.steps
-        value = total_photons / elapsed
-        achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9
-        traffic, instruction_side = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):   # last committed PMC passes of this same command (tools/gpu_pmc.sh)
-            try:
-                summary = json.load(open(pmc))
-                traffic = summary.get("hbm_bytes_per_launch")
-                derived = summary.get("derived", {})
-                instruction_side = {
-                    "source": "profiles/pmc_summary.json (" + str(summary.get("stage", "")) + ")",
-                    "valu_wave_instructions_per_photon": derived.get("valu_wave_instructions_per_photon"),
-                    "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
-                    "wait_fraction_of_wave_cycles": derived.get("wait_any_fraction_of_wave_cycles"),
-                    # measured with counters, for ONE launch of this shape alone (rocprofv3 serialises
-                    # dispatches while sampling): 4*SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8)
-                    "valu_busy_measured_single_launch": derived.get("valu_busy_measured"),
-                }
-                per_photon = derived.get("valu_wave_instructions_per_photon")
-                if per_photon:
-                    # the operative ceiling: VALU issue.  Nominal: one wave64 FP64 instruction per SIMD every 4
-                    # cycles at 2.4 GHz.  ACHIEVABLE on this part with the kernel's four waves per SIMD: a pure
-                    # chain of v_fma_f64 issues one per 4.83-5.26 nominal cycles (tools/gpu_fma_peak.hip,
-                    # profiles/r02_fma_peak.txt) -- the kernel is measured against both
-                    cus = torch.cuda.get_device_properties(dev).multi_processor_count
-                    nominal = cus * 4 * 2.4e9 / 4.0
-                    achievable = cus * 4 * 4.85e8          # wave-FMA/s/SIMD at 4 waves x 4 chains: 4.73e8 and 4.96e8 on two boxes
-                    rate = per_photon * value / world
-                    instruction_side["valu_issue_rate_per_s"] = rate
-                    instruction_side["valu_issue_peak_per_s"] = nominal
-                    instruction_side["valu_issue_frac"] = rate / nominal
-                    instruction_side["valu_issue_achievable_per_s"] = achievable
-                    instruction_side["valu_issue_frac_of_achievable"] = rate / achievable
-            except Exception:
-                traffic = None
-        nrec = compiled.rec_node.shape[0]
-        distinct = totals["rec_distinct"]
-        names = compiled.recorder_names
-        fractions = {names[i]: float(distinct[i]) / total_photons for i in range(nrec)}
+        achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9 if leg.array_input else 0.0
+        traffic, instruction_side = load_pmc(args.config, value / world, cus)
+        rates = [per_window / d for d in window_dts]
         out = {
             "metric": "photons/sec on 5x5x1 cm Lumogen-F-Red LSC",
             "value": value,
@@ -323,51 +460,58 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": median_dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: 5x5x1 cm LSC-equivalent scene, Lumogen F Red 305 "
-                            "(10 cm^-1 peak, qy 1) + 0.1 cm^-1 background, 20-degree cone @555 nm, "
-                            "10 recorders, record_every=0, emit_method=kT, maxsteps=1000",
+                "workload": CONFIGS[args.config]["workload"],
+                "scene_builder": "pvtrace_amd.LSC((5,5,1)) + engine.instrument.face_recorders() (benchmarks/configs.py)"
+                                 if args.config == "cfg2" else "benchmarks/configs.py",
                 "photons_per_gpu_per_step": n,
-                "sharding": (f"index-range x{world}, tallies {'RCCL' if os.environ.get('PVT_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['PVT_BENCH_BACKEND']} all-reduce "
-                             + ("once per job, inside the timed region" if args.reduce == "end" else "per step")) if distributed
-                            else "single GPU",
-                "input": f"rays resident in HBM (array-input mode, 56 B/photon), steps rotate through {nbuf} distinct "
-                         f"ray sets ({nbuf * 56 * n / 1e6:.0f} MB)",
+                "sharding": (f"index-range x{world}, tallies {'RCCL' if backend == 'nccl' else backend} all-reduce "
+                             + ("once per job, inside the timed region" if args.reduce == "end" else "per step"))
+                            if distributed else "single GPU",
+                "input": (f"rays resident in HBM (array-input mode, 56 B/photon), steps rotate through {nbuf} distinct "
+                          f"ray sets ({nbuf * 56 * n / 1e6:.0f} MB)") if leg.array_input
+                         else "device-side emission inside the trace kernel (0 B/photon in)",
                 "bundles_in_flight": args.streams,
+                "value_is": f"median of {len(window_dts)} fenced windows of {args.steps} steps",
             },
+            "rccl_ranks": rccl_ranks,
+            "host": {"usable_cores": usable_cores(), "cores_of_rank0": cores_pinned},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "trace_kernel_w4<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=0> (pvt_trace_kernel.h trace_body, MESH=0)",
+                "kernel": "trace_kernel_w4<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=%d> (pvt_trace_kernel.h trace_body, MESH=0)"
+                          % (0 if leg.array_input else 1),
                 "kernel_ms_mean": mean_kernel_ms,
                 "instruction_side": instruction_side,
                 "kernel_photons_per_s": n / (mean_kernel_ms * 1e-3),
-                "achieved_at_step_rate": ALGORITHMIC_BYTES_PER_PHOTON * n * args.steps / elapsed / 1e9,
+                "achieved_at_step_rate": (ALGORITHMIC_BYTES_PER_PHOTON if leg.array_input else 0) * per_window / world
+                                         / median_dt / 1e9,
                 "note": "not HBM-bound: 56 algorithmic B/photon; the loop is FP64-VALU/latency/"
                         "divergence-bound (DESIGN.md). kernel_ms_mean is per launch (HIP events on the "
-                        "launch's own stream); with several bundles in flight launches overlap, so "
+                        "launch's own stream, first window); with several bundles in flight launches overlap, so "
                         "ms_per_step < kernel_ms_mean",
             },
-            "launch": dscene.launch_info(),
+            "launch": launch,
             "tallies": fractions,
+            "repeats": {"windows": len(rates), "steps_each": args.steps, "min": min(rates), "median": value,
+                        "max": max(rates), "first_window": rates[0], "spread": (max(rates) - min(rates)) / value},
         }
-        if repeat_values:
-            rv = sorted(repeat_values + [value])
-            out["repeats"] = {"windows": len(rv), "steps_each": args.steps, "min": rv[0], "median": rv[len(rv) // 2],
-                              "max": rv[-1], "spread": (rv[-1] - rv[0]) / rv[len(rv) // 2]}
         if sustained is not None:
             out["sustained"] = sustained
         if strong is not None:
             out["strong_scaling"] = strong
-        if not args.no_cpu_baseline and world == 1:   # the CPU referee is timed at N=1 only
-            out["cpu_baseline"] = cpu_baseline(compiled, pos, dirs, wl)
-        print(json.dumps(out))
+        if extra:
+            out["configs"] = extra
+        if not args.no_cpu_baseline and world == 1 and leg.array_input:   # the CPU referee is timed at N=1 only
+            out["cpu_baseline"] = cpu_baseline(leg.compiled, *leg.host_rays)
+        print(json.dumps(out), flush=True)
+    leg.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

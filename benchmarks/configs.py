@@ -1,0 +1,79 @@
+"""The BASELINE.json configurations as scenes, built with the product's own API (nothing from tests/).
+
+* cfg2 / cfg3: ``LSC((5, 5, 1))`` -- the library's LSC builder (reference pvtrace/device/lsc.py:95-219:
+  500x500x100 cm world, 5x5x1 cm n = 1.5 slab with Lumogen F Red 305 at 10 cm^-1 peak, qy 1, plus 0.1 cm^-1
+  background, point light at (0, 0, 5) facing down, 20-degree cone, 555 nm) carrying the tally set of
+  SURVEY.md §8(d) (`engine.instrument.face_recorders`).
+* cfg4: reference examples/nested_cylinders.py:21-64 (two glass cylinders, the child rotated and protruding from
+  its parent, in a 10 cm air sphere; 30-degree cone from z = -1).
+* cfg5: reference examples/006 Coatings.ipynb cell 5 (10x10x1 cm slab, perfect mirror on the x>0, y>0 quadrant of
+  the top face, 5x5 rectangular source above it) plus an isotropic 1 cm^-1 scatterer (qy 1) in the slab.
+"""
+import functools
+
+import numpy as np
+
+from pvtrace_amd import (
+    LSC, Box, Coating, CoatedSurfaceDelegate, Cylinder, Light, Material, Node, Scatterer, Scene, Sphere,
+    Surface, cone, rectangular_mask,
+)
+from pvtrace_amd.engine import Heatmap, Histogram, Recorder
+from pvtrace_amd.engine.instrument import face_recorders
+
+
+def cfg2_lsc():
+    lsc = LSC((5.0, 5.0, 1.0))
+    scene = lsc.scene
+    slab = next(n for n in scene.root.children if n.name == "LSC")
+    slab.recorders = face_recorders()
+    return scene
+
+
+def cfg4_nested_cylinders():
+    world = Node(name="World", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    a = Node(name="A", parent=world,
+             geometry=Cylinder(length=2, radius=0.5, material=Material(refractive_index=1.5)))
+    a.translate((0, 0, 2))
+    a.rotate(np.pi * 0.2, (0, 1, 0))
+    b = Node(name="B", parent=a,
+             geometry=Cylinder(length=2.0, radius=0.4, material=Material(refractive_index=1.5)))
+    b.rotate(np.pi / 2, (1, 0, 0))
+    light = Node(name="Light (555nm)", parent=world,
+                 light=Light(direction=functools.partial(cone, np.radians(30)), name="Light (555nm)"))
+    light.translate((0, 0, -1))
+    a.recorders = [Recorder("A-escaping", event="escaping"), Recorder("A-entering", event="entering")]
+    b.recorders = [Recorder("B-escaping", event="escaping"), Recorder("B-entering", event="entering")]
+    world.recorders = [Recorder("exit", event="exit", histograms=[Histogram("angle", 0.0, np.pi / 2, 18)])]
+    return Scene(world)
+
+
+def cfg5_coated_slab(scatter=1.0):
+    world = Node(name="world (air)", geometry=Box((15.0, 15.0, 15.0), material=Material(refractive_index=1.0)))
+    mirror = Coating((0, 0, 1), reflectivity=1.0, region=((0.0, None), (0.0, None), None))
+    slab = Node(
+        name="box (glass)", parent=world,
+        geometry=Box((10.0, 10.0, 1.0),
+                     material=Material(refractive_index=1.5, components=[Scatterer(float(scatter), name="Scatterer")],
+                                       surface=Surface(delegate=CoatedSurfaceDelegate([mirror])))))
+    slab.recorders = face_recorders(wavelength=None) + [
+        Recorder("top-reflect-map", event="reflected", facet=(0, 0, 1),
+                 histograms=[Heatmap("x", "y", (-5, 5, 20), (-5, 5, 20))])]
+    light = Node(name="Light", parent=world,
+                 light=Light(position=functools.partial(rectangular_mask, 5, 5), name="Light"))
+    light.location = (0, 0, 2)
+    light.rotate(np.radians(180), (1, 0, 0))
+    return Scene(world)
+
+
+CONFIGS = {
+    "cfg2": dict(build=cfg2_lsc, emit_method="kT",
+                 workload="BASELINE configs[1]: 5x5x1 cm LSC((5,5,1)), Lumogen F Red 305 (10 cm^-1 peak, qy 1) + "
+                          "0.1 cm^-1 background, 20-degree cone @555 nm, 10 recorders, record_every=0, "
+                          "emit_method=kT, maxsteps=1000"),
+    "cfg4": dict(build=cfg4_nested_cylinders, emit_method="kT",
+                 workload="BASELINE configs[3]: nested_cylinders (two rotated glass cylinders in a 10 cm air sphere, "
+                          "30-degree cone), 5 recorders incl. world exit, record_every=0"),
+    "cfg5": dict(build=cfg5_coated_slab, emit_method="kT",
+                 workload="BASELINE configs[4]: 10x10x1 cm slab, mirror coating on a quadrant of the top face + "
+                          "1 cm^-1 isotropic scatterer, 5x5 cm rectangular source, 11 recorders, record_every=0"),
+}

@@ -38,6 +38,22 @@ def auto_recorders(node):
     return recs
 
 
+def face_recorders(prefix="", wavelength=(400, 800, 80)):
+    """The tally set of the headline benchmark: one `escaping` recorder per box face
+    (top/bottom = +-z, right/left = +-x, far/near = +-y) with a wavelength histogram (`wavelength` =
+    (start, stop, bins), None for no histogram), then `lost`, `entering`, `reflected` and `killed` for the
+    whole node.  Attach the list to a Box node: ``node.recorders = face_recorders()``."""
+    faces = (("top", (0, 0, 1)), ("bottom", (0, 0, -1)), ("right", (1, 0, 0)), ("left", (-1, 0, 0)),
+             ("far", (0, 1, 0)), ("near", (0, -1, 0)))
+    recs = []
+    for label, normal in faces:
+        hs = [Histogram("wavelength", *wavelength)] if wavelength else []
+        recs.append(Recorder(f"{prefix}{label}", event="escaping", facet=normal, histograms=hs))
+    recs += [Recorder(f"{prefix}lost", event="lost"), Recorder(f"{prefix}entering", event="entering"),
+             Recorder(f"{prefix}reflected", event="reflected"), Recorder(f"{prefix}killed", event="killed")]
+    return recs
+
+
 def instrument(node, explicit=()):
     """Attach `auto_recorders(node)` to `node`; recorders in `explicit` with the same
     name take precedence (as explicit spec entries do in the reference)."""

@@ -1,13 +1,15 @@
 #!/bin/bash
 # PMC passes for the bench's trace kernel (each counter set in its own run, with --kernel-trace only, as the
-# pool rules require).  usage: tools/gpu_pmc.sh [pipelined|serial]   Outputs -> gpurun_out/pmc_<mode>_*/
+# pool rules require).  usage: tools/gpu_pmc.sh [pipelined|serial] [cfg2|cfg4|cfg5]   Outputs -> gpurun_out/pmc_<mode>[_cfgN]_*/
 # "pipelined" is the bench's default configuration (3 bundles in flight, 2 workgroups per CU per launch);
 # "serial" is --streams 1 (4 workgroups per CU).  NB rocprofv3 serialises dispatches while it samples
 # counters, so the pipelined passes measure the pipelined LAUNCH SHAPE, one launch at a time.
 set -x
 mode=${1:-pipelined}
-flags="--gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2"
+cfg=${2:-cfg2}
+flags="--gpus 1 --steps 6 --warmup 1 --no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2 --extra-configs none --config $cfg"
 [ "$mode" = serial ] && flags="$flags --streams 1"
+[ "$cfg" != cfg2 ] && mode=${mode}_$cfg
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out

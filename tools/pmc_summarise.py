@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 stage = sys.argv[2] if len(sys.argv) > 2 else ""
 mode = sys.argv[3] if len(sys.argv) > 3 else "pipelined"
+cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+if cfg != "cfg2":
+    mode = f"{mode}_{cfg}"
 photons = 1_000_000
 sums = collections.defaultdict(list)
 kernel = None
@@ -26,17 +29,17 @@ c = dict(sums)
 read_b = c["FETCH_SIZE"] * 1024 * 2
 write_b = c["WRITE_SIZE"] * 1024
 out = {
-    "round": 2, "stage": stage, "mode": mode,
+    "round": 3, "stage": stage, "mode": mode, "config": cfg,
     "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --gpus 1 --steps 6 --warmup 1 "
-               "--no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2"
-               + (" --streams 1" if mode == "serial" else "") + " (one counter set per run; tools/gpu_pmc.sh " + mode + "); "
+               "--no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2 --extra-configs none --config " + cfg
+               + (" --streams 1" if mode.startswith("serial") else "") + " (one counter set per run; tools/gpu_pmc.sh " + mode.split("_")[0] + " " + cfg + "); "
                "rocprofv3 serialises dispatches while sampling counters",
     "kernel": kernel, "photons_per_launch": photons, "counters_mean_per_launch": c,
     "hbm_read_bytes_per_launch_corrected": read_b, "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
     "correction": "FETCH_SIZE doubled: gfx950 rocprofv3 reports 1/2 of a wide coalesced read stream "
                   "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as is",
-    "algorithmic_bytes_per_launch": 56 * photons,
+    "algorithmic_bytes_per_launch": (56 if cfg == "cfg2" else 0) * photons,
     "derived": {
         "valu_lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) if "SQ_ACTIVE_INST_VALU" in c else None,
         "valu_wave_instructions_per_photon": c.get("SQ_INSTS_VALU", 0) / photons,
@@ -53,7 +56,8 @@ out = {
         "vmem_instructions_per_wave": c.get("SQ_INSTS_VMEM", 0) / c["SQ_WAVES"],
     },
 }
-for name in ((f"{tag}_pmc_summary.json", "pmc_summary.json") if mode == "pipelined" else (f"{tag}_pmc_summary.json",)):
+live = {"pipelined": "pmc_summary.json"}.get(mode, f"pmc_summary_{cfg}.json" if mode == f"pipelined_{cfg}" else None)
+for name in ((f"{tag}_pmc_summary.json", live) if live else (f"{tag}_pmc_summary.json",)):
     with open(os.path.join(ROOT, "profiles", name), "w") as fp:
         json.dump(out, fp, indent=1)
 print(json.dumps(out["derived"], indent=1), out["hbm_bytes_per_launch"])
