@@ -93,6 +93,11 @@ struct PvtScene {
                                         // different streams may overlap, each needs its own
     std::mutex slot_mutex;              // launches on one stream are ordered and may share a cursor;
     std::vector<hipStream_t> slot_of;   // index = cursor slot owned by that stream
+    // pvt_trace_device with column arrays: the kernel's 128-byte event records are staged here (one buffer per
+    // stream slot, grown on demand, at most `stage_limit` bytes: larger logs are traced in several launches)
+    std::vector<unsigned long long*> stage;
+    std::vector<size_t> stage_bytes;
+    size_t stage_limit = (size_t)8 << 30;
     int num_cu = 0;
     int last_grid = 0, last_lds = 0;
     size_t lds_limit = 0;
@@ -517,6 +522,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->lds_limit = prop.sharedMemPerBlock;
     s->consolidate = getenv("PVT_NO_CONSOLIDATE") == nullptr;
     if (const char* env = getenv("PVT_BLOCKS_PER_CU")) s->dev_blocks_per_cu = atof(env);
+    if (const char* env = getenv("PVT_STAGE_BYTES")) s->stage_limit = (size_t)atoll(env);   // (tests: force several launches)
     HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
     HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
@@ -576,6 +582,7 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_set_cursor) (void)hipFree(s->d_set_cursor);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->d_tris) (void)hipFree(s->d_tris);
+    for (auto* b : s->stage) if (b) (void)hipFree(b);
     delete s;
 }
 
@@ -633,25 +640,47 @@ hipError_t launch_seen(int n_rec, bool emit, int grid, size_t lds, hipStream_t s
 
 extern "C" {
 
-int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
-                     const PvtEventLog* log, void* stream) {
+}  // extern "C"
+
+namespace {
+
+// cursor / staging slot of a stream (launches on one stream are ordered and share it)
+int slot_of_stream(PvtScene* s, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(s->slot_mutex);
+    size_t slot = 0;
+    while (slot < s->slot_of.size() && s->slot_of[slot] != st) slot++;
+    if (slot == s->slot_of.size()) {
+        if (slot >= (size_t)kCursorSlots) return -1;
+        s->slot_of.push_back(st);
+        s->stage.push_back(nullptr);
+        s->stage_bytes.push_back(0);
+    }
+    return (int)slot;
+}
+
+int check_trace_args(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl) {
     if (!s || !p || !tl) return fail(PVT_ERR_INVALID, "null argument");
     if (p->n_rays < 0 || p->n_rays > 0x7fffffffLL)
         return fail(PVT_ERR_INVALID, "n_rays must fit in 31 bits per bundle");
     if (p->max_events < 2 && p->record_every > 0) return fail(PVT_ERR_INVALID, "max_events must be >= 2");
     if (!rays && !s->d_ed) return fail(PVT_ERR_INVALID, "no rays and no emitter");
-    if (p->record_every > 0 && !log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+    if (p->tally_bundle > 0 && p->record_every > 0) return fail(PVT_ERR_INVALID, "tally_bundle needs record_every == 0");
+    return PVT_OK;
+}
+
+// Enqueue ONE trace kernel.  `log_rows` / `log_counts`: the event records of the recorded rays (device memory,
+// null when record_every == 0); counts are cleared here.
+int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
+                 unsigned long long* log_rows, int* log_counts, hipStream_t st) {
     if (p->n_rays == 0) return PVT_OK;
     long long n_sets = 0;
     if (p->tally_bundle > 0) {
-        if (p->record_every > 0) return fail(PVT_ERR_INVALID, "tally_bundle needs record_every == 0");
         n_sets = (p->n_rays + p->tally_bundle - 1) / p->tally_bundle;
         if (p->tally_bundle > 0x7fffffffLL || n_sets > kMaxSets)
             return fail(PVT_ERR_INVALID, "at most 1024 tally sets per launch");
         if (p->tally_stride_i64 < 0 || p->tally_stride_f64 < 0) return fail(PVT_ERR_INVALID, "negative tally stride");
     }
     HIP_TRY(hipSetDevice(s->device));
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
     KArgs a = base_args(s, p);
     if (rays) { a.pos = rays->position; a.dir = rays->direction; a.wl = rays->wavelength; }
@@ -665,34 +694,16 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     a.fuse_exit = (a.lazy_root && s->fuse_exit) ? 1 : 0;
     a.lazy_k = s->lazy_k;
     if (record) {
-        a.log = *log;
+        if (!log_rows || !log_counts) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+        a.log_rows = log_rows;
+        a.log_counts = log_counts;
         const size_t nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
-        const size_t rows = nrec * (size_t)p->max_events;
-        HIP_TRY(hipMemsetAsync(log->counts, 0, nrec * 4, st));
-        if (!(p->flags & PVT_FLAG_NO_LOG_PREFILL)) {
-        HIP_TRY(hipMemsetAsync(log->kind, 0, rows, st));
-        HIP_TRY(hipMemsetAsync(log->hit, 0xFF, rows * 4, st));
-        HIP_TRY(hipMemsetAsync(log->container, 0xFF, rows * 4, st));
-        HIP_TRY(hipMemsetAsync(log->adjacent, 0xFF, rows * 4, st));
-        HIP_TRY(hipMemsetAsync(log->component, 0xFF, rows * 4, st));
-        HIP_TRY(hipMemsetAsync(log->source, 0xFF, rows * 4, st));
-        HIP_TRY(hipMemsetAsync(log->position, 0, rows * 24, st));
-        HIP_TRY(hipMemsetAsync(log->direction, 0, rows * 24, st));
-        HIP_TRY(hipMemsetAsync(log->normal, 0, rows * 24, st));
-        HIP_TRY(hipMemsetAsync(log->wavelength, 0, rows * 8, st));
-        HIP_TRY(hipMemsetAsync(log->travelled, 0, rows * 8, st));
-        HIP_TRY(hipMemsetAsync(log->duration, 0, rows * 8, st));
-        }
+        HIP_TRY(hipMemsetAsync(log_counts, 0, nrec * 4, st));
     }
     {   // the cursor belongs to the stream: two launches can only overlap on different streams
-        std::lock_guard<std::mutex> lock(s->slot_mutex);
-        size_t slot = 0;
-        while (slot < s->slot_of.size() && s->slot_of[slot] != st) slot++;
-        if (slot == s->slot_of.size()) {
-            if (slot >= (size_t)kCursorSlots)
-                return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
-            s->slot_of.push_back(st);
-        }
+        const int slot = slot_of_stream(s, st);
+        if (slot < 0)
+            return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
         a.cursor = n_sets ? s->d_set_cursor + (size_t)kMaxSets * slot : s->d_cursor + 16 * slot;
     }
     HIP_TRY(hipMemsetAsync(a.cursor, 0, n_sets ? (size_t)n_sets * 4 : (PVT_STATS ? 256 : 4), st));
@@ -774,6 +785,92 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
                 c[17] / bi, c[18] / bi, c[19] / bi, c[20] / bi, c[21] / bi, c[22] / bi, c[23] / bi);
     }
 #endif
+    return PVT_OK;
+}
+
+int unpack_launch(const unsigned long long* rows, const int* counts, long long n_recorded, int max_events,
+                  const PvtEventLog* out, bool prefill, hipStream_t st) {
+    if (n_recorded <= 0) return PVT_OK;
+    const int rays_per_block = max_events >= kBlock ? 1 : kBlock / max_events;
+    const long long gx = (n_recorded + rays_per_block - 1) / rays_per_block;
+    const int gy = rays_per_block > 1 ? 1 : (max_events + kBlock - 1) / kBlock;
+    if (gx > 0x7fffffffLL) return fail(PVT_ERR_INVALID, "too many recorded rays for one unpack launch");
+    hipLaunchKernelGGL(unpack_log_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, st, rows, counts, *out,
+                       n_recorded, max_events, rays_per_block, prefill ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("unpack_log_kernel launch: ") + hipGetErrorString(e));
+    return PVT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pvt_trace_device_records(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
+                             const PvtEventRecords* rec, void* stream) {
+    int rc = check_trace_args(s, rays, p, tl);
+    if (rc != PVT_OK) return rc;
+    if (p->record_every > 0 && (!rec || !rec->rows || !rec->counts))
+        return fail(PVT_ERR_INVALID, "record_every > 0 needs event records");
+    return trace_launch(s, rays, p, tl, rec ? reinterpret_cast<unsigned long long*>(rec->rows) : nullptr, rec ? rec->counts : nullptr,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+int pvt_unpack_records_device(const PvtEventRecords* rec, int64_t n_recorded, int32_t max_events,
+                              const PvtEventLog* out, int prefill, void* stream) {
+    if (!rec || !out || !rec->rows || !rec->counts || n_recorded < 0 || max_events < 1)
+        return fail(PVT_ERR_INVALID, "bad unpack arguments");
+    return unpack_launch(reinterpret_cast<const unsigned long long*>(rec->rows), rec->counts, n_recorded, max_events, out, prefill != 0,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
+// Column arrays on the device: the records are staged in a buffer of the scene (one per stream) and unpacked by
+// a second kernel, which also writes the reference's fill values into the rows no event reached.  A log too
+// large for the staging limit is traced in several launches over consecutive ray ranges (each a multiple of
+// record_every, so the rows and RNG streams are those of the single launch).
+int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
+                     const PvtEventLog* log, void* stream) {
+    int rc = check_trace_args(s, rays, p, tl);
+    if (rc != PVT_OK) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p->record_every <= 0) return trace_launch(s, rays, p, tl, nullptr, nullptr, st);
+    if (!log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+    if (p->n_rays == 0) return PVT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    const int slot = slot_of_stream(s, st);
+    if (slot < 0) return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
+    const long long every = p->record_every, me = p->max_events;
+    const long long nrec = (p->n_rays + every - 1) / every;
+    const size_t row_bytes = (size_t)kRecWords * 8;
+    // recorded rays per launch under the staging limit
+    long long per_launch = (long long)(s->stage_limit / (row_bytes * (size_t)me));
+    if (per_launch < 1) per_launch = 1;
+    if (per_launch > nrec) per_launch = nrec;
+    const size_t need = (size_t)per_launch * (size_t)me * row_bytes;
+    if (s->stage_bytes[slot] < need) {
+        // (a stream-ordered free would do; growth is rare and the buffer may still be read by an unpack in flight)
+        if (s->stage[slot]) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(s->stage[slot]); s->stage[slot] = nullptr; s->stage_bytes[slot] = 0; }
+        HIP_TRY(hipMalloc(&s->stage[slot], need));
+        s->stage_bytes[slot] = need;
+    }
+    const bool prefill = !(p->flags & PVT_FLAG_NO_LOG_PREFILL);
+    for (long long j0 = 0; j0 < nrec; j0 += per_launch) {
+        const long long j1 = j0 + per_launch < nrec ? j0 + per_launch : nrec;
+        const long long r0 = j0 * every, r1 = j1 * every < p->n_rays ? j1 * every : p->n_rays;
+        PvtTraceParams q = *p;
+        q.n_rays = r1 - r0;
+        q.ray_offset = p->ray_offset + (uint64_t)r0;
+        PvtRays sub{};
+        if (rays) sub = PvtRays{rays->position + 3 * r0, rays->direction + 3 * r0, rays->wavelength + r0};
+        rc = trace_launch(s, rays ? &sub : nullptr, &q, tl, s->stage[slot], log->counts + j0, st);
+        if (rc != PVT_OK) return rc;
+        const long long row0 = j0 * me;
+        PvtEventLog out{log->counts + j0, log->kind + row0, log->hit + row0, log->container + row0, log->adjacent + row0,
+                        log->component + row0, log->source + row0, log->position + 3 * row0, log->direction + 3 * row0,
+                        log->normal + 3 * row0, log->wavelength + row0, log->travelled + row0, log->duration + row0};
+        rc = unpack_launch(s->stage[slot], log->counts + j0, j1 - j0, (int)me, &out, prefill, st);
+        if (rc != PVT_OK) return rc;
+    }
     return PVT_OK;
 }
 

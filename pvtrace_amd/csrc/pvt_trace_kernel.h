@@ -93,7 +93,11 @@ struct KArgs {
     long long* rec_crossings;
     double* rec_sums;
     long long* rec_bins;
-    PvtEventLog log;
+    // event log of the recorded rays: one 128-byte RECORD per event (see log_row), record of event k of recorded
+    // ray j at row j*max_events + k; log_counts[j] = events written.  The reference's column arrays are made from
+    // these by unpack_log_kernel.
+    unsigned long long* log_rows;
+    int* log_counts;
     // tally sets (0 = the launch is one bundle): rays [j*set_size, (j+1)*set_size) are bundle j of a stream of
     // equal bundles; a workgroup serves ONE set (its own ray cursor, its own slice of the tally arrays)
     unsigned int set_size;
@@ -459,6 +463,21 @@ __global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, d
 }
 
 // ----------------------------------------------------------- event log
+// One event = one 128-byte record = one cache line, written by its lane with eight 16-byte stores:
+//   words (u64)  0: hit | container<<32   1: adjacent | component<<32   2: source | kind<<32
+//                3-5 position   6-8 direction   9-11 normal (zeros when the event has none)
+//                12 wavelength  13 travelled  14 duration  15 row index (j*max_events + k)
+// The reference keeps thirteen column arrays indexed [ray][event] (_kernel.pyx:562-597, :1035-1047); written
+// from 64 lanes that follow 64 different rays, every 1-, 4-, 8- and 24-byte column store lands in a memory
+// sector of its own (measured: 4.2 x the algorithmic bytes reach HBM).  A record is one full line instead; the
+// column arrays, for callers that want them on the device, are made by unpack_log_kernel below with
+// consecutive lanes on consecutive rows.
+constexpr int kRecWords = 16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 pack_dd(double a, double b) {
+    const unsigned long long ua = pvt_d2u(a), ub = pvt_d2u(b);
+    return u32x4{(unsigned int)ua, (unsigned int)(ua >> 32), (unsigned int)ub, (unsigned int)(ub >> 32)};
+}
 template <bool RECORD>
 __device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev, int kind, int hit,
                                         int container, int adjacent, int component, int source,
@@ -466,24 +485,66 @@ __device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev
                                         double wl, double travelled, double duration) {
     if constexpr (RECORD) {
         if (base < 0 || nev >= A.max_events) return;
-        long long row = base + nev;
-        const PvtEventLog& L = A.log;
-        L.kind[row] = (uint8_t)kind;
-        L.hit[row] = hit;
-        L.container[row] = container;
-        L.adjacent[row] = adjacent;
-        L.component[row] = component;
-        L.source[row] = source;
-        L.position[row * 3] = pos.x; L.position[row * 3 + 1] = pos.y; L.position[row * 3 + 2] = pos.z;
-        L.direction[row * 3] = dir.x; L.direction[row * 3 + 1] = dir.y; L.direction[row * 3 + 2] = dir.z;
-        L.normal[row * 3] = has_normal ? nrm.x : 0.0;
-        L.normal[row * 3 + 1] = has_normal ? nrm.y : 0.0;
-        L.normal[row * 3 + 2] = has_normal ? nrm.z : 0.0;
-        L.wavelength[row] = wl;
-        L.travelled[row] = travelled;
-        L.duration[row] = duration;
+        const long long row = base + nev;
+        // the log pointer is read from the kernel-argument segment at the point of use (scalar load) instead of
+        // living in two scalar registers across the whole loop
+        const __attribute__((address_space(4))) KArgs* ak =
+            (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ak));
+        u32x4* dst = reinterpret_cast<u32x4*>(ak->log_rows + row * kRecWords);
+        const unsigned long long p0 = pvt_d2u(pos.x);
+        const V3 n = has_normal ? nrm : V3{0.0, 0.0, 0.0};
+        dst[0] = u32x4{(unsigned int)hit, (unsigned int)container, (unsigned int)adjacent, (unsigned int)component};
+        dst[1] = u32x4{(unsigned int)source, (unsigned int)kind, (unsigned int)p0, (unsigned int)(p0 >> 32)};
+        dst[2] = pack_dd(pos.y, pos.z);
+        dst[3] = pack_dd(dir.x, dir.y);
+        dst[4] = pack_dd(dir.z, n.x);
+        dst[5] = pack_dd(n.y, n.z);
+        dst[6] = pack_dd(wl, travelled);
+        dst[7] = pack_dd(duration, pvt_u2d((unsigned long long)row));
         nev += 1;
     }
+}
+
+// Records -> the reference's column arrays (PvtEventLog), one thread per row, consecutive lanes on consecutive
+// rows of the same recorded ray, so every column is written in contiguous runs.  Rows a ray did not write
+// (k >= counts[j]) get the reference's fill values (0, ids -1; _kernel.pyx:1035-1047) when `prefill`, else they
+// are left alone.  grid.x walks the recorded rays (`rays_per_block` each), grid.y the events in chunks of 256.
+__global__ void __launch_bounds__(kBlock) unpack_log_kernel(const unsigned long long* __restrict__ rows_in,
+                                                            const int* __restrict__ counts, PvtEventLog out,
+                                                            long long n_recorded, int max_events, int rays_per_block,
+                                                            int prefill) {
+    const int t = threadIdx.x;
+    const int jr = rays_per_block > 1 ? t / max_events : 0;
+    const int k = (rays_per_block > 1 ? t - jr * max_events : t) + (int)blockIdx.y * kBlock;
+    const long long j = (long long)blockIdx.x * rays_per_block + jr;
+    if (jr >= rays_per_block || j >= n_recorded || k >= max_events) return;
+    const bool valid = k < counts[j];
+    if (!valid && !prefill) return;
+    const long long row = j * max_events + k;
+    u32x4 q[8];
+    if (valid) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(rows_in + row * kRecWords);
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = __builtin_nontemporal_load(src + i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = u32x4{0u, 0u, 0u, 0u};
+        q[0] = u32x4{~0u, ~0u, ~0u, ~0u};
+        q[1].x = ~0u;
+    }
+    auto dd = [&](int word) -> double {   // u64 word `word` of the record as a double
+        const u32x4 v = q[word >> 1];
+        const unsigned long long u = (word & 1) ? ((unsigned long long)v.w << 32 | v.z) : ((unsigned long long)v.y << 32 | v.x);
+        return pvt_u2d(u);
+    };
+    out.hit[row] = (int)q[0].x; out.container[row] = (int)q[0].y;
+    out.adjacent[row] = (int)q[0].z; out.component[row] = (int)q[0].w;
+    out.source[row] = (int)q[1].x; out.kind[row] = (uint8_t)q[1].y;
+    out.position[row * 3] = dd(3); out.position[row * 3 + 1] = dd(4); out.position[row * 3 + 2] = dd(5);
+    out.direction[row * 3] = dd(6); out.direction[row * 3 + 1] = dd(7); out.direction[row * 3 + 2] = dd(8);
+    out.normal[row * 3] = dd(9); out.normal[row * 3 + 1] = dd(10); out.normal[row * 3 + 2] = dd(11);
+    out.wavelength[row] = dd(12); out.travelled[row] = dd(13); out.duration[row] = dd(14);
 }
 
 // LDS accumulator layout (per workgroup), after the table copies:
@@ -1581,7 +1642,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         PVT_MARK(6);  // log + tally
         if (alive && terminal) {
             if constexpr (RECORD) {
-                if (base >= 0) A.log.counts[rec_slot] = nev;
+                if (base >= 0) A.log_counts[rec_slot] = nev;
             }
             alive = false;
         }

@@ -234,53 +234,38 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
             col = np.zeros(0, dtype=dtype)
             data[name] = col.reshape(0, 3) if width == 3 else col
         return data
-    # The log is `max_events` rows per recorded ray but a ray writes only `counts[j]` of them
-    # (10 of 128 on the LSC): gather the written rows on the GPU, move those, and scatter them into
-    # host arrays pre-filled like the reference's (`np.zeros` / `np.full(-1)`, _kernel.pyx:1035-1047).
-    # Untouched pages of the zero-filled columns are never committed, as in the reference.
+    # The log is `max_events` rows per recorded ray but a ray writes only `counts[j]` of them (10 of 128 on the
+    # LSC): the written RECORDS (one 128-byte row per event, PvtEventRecords) are gathered on the GPU with one
+    # index_select, moved, decoded into the reference's columns and -- unless `packed` -- scattered into host
+    # arrays pre-filled like the reference's (`np.zeros` / `np.full(-1)`, _kernel.pyx:1035-1047).  Untouched pages
+    # of the zero-filled columns are never committed, as in the reference.
     import torch
 
     counts = log["counts"][:n_recorded]
     used = int(counts.sum().item())
-    sparse = packed or used < 0.6 * rows
     if packed:
         starts = np.zeros(n_recorded + 1, dtype=np.int64)
         np.cumsum(data["counts"], out=starts[1:])
         data["row_start"] = starts
-    unwritten_host = None
-    if sparse:
-        # rows written = event k < counts[j] of recorded ray j, i.e. row j*max_events + k: built from the counts
-        # (one entry per written row), not by scanning a mask over every row of the log
-        counts64 = counts.to(torch.int64)
-        first = torch.cumsum(counts64, 0) - counts64                     # first packed position of each ray
-        ray = torch.repeat_interleave(torch.arange(n_recorded, device=counts.device), counts64, output_size=used)
-        index = ray * max_events + (torch.arange(used, device=counts.device) - first[ray])
-        index_host = index.cpu().numpy()
+    # rows written = event k < counts[j] of recorded ray j, i.e. row j*max_events + k: built from the counts
+    # (one entry per written row), not by scanning a mask over every row of the log
+    counts64 = counts.to(torch.int64)
+    first = torch.cumsum(counts64, 0) - counts64                     # first packed position of each ray
+    ray = torch.repeat_interleave(torch.arange(n_recorded, device=counts.device), counts64, output_size=used)
+    index = ray * max_events + (torch.arange(used, device=counts.device) - first[ray])
+    written = native.decode_records(log["rows"][:rows].index_select(0, index).cpu().numpy())
+    if packed:
+        data.update(written)
+        return data
+    index_host = index.cpu().numpy()
     for name, dtype, width in native.EVENT_LOG_COLUMNS:
-        col = log[name][: rows * width]
-        if packed:
-            view = col.view(rows, 3) if width == 3 else col
-            data[name] = view[index].cpu().numpy() if used else np.zeros((0, 3) if width == 3 else 0, dtype=dtype)
-        elif sparse:
-            fill = -1 if name in ("hit", "container", "adjacent", "component", "source") else 0
-            shape = (rows, 3) if width == 3 else (rows,)
-            # zero columns stay uncommitted (calloc); the -1 fill is the reference's eager cost too
-            host = np.zeros(shape, dtype=dtype) if fill == 0 else np.full(shape, fill, dtype=dtype)
-            if used:
-                written_rows = (col.view(rows, 3) if width == 3 else col)[index].cpu().numpy()
-                host[index_host] = written_rows
-            data[name] = host
-        else:
-            # most rows are written: move the whole column, then give the unwritten rows the reference's
-            # fill values on the host (the device log is not pre-filled, PVT_FLAG_NO_LOG_PREFILL)
-            host = col.cpu().numpy()
-            host = host.reshape(rows, 3) if width == 3 else host
-            if unwritten_host is None:
-                written = (torch.arange(max_events, device=counts.device, dtype=torch.int32)[None, :]
-                           < counts[:, None]).reshape(-1)
-                unwritten_host = (~written).nonzero().squeeze(1).cpu().numpy()
-            host[unwritten_host] = -1 if name in ("hit", "container", "adjacent", "component", "source") else 0
-            data[name] = host
+        fill = -1 if name in native._ID_COLUMNS else 0
+        shape = (rows, 3) if width == 3 else (rows,)
+        # zero columns stay uncommitted (calloc); the -1 fill is the reference's eager cost too
+        host = np.zeros(shape, dtype=dtype) if fill == 0 else np.full(shape, fill, dtype=dtype)
+        if used:
+            host[index_host] = written[name]
+        data[name] = host
     return data
 
 

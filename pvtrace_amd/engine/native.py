@@ -99,6 +99,10 @@ class PvtEventLog(C.Structure):
     ]
 
 
+class PvtEventRecords(C.Structure):
+    _fields_ = [("counts", _p_i32), ("rows", C.POINTER(C.c_uint64))]
+
+
 _CTYPE_OF = {
     np.dtype(np.int32): C.c_int32, np.dtype(np.float64): C.c_double,
     np.dtype(np.int64): C.c_int64, np.dtype(np.uint8): C.c_uint8,
@@ -193,6 +197,24 @@ EVENT_LOG_COLUMNS = (
 )
 
 
+RECORD_WORDS = 16   # uint64 words of one event record (include/pvtrace_hip.h PvtEventRecords)
+_ID_COLUMNS = ("hit", "container", "adjacent", "component", "source")
+
+
+def decode_records(rows):
+    """(m, 16) int64 event records (host numpy) -> dict of the reference's columns for those m rows
+    (layout: include/pvtrace_hip.h PvtEventRecords)."""
+    rows = np.ascontiguousarray(rows).reshape(-1, RECORD_WORDS)
+    i32 = rows.view(np.int32).reshape(-1, 2 * RECORD_WORDS)
+    f64 = rows.view(np.float64).reshape(-1, RECORD_WORDS)
+    return {
+        "kind": i32[:, 5].astype(np.uint8), "hit": i32[:, 0].copy(), "container": i32[:, 1].copy(),
+        "adjacent": i32[:, 2].copy(), "component": i32[:, 3].copy(), "source": i32[:, 4].copy(),
+        "position": f64[:, 3:6].copy(), "direction": f64[:, 6:9].copy(), "normal": f64[:, 9:12].copy(),
+        "wavelength": f64[:, 12].copy(), "travelled": f64[:, 13].copy(), "duration": f64[:, 14].copy(),
+    }
+
+
 def declare_signatures(lib, names):
     """Set argtypes/restype of the C-ABI entry points present in `lib`."""
     vp = C.c_void_p
@@ -206,6 +228,11 @@ def declare_signatures(lib, names):
         "pvt_trace_device": (
             [vp, C.POINTER(PvtRays), C.POINTER(PvtTraceParams), C.POINTER(PvtTallies),
              C.POINTER(PvtEventLog), vp], C.c_int),
+        "pvt_trace_device_records": (
+            [vp, C.POINTER(PvtRays), C.POINTER(PvtTraceParams), C.POINTER(PvtTallies),
+             C.POINTER(PvtEventRecords), vp], C.c_int),
+        "pvt_unpack_records_device": (
+            [C.POINTER(PvtEventRecords), C.c_int64, C.c_int32, C.POINTER(PvtEventLog), C.c_int, vp], C.c_int),
         "pvt_trace_bundle": (
             [C.POINTER(PvtSceneTables), C.POINTER(PvtEmitterTables), C.POINTER(PvtRays),
              C.POINTER(PvtTraceParams), C.POINTER(PvtTallies), C.POINTER(PvtEventLog), C.c_int,
@@ -235,11 +262,11 @@ ABI_SYMBOLS = (
     "pvt_abi_version", "pvt_last_error", "pvt_device_count", "pvt_scene_create",
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
-    "pvt_trace_bundle_multi", "pvt_shard_range",
+    "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
 )
 
 _lib = None
-ABI_VERSION = 8   # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 9   # include/pvtrace_hip.h PVT_ABI_VERSION
 FLAG_NO_LOG_PREFILL = 1   # PvtTraceParams.flags
 
 
@@ -416,6 +443,19 @@ class DeviceScene:
         }
 
     def new_event_log(self, n_rays, record_every, max_events):
+        """Event-RECORD buffers for one bundle (PvtEventRecords): `counts` (recorded rays) and `rows`
+        (recorded rays x max_events, 16) int64 -- one 128-byte row per event, uninitialised: only the
+        rows k < counts[j] of recorded ray j are ever written (`decode_records`)."""
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        nrec = num_recorded(n_rays, record_every)
+        rows = nrec * max_events
+        return {"counts": torch.empty(max(nrec, 1), dtype=torch.int32, device=dev),
+                "rows": torch.empty((max(rows, 1), RECORD_WORDS), dtype=torch.int64, device=dev)}
+
+    def new_event_columns(self, n_rays, record_every, max_events):
+        """The reference's thirteen column arrays on the device (PvtEventLog), for `unpack_records`."""
         import torch
 
         dev = torch.device("cuda", self.device)
@@ -426,6 +466,26 @@ class DeviceScene:
         for name, dtype, width in EVENT_LOG_COLUMNS:
             log[name] = torch.empty(max(rows, 1) * width, dtype=tmap[dtype], device=dev)
         return log
+
+    @staticmethod
+    def _columns_struct(log):
+        el = PvtEventLog()
+        el.counts = addr_ptr(log["counts"].data_ptr(), C.c_int32)
+        for name, dtype, _ in EVENT_LOG_COLUMNS:
+            setattr(el, name, addr_ptr(log[name].data_ptr(), _CTYPE_OF[np.dtype(dtype)]))
+        return el
+
+    def unpack_records(self, records, columns, n_recorded, max_events, prefill=True, stream=None):
+        """Records -> column arrays on the device (pvt_unpack_records_device)."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rec = PvtEventRecords(addr_ptr(records["counts"].data_ptr(), C.c_int32),
+                              addr_ptr(records["rows"].data_ptr(), C.c_uint64))
+        el = self._columns_struct(columns)
+        check(self.lib.pvt_unpack_records_device(C.byref(rec), int(n_recorded), int(max_events), C.byref(el),
+                                                 1 if prefill else 0, C.c_void_p(stream)), "pvt_unpack_records_device")
 
     def trace(self, rays, n_rays, seed, tallies, log=None, ray_offset=0, emit_seed=0,
               record_every=0, maxsteps=1000, max_events=128, emit_method=0, stream=None,
@@ -467,17 +527,20 @@ class DeviceScene:
                                        addr_ptr(wl.data_ptr(), C.c_double)))
         elif not self.has_emitter:
             raise ValueError("device emission requested but the scene has no emitter tables")
-        log_ref = None
+        if record_every > 0 and log is None:
+            raise ValueError("record_every > 0 needs event-log buffers")
+        if record_every > 0 and "rows" not in log:
+            # column arrays (PvtEventLog) on the device: the library stages the records and unpacks them
+            el = self._columns_struct(log)
+            check(self.lib.pvt_trace_device(self.handle, rays_ref, C.byref(params), C.byref(tl),
+                                            C.byref(el), C.c_void_p(stream)), "pvt_trace_device")
+            return
+        rec_ref = None
         if record_every > 0:
-            if log is None:
-                raise ValueError("record_every > 0 needs event-log buffers")
-            el = PvtEventLog()
-            el.counts = addr_ptr(log["counts"].data_ptr(), C.c_int32)
-            for name, dtype, _ in EVENT_LOG_COLUMNS:
-                setattr(el, name, addr_ptr(log[name].data_ptr(), _CTYPE_OF[np.dtype(dtype)]))
-            log_ref = C.byref(el)
-        check(self.lib.pvt_trace_device(self.handle, rays_ref, C.byref(params), C.byref(tl),
-                                        log_ref, C.c_void_p(stream)), "pvt_trace_device")
+            rec_ref = C.byref(PvtEventRecords(addr_ptr(log["counts"].data_ptr(), C.c_int32),
+                                              addr_ptr(log["rows"].data_ptr(), C.c_uint64)))
+        check(self.lib.pvt_trace_device_records(self.handle, rays_ref, C.byref(params), C.byref(tl),
+                                                rec_ref, C.c_void_p(stream)), "pvt_trace_device_records")
 
     def emit(self, n_rays, emit_seed, ray_offset=0, stream=None):
         """Device-side emission only -> (positions, directions, wavelengths) CUDA tensors."""

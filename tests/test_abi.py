@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol(built):
     lib = native.load_library()
     for name in names:
         assert hasattr(lib, name), name
-    assert lib.pvt_abi_version() == 8 == native.ABI_VERSION
+    assert lib.pvt_abi_version() == 9 == native.ABI_VERSION
     # the embedded device code object really targets gfx950
     blob = open(native.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
@@ -39,12 +39,13 @@ def test_ctypes_structs_match_the_header(tmp_path):
     from pvtrace_amd.engine import native as N
 
     structs = ["PvtSceneTables", "PvtEmitterTables", "PvtTraceParams", "PvtRays", "PvtTallies",
-               "PvtEventLog"]
+               "PvtEventLog", "PvtEventRecords"]
     probes = {"PvtSceneTables": ["n_nodes", "geom_type", "comp_type", "abs_x", "rec_node",
                                  "hist_prop_a", "coat_facet", "coat_transmit_mode", "rec_source_id", "comp_ems_hist"],
               "PvtEmitterTables": ["wl_type", "spec_cdf"],
               "PvtTraceParams": ["seed", "ray_offset", "record_every", "maxsteps", "emit_method"],
-              "PvtRays": ["wavelength"], "PvtTallies": ["rec_bins"], "PvtEventLog": ["kind", "duration"]}
+              "PvtRays": ["wavelength"], "PvtTallies": ["rec_bins"], "PvtEventLog": ["kind", "duration"],
+              "PvtEventRecords": ["counts", "rows"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for s in structs:
         lines.append(f'printf("{s} %zu\\n", sizeof({s}));')
