@@ -197,7 +197,19 @@ enum {
      * reference's defaults, 128 rows per ray of which a ray writes a dozen, that is most of the log).  Rows beyond
      * counts[j] of recorded ray j are then undefined; only counts[] is cleared.  For callers that read the
      * written rows only. */
-    PVT_FLAG_NO_LOG_PREFILL = 1
+    PVT_FLAG_NO_LOG_PREFILL = 1,
+    /* A STREAM of tally bundles whose totals are wanted, not each bundle's own (record_every == 0, no tally sets):
+     * the launch does not trace its last photons to completion.  A wave that finds no new ray parks its live
+     * photons -- complete state: position, direction, wavelength, path, clock, RNG stream, step count, source,
+     * first-crossing mask -- in a buffer of the scene that belongs to the HIP stream, and retires; the NEXT
+     * launch on that stream (same scene, same maxsteps / emit_method; it adds to the tallies IT is given) hands
+     * them to its lanes before its own rays.  Histories are unchanged bit for bit (a photon's draws depend on its
+     * stream alone), integer tallies summed over the launches are identical; what disappears is the tail of
+     * every launch, where a few long histories keep a few lanes busy (a fifth of all wave-iterations of a 10^6-
+     * photon launch of the headline scene).  A launch WITHOUT the flag finishes everything, what it resumed
+     * included; with n_rays == 0 it is the closing flush of a job.  pvt_scene_carry_pending() tells whether
+     * photons are waiting.  (The reference has no counterpart: its bundles end when their slowest ray ends.) */
+    PVT_FLAG_CARRY_OUT = 2
 };
 
 /* initial rays, world frame (exactly trace_bundle's three array arguments) */
@@ -276,6 +288,9 @@ int pvt_trace_device(PvtScene* scene, const PvtRays* rays, const PvtTraceParams*
  * `records` may be NULL when record_every == 0. */
 int pvt_trace_device_records(PvtScene* scene, const PvtRays* rays, const PvtTraceParams* params,
                              const PvtTallies* tallies, const PvtEventRecords* records, void* stream);
+
+/* 1 when photons parked by the last launch on `stream` (PVT_FLAG_CARRY_OUT) wait to be resumed, else 0. */
+int pvt_scene_carry_pending(PvtScene* scene, void* stream);
 
 /* Records -> column arrays (all DEVICE pointers), one coalesced pass; `prefill` != 0 also writes the
  * reference's fill values (0 / -1) into the rows no event reached, else those rows are left alone.

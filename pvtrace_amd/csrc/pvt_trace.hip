@@ -98,6 +98,16 @@ struct PvtScene {
     std::vector<unsigned long long*> stage;
     std::vector<size_t> stage_bytes;
     size_t stage_limit = (size_t)8 << 30;
+    // photons carried from launch to launch of a stream (PVT_FLAG_CARRY_OUT; see KArgs::carry_in): per stream slot
+    // two buffers (the launch that resumes one may park into the other) and which of them holds parked photons
+    struct Carry {
+        unsigned long long* buf[2] = {nullptr, nullptr};
+        int parity = 0;            // the NEXT launch uses cursor block `parity` and parks into buf[parity]
+        bool pending = false;      // buf[parity ^ 1] holds photons parked by the previous launch
+        long long bound = 0;       // at most this many
+    };
+    std::vector<Carry> carry;
+    unsigned int carry_cap = 0;    // photons one buffer holds (a launch of more lanes than that does not park)
     int num_cu = 0;
     int last_grid = 0, last_lds = 0;
     size_t lds_limit = 0;
@@ -583,6 +593,7 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->d_tris) (void)hipFree(s->d_tris);
     for (auto* b : s->stage) if (b) (void)hipFree(b);
+    for (auto& c : s->carry) for (auto* b : c.buf) if (b) (void)hipFree(b);
     delete s;
 }
 
@@ -654,6 +665,7 @@ int slot_of_stream(PvtScene* s, hipStream_t st) {
         s->slot_of.push_back(st);
         s->stage.push_back(nullptr);
         s->stage_bytes.push_back(0);
+        s->carry.emplace_back();
     }
     return (int)slot;
 }
@@ -663,7 +675,9 @@ int check_trace_args(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
     if (p->n_rays < 0 || p->n_rays > 0x7fffffffLL)
         return fail(PVT_ERR_INVALID, "n_rays must fit in 31 bits per bundle");
     if (p->max_events < 2 && p->record_every > 0) return fail(PVT_ERR_INVALID, "max_events must be >= 2");
-    if (!rays && !s->d_ed) return fail(PVT_ERR_INVALID, "no rays and no emitter");
+    if (!rays && !s->d_ed && p->n_rays > 0) return fail(PVT_ERR_INVALID, "no rays and no emitter");
+    if ((p->flags & PVT_FLAG_CARRY_OUT) && (p->record_every > 0 || p->tally_bundle > 0))
+        return fail(PVT_ERR_INVALID, "PVT_FLAG_CARRY_OUT is for plain tally launches (record_every == 0, no tally sets)");
     if (p->tally_bundle > 0 && p->record_every > 0) return fail(PVT_ERR_INVALID, "tally_bundle needs record_every == 0");
     return PVT_OK;
 }
@@ -672,14 +686,16 @@ int check_trace_args(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
 // null when record_every == 0); counts are cleared here.
 int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
                  unsigned long long* log_rows, int* log_counts, hipStream_t st) {
-    if (p->n_rays == 0) return PVT_OK;
+    const int slot = slot_of_stream(s, st);
+    if (slot < 0)
+        return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
+    PvtScene::Carry& carry = s->carry[(size_t)slot];
+    const bool carry_in = carry.pending;
+    if (p->n_rays == 0 && !carry_in) return PVT_OK;
+    if (carry_in && (p->record_every > 0 || p->tally_bundle > 0))
+        return fail(PVT_ERR_INVALID, "photons parked by the previous launch on this stream (PVT_FLAG_CARRY_OUT) are waiting: "
+                                     "finish them with a plain tally launch (n_rays may be 0) first");
     long long n_sets = 0;
-    if (p->tally_bundle > 0) {
-        n_sets = (p->n_rays + p->tally_bundle - 1) / p->tally_bundle;
-        if (p->tally_bundle > 0x7fffffffLL || n_sets > kMaxSets)
-            return fail(PVT_ERR_INVALID, "at most 1024 tally sets per launch");
-        if (p->tally_stride_i64 < 0 || p->tally_stride_f64 < 0) return fail(PVT_ERR_INVALID, "negative tally stride");
-    }
     HIP_TRY(hipSetDevice(s->device));
 
     KArgs a = base_args(s, p);
@@ -700,13 +716,11 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
         const size_t nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
         HIP_TRY(hipMemsetAsync(log_counts, 0, nrec * 4, st));
     }
-    {   // the cursor belongs to the stream: two launches can only overlap on different streams
-        const int slot = slot_of_stream(s, st);
-        if (slot < 0)
-            return fail(PVT_ERR_INVALID, "more than 64 HIP streams are tracing this scene; create one scene per group of streams");
-        a.cursor = n_sets ? s->d_set_cursor + (size_t)kMaxSets * slot : s->d_cursor + 16 * slot;
-    }
-    HIP_TRY(hipMemsetAsync(a.cursor, 0, n_sets ? (size_t)n_sets * 4 : (PVT_STATS ? 256 : 4), st));
+    // the cursor belongs to the stream: two launches can only overlap on different streams.  A slot holds two
+    // blocks {ray cursor, claim cursor of the resumed photons, count of the photons parked} used alternately, so
+    // that a launch can read how many photons its predecessor parked while it counts its own
+    a.cursor = n_sets ? s->d_set_cursor + (size_t)kMaxSets * slot : s->d_cursor + 16 * slot + 4 * carry.parity;
+    HIP_TRY(hipMemsetAsync(a.cursor, 0, n_sets ? (size_t)n_sets * 4 : (PVT_STATS ? 256 : 12), st));
 #if PVT_STATS
     static unsigned long long* g_stats = nullptr;
     if (!g_stats) (void)hipMalloc(&g_stats, 256);
@@ -739,7 +753,7 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
 
     // persistent grid: enough workgroups to fill every CU a few times over,
     // never more than the rays can feed
-    long long blocks_for_rays = (p->n_rays + kBlock - 1) / kBlock;
+    long long blocks_for_rays = (p->n_rays + (carry_in ? carry.bound : 0) + kBlock - 1) / kBlock;
     double per_cu = p->workgroups_per_cu > 0 ? (double)p->workgroups_per_cu : 4.0;
     if (s->dev_blocks_per_cu > 0) per_cu = s->dev_blocks_per_cu;   // developer override, read once per scene
     long long grid = (long long)((double)s->num_cu * per_cu);
@@ -759,7 +773,22 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     s->last_grid = (int)grid;
     s->last_lds = (int)lds;
 
-    const bool emit = rays == nullptr;
+    // carried photons
+    bool carry_out = (p->flags & PVT_FLAG_CARRY_OUT) != 0 && !record && !n_sets;
+    if (carry_in || carry_out) {
+        if (!s->carry_cap) s->carry_cap = (unsigned int)((long long)s->num_cu * 4 * kBlock);
+        if (grid * kBlock > (long long)s->carry_cap) carry_out = false;   // an unusually wide launch finishes its own photons
+        const size_t bytes = (size_t)s->carry_cap * kCarryStride * 8;
+        for (int q = 0; q < 2; q++)
+            if (!carry.buf[q]) HIP_TRY(hipMalloc(&carry.buf[q], bytes));
+        a.carry_cap = s->carry_cap;
+        a.carry_in = carry.buf[carry.parity ^ 1];
+        a.carry_out = carry.buf[carry.parity];
+        a.carry_in_count = s->d_cursor + 16 * slot + 4 * (carry.parity ^ 1) + 2;
+        a.carry_flags = (carry_in ? 1 : 0) | (carry_out ? 2 : 0);
+    }
+
+    const bool emit = rays == nullptr && s->d_ed != nullptr;
     hipError_t e;
     if (record) {
         e = tab_lds ? launch_seen<true, true>(s->n_rec, emit, (int)grid, lds, st, a)
@@ -769,6 +798,11 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
                     : launch_seen<false, false>(s->n_rec, emit, (int)grid, lds, st, a);
     }
     if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
+    if (carry_in || carry_out) {
+        carry.pending = carry_out;
+        carry.bound = carry_out ? grid * kBlock : 0;
+        carry.parity ^= 1;
+    }
 #if PVT_STATS
     {
         unsigned long long c[32];
@@ -814,6 +848,14 @@ int pvt_trace_device_records(PvtScene* s, const PvtRays* rays, const PvtTracePar
         return fail(PVT_ERR_INVALID, "record_every > 0 needs event records");
     return trace_launch(s, rays, p, tl, rec ? reinterpret_cast<unsigned long long*>(rec->rows) : nullptr, rec ? rec->counts : nullptr,
                         reinterpret_cast<hipStream_t>(stream));
+}
+
+int pvt_scene_carry_pending(PvtScene* s, void* stream) {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lock(s->slot_mutex);
+    for (size_t k = 0; k < s->slot_of.size(); k++)
+        if (s->slot_of[k] == reinterpret_cast<hipStream_t>(stream)) return s->carry[k].pending ? 1 : 0;
+    return 0;
 }
 
 int pvt_unpack_records_device(const PvtEventRecords* rec, int64_t n_recorded, int32_t max_events,
@@ -868,7 +910,24 @@ int pvt_trace_device(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
         PvtEventLog out{log->counts + j0, log->kind + row0, log->hit + row0, log->container + row0, log->adjacent + row0,
                         log->component + row0, log->source + row0, log->position + 3 * row0, log->direction + 3 * row0,
                         log->normal + 3 * row0, log->wavelength + row0, log->travelled + row0, log->duration + row0};
-        rc = unpack_launch(s->stage[slot], log->counts + j0, j1 - j0, (int)me, &out, prefill, st);
+        if (prefill) {
+            // the fill values go down as plain memsets (full-width stores: measured 1.6 x the rate of filling from
+            // the unpack kernel's per-row stores); the unpack pass then writes the rows that hold events
+            const size_t rows = (size_t)(j1 - j0) * (size_t)me;
+            HIP_TRY(hipMemsetAsync(out.kind, 0, rows, st));
+            HIP_TRY(hipMemsetAsync(out.hit, 0xFF, rows * 4, st));
+            HIP_TRY(hipMemsetAsync(out.container, 0xFF, rows * 4, st));
+            HIP_TRY(hipMemsetAsync(out.adjacent, 0xFF, rows * 4, st));
+            HIP_TRY(hipMemsetAsync(out.component, 0xFF, rows * 4, st));
+            HIP_TRY(hipMemsetAsync(out.source, 0xFF, rows * 4, st));
+            HIP_TRY(hipMemsetAsync(out.position, 0, rows * 24, st));
+            HIP_TRY(hipMemsetAsync(out.direction, 0, rows * 24, st));
+            HIP_TRY(hipMemsetAsync(out.normal, 0, rows * 24, st));
+            HIP_TRY(hipMemsetAsync(out.wavelength, 0, rows * 8, st));
+            HIP_TRY(hipMemsetAsync(out.travelled, 0, rows * 8, st));
+            HIP_TRY(hipMemsetAsync(out.duration, 0, rows * 8, st));
+        }
+        rc = unpack_launch(s->stage[slot], log->counts + j0, j1 - j0, (int)me, &out, false, st);
         if (rc != PVT_OK) return rc;
     }
     return PVT_OK;

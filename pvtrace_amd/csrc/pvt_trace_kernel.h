@@ -4,6 +4,12 @@
 // overview, the host-side packing and the C ABI).
 #pragma once
 // Developer-only counters (tools/: -DPVT_STATS=1 builds print per-launch lane statistics; off in the product).
+#ifndef PVT_CARRY_IN
+#define PVT_CARRY_IN 1
+#endif
+#ifndef PVT_CARRY_OUT
+#define PVT_CARRY_OUT 1
+#endif
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
@@ -113,7 +119,20 @@ struct KArgs {
     int bins_in_lds;
     int xslots;   // photon-state slots in LDS for drain-phase consolidation (0 = off)
     int tq_pos;   // 1: a histogram reads x, y or z -- queued first crossings carry the local position too
+    // Photons carried from launch to launch of a stream of bundles (tally launches; PVT_FLAG_CARRY_OUT): a wave
+    // that finds the ray cursor dry PARKS its live photons -- complete state, one record of kCarryStride u64 words
+    // per photon -- in `carry_out` (count in cursor[2], one atomic per wave) and retires; the next
+    // launch on the stream hands them to its lanes first (`carry_in`, count `*carry_in_count`, claimed through
+    // cursor[1]) before it touches its own rays.  A launch then has no drain phase: the low-occupancy iterations at
+    // the end of every bundle (a fifth of all wave-iterations of a 10^6-photon launch) run once per JOB.
+    unsigned long long* carry_in;
+    unsigned long long* carry_out;
+    const unsigned int* carry_in_count;
+    unsigned int carry_cap;
+    int carry_flags;   // 1: resume parked photons first   2: park at exhaustion
 };
+constexpr int kCarryBase = 14;     // u64 words of a parked photon before its seen-mask
+constexpr int kCarryStride = 18;   // words per parked photon (room for the four-word mask of scenes with > 64 recorders)
 
 // ------------------------------------------------------------------ RNG
 struct Rng {
@@ -641,6 +660,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     // wave-uniform ray window claimed from the global cursor
     unsigned int w_next = 0, w_end = 0, w_base = 0;
     bool exhausted = false;
+    bool carry_in_live = !RECORD && (A.carry_flags & 1) != 0;   // (wave-uniform) parked photons may still be waiting
     // Per-wave pool of ready-made RNG states for the claimed chunk (4 x 64 u64 = 2 KB).  It lives
     // in the photon-exchange buffer: that buffer is first used when ALL waves of the workgroup
     // have run the cursor dry, i.e. after every pool has been consumed.
@@ -699,6 +719,42 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     for (;;) {
         // ================= refill dead lanes ==============================
         unsigned long long need = __ballot(!alive);
+        if constexpr (!RECORD) {
+            // photons parked by the previous launch on this stream come first (see KArgs::carry_in)
+            if (PVT_CARRY_IN && carry_in_live && need != 0ull) {
+                const __attribute__((address_space(4))) KArgs* ak =
+                    (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(ak));
+                const unsigned int want = __popcll(need);
+                unsigned int b = 0;
+                if (lane == 0) b = atomicAdd(cursor + 1, want);
+                b = __builtin_amdgcn_readfirstlane(b);
+                const unsigned int have = *ak->carry_in_count;
+                if (b >= have) {
+                    carry_in_live = false;
+                } else {
+                    const unsigned int got = have - b < want ? have - b : want;
+                    const unsigned int rank = rank_in(need);
+                    if (!alive && rank < got) {
+                        // photon-major records: one base address, every word at an immediate offset
+                        const unsigned long long* src = ak->carry_in + (unsigned long long)(b + rank) * kCarryStride;
+                        pos = V3{pvt_u2d(src[0]), pvt_u2d(src[1]), pvt_u2d(src[2])};
+                        dir = V3{pvt_u2d(src[3]), pvt_u2d(src[4]), pvt_u2d(src[5])};
+                        wl = pvt_u2d(src[6]); travelled = pvt_u2d(src[7]); duration = pvt_u2d(src[8]);
+                        rng.s0 = src[9]; rng.s1 = src[10]; rng.s2 = src[11]; rng.s3 = src[12];
+                        const unsigned long long cs_ = src[13];
+                        count = (int)(unsigned int)cs_;
+                        source = (int)(unsigned int)(cs_ >> 32);
+#pragma unroll
+                        for (int w = 0; w < SEENW; w++) seen.w[w] = src[kCarryBase + w];
+                        nev = 0;
+                        alive = true;
+                    }
+                    if (got < want) carry_in_live = false;
+                    need = __ballot(!alive);
+                }
+            }
+        }
         for (int pass = 0; pass < 2 && need != 0ull; pass++) {
             if (w_next >= w_end) {
                 if (exhausted) break;
@@ -780,6 +836,32 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // waves every live photon's state is moved through LDS into the lowest waves and the
         // emptied waves retire.  Which lane carries a photon never affects its history (RNG
         // stream, seen-mask and log rows travel with it), so results stay bit-identical.
+        if constexpr (!RECORD) {
+            if (PVT_CARRY_OUT && exhausted && (A.carry_flags & 2)) {
+                // no rays left for this wave: its live photons are parked for the next launch on the stream
+                const unsigned long long live_mask = __ballot(alive);
+                if (live_mask != 0ull) {
+                    const __attribute__((address_space(4))) KArgs* ak =
+                        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ak));
+                    unsigned int b = 0;
+                    if (lane == 0) b = atomicAdd(cursor + 2, (unsigned int)__popcll(live_mask));
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    const unsigned int at = b + rank_in(live_mask);
+                    if (alive && at < ak->carry_cap) {
+                        unsigned long long* dst = ak->carry_out + (unsigned long long)at * kCarryStride;
+                        dst[0] = pvt_d2u(pos.x); dst[1] = pvt_d2u(pos.y); dst[2] = pvt_d2u(pos.z);
+                        dst[3] = pvt_d2u(dir.x); dst[4] = pvt_d2u(dir.y); dst[5] = pvt_d2u(dir.z);
+                        dst[6] = pvt_d2u(wl); dst[7] = pvt_d2u(travelled); dst[8] = pvt_d2u(duration);
+                        dst[9] = rng.s0; dst[10] = rng.s1; dst[11] = rng.s2; dst[12] = rng.s3;
+                        dst[13] = (unsigned long long)(unsigned int)count | ((unsigned long long)(unsigned int)source << 32);
+#pragma unroll
+                        for (int w = 0; w < SEENW; w++) dst[kCarryBase + w] = seen.w[w];
+                    }
+                    alive = false;   // (the wave leaves through the "nothing alive, no rays left" exit below)
+                }
+            }
+        }
         if (exhausted && !counted) {
             counted = true;
             if (lane == 0) atomicAdd(&ctl[CTL_EXHAUSTED], 1);

@@ -253,7 +253,15 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
     first = torch.cumsum(counts64, 0) - counts64                     # first packed position of each ray
     ray = torch.repeat_interleave(torch.arange(n_recorded, device=counts.device), counts64, output_size=used)
     index = ray * max_events + (torch.arange(used, device=counts.device) - first[ray])
-    written = native.decode_records(log["rows"][:rows].index_select(0, index).cpu().numpy())
+    # decoded into columns on the GPU (slices of the gathered records), so that what crosses PCIe and lands in
+    # host memory is already the reference's contiguous arrays
+    picked = log["rows"][:rows].index_select(0, index)
+    i32, f64 = picked.view(torch.int32), picked.view(torch.float64)
+    columns = {"kind": i32[:, 5].to(torch.uint8), "hit": i32[:, 0], "container": i32[:, 1], "adjacent": i32[:, 2],
+               "component": i32[:, 3], "source": i32[:, 4], "position": f64[:, 3:6], "direction": f64[:, 6:9],
+               "normal": f64[:, 9:12], "wavelength": f64[:, 12], "travelled": f64[:, 13], "duration": f64[:, 14]}
+    written = {name: col.contiguous().cpu().numpy() for name, col in columns.items()}
+    del picked, i32, f64, columns
     if packed:
         data.update(written)
         return data

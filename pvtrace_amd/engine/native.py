@@ -231,6 +231,7 @@ def declare_signatures(lib, names):
         "pvt_trace_device_records": (
             [vp, C.POINTER(PvtRays), C.POINTER(PvtTraceParams), C.POINTER(PvtTallies),
              C.POINTER(PvtEventRecords), vp], C.c_int),
+        "pvt_scene_carry_pending": ([vp, vp], C.c_int),
         "pvt_unpack_records_device": (
             [C.POINTER(PvtEventRecords), C.c_int64, C.c_int32, C.POINTER(PvtEventLog), C.c_int, vp], C.c_int),
         "pvt_trace_bundle": (
@@ -263,11 +264,13 @@ ABI_SYMBOLS = (
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
     "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
+    "pvt_scene_carry_pending",
 )
 
 _lib = None
 ABI_VERSION = 9   # include/pvtrace_hip.h PVT_ABI_VERSION
 FLAG_NO_LOG_PREFILL = 1   # PvtTraceParams.flags
+FLAG_CARRY_OUT = 2        # park the photons still alive at the end of the launch for the next launch on the stream
 
 
 def library_built():
@@ -489,10 +492,13 @@ class DeviceScene:
 
     def trace(self, rays, n_rays, seed, tallies, log=None, ray_offset=0, emit_seed=0,
               record_every=0, maxsteps=1000, max_events=128, emit_method=0, stream=None,
-              workgroups_per_cu=0, tally_bundle=0, log_prefill=True):
+              workgroups_per_cu=0, tally_bundle=0, log_prefill=True, carry_out=False):
         """Enqueue one bundle (`workgroups_per_cu`: see PvtTraceParams; 0 = the library default).
         `rays` is None (device emission) or a tuple of
-        three float64 CUDA tensors (positions (n,3), directions (n,3), wavelengths (n))."""
+        three float64 CUDA tensors (positions (n,3), directions (n,3), wavelengths (n)).
+        `carry_out` (tally launches of a stream of bundles): PVT_FLAG_CARRY_OUT -- the photons still alive when the
+        launch runs out of new rays are parked for the NEXT launch on this HIP stream instead of being traced to
+        completion; finish a job with a launch without it (`n_rays` may be 0), see `carry_pending`."""
         import torch
 
         if stream is None:
@@ -509,7 +515,7 @@ class DeviceScene:
                               max_events, emit_method, workgroups_per_cu, tally_bundle,
                               tallies.get("stride_i64", 0) if tally_bundle else 0,
                               tallies.get("stride_f64", 0) if tally_bundle else 0,
-                              0 if log_prefill else FLAG_NO_LOG_PREFILL)
+                              (0 if log_prefill else FLAG_NO_LOG_PREFILL) | (FLAG_CARRY_OUT if carry_out else 0))
         tl = PvtTallies(
             addr_ptr(tallies["rec_distinct"].data_ptr(), C.c_int64),
             addr_ptr(tallies["rec_crossings"].data_ptr(), C.c_int64),
@@ -525,7 +531,7 @@ class DeviceScene:
             rays_ref = C.byref(PvtRays(addr_ptr(pos.data_ptr(), C.c_double),
                                        addr_ptr(direc.data_ptr(), C.c_double),
                                        addr_ptr(wl.data_ptr(), C.c_double)))
-        elif not self.has_emitter:
+        elif not self.has_emitter and n_rays > 0:
             raise ValueError("device emission requested but the scene has no emitter tables")
         if record_every > 0 and log is None:
             raise ValueError("record_every > 0 needs event-log buffers")
@@ -541,6 +547,14 @@ class DeviceScene:
                                               addr_ptr(log["rows"].data_ptr(), C.c_uint64)))
         check(self.lib.pvt_trace_device_records(self.handle, rays_ref, C.byref(params), C.byref(tl),
                                                 rec_ref, C.c_void_p(stream)), "pvt_trace_device_records")
+
+    def carry_pending(self, stream=None):
+        """True when photons parked by the last launch on `stream` (`carry_out=True`) wait to be resumed."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        return bool(self.lib.pvt_scene_carry_pending(self.handle, C.c_void_p(stream)))
 
     def emit(self, n_rays, emit_seed, ray_offset=0, stream=None):
         """Device-side emission only -> (positions, directions, wavelengths) CUDA tensors."""

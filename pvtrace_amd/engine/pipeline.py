@@ -14,12 +14,16 @@ from pvtrace_amd.engine import native
 
 
 class BundlePipeline:
-    def __init__(self, dscene, depth=2, distributed=False, group=None, reduce="end"):
+    def __init__(self, dscene, depth=2, distributed=False, group=None, reduce="end", carry=True):
         """`distributed`: the bundles of this pipeline are one rank's shard of a multi-GPU job.
         `reduce="end"` sums the tallies over ranks ONCE, when the totals are asked for (the sum
         over bundles commutes with the sum over ranks, so one RCCL all-reduce of a few KB serves
         the whole job); `reduce="bundle"` all-reduces every bundle as it completes, for consumers
-        that show global running totals."""
+        that show global running totals.
+        `carry`: the bundles are parts of ONE job whose totals are wanted (every mode but per-bundle all-reduces):
+        a launch does not trace its last, longest histories to completion but hands the photons still alive to the
+        next launch on its stream (PVT_FLAG_CARRY_OUT); `reduce_totals()` / `reset_totals()` finish what is
+        waiting, so totals always cover every photon submitted, completely traced."""
         import torch
 
         if reduce not in ("end", "bundle"):
@@ -27,6 +31,8 @@ class BundlePipeline:
         self.reduce = reduce
         self._reduced = False
         self._unordered = set()   # streams whose totals were zero-filled on streams[0] by the last reduce_totals()
+        self.carry = bool(carry) and not (distributed and reduce == "bundle")
+        self._parked = {}         # stream index -> (maxsteps, max_events, emit_method) of the launch that parked photons
 
         self.torch = torch
         self.dscene = dscene
@@ -79,7 +85,13 @@ class BundlePipeline:
             self.dscene.trace(rays, n_rays, seed=seed, tallies=tallies if per_bundle else total, ray_offset=ray_offset,
                               emit_seed=emit_seed, record_every=0, maxsteps=maxsteps,
                               max_events=max_events, emit_method=emit_method,
-                              stream=stream.cuda_stream, workgroups_per_cu=4 if tail else self.workgroups_per_cu)
+                              stream=stream.cuda_stream, workgroups_per_cu=4 if tail else self.workgroups_per_cu,
+                              carry_out=self.carry and not tail)
+            if self.carry:
+                if tail:
+                    self._parked.pop(k, None)   # a tail launch finishes what it resumed
+                else:
+                    self._parked[k] = (maxsteps, max_events, emit_method)
             if timed:
                 ev[1].record(stream)
                 self.events.append(ev)
@@ -102,7 +114,23 @@ class BundlePipeline:
         for s in self.streams:
             s.synchronize()
 
+    def finish_parked(self):
+        """Trace the photons parked on the pipeline's streams to completion (one launch without new rays per
+        stream that holds any), into that stream's totals."""
+        torch = self.torch
+        for k, (maxsteps, max_events, emit_method) in sorted(self._parked.items()):
+            stream = self.streams[k]
+            if k in self._unordered:
+                stream.wait_stream(self.streams[0])
+                self._unordered.discard(k)
+            with torch.cuda.stream(stream):
+                self.dscene.trace(None, 0, seed=0, tallies=self.totals[k], record_every=0, maxsteps=maxsteps,
+                                  max_events=max_events, emit_method=emit_method, stream=stream.cuda_stream,
+                                  workgroups_per_cu=4, carry_out=False)
+        self._parked = {}
+
     def reset_totals(self):
+        self.finish_parked()      # photons of earlier bundles must not be tallied into what follows
         self.synchronize()
         for t in self.totals:
             t["_ints"].zero_()
@@ -119,6 +147,7 @@ class BundlePipeline:
         torch = self.torch
         if self._reduced:
             return
+        self.finish_parked()
         first = self.streams[0]
         for s in self.streams[1:]:
             first.wait_stream(s)

@@ -1,0 +1,99 @@
+"""Photons carried from launch to launch of a stream of bundles (PVT_FLAG_CARRY_OUT): a launch hands the photons
+still alive when it runs out of new rays to the next launch on its HIP stream.  Which launch finishes a photon
+must not change its history: totals over the job equal the totals of launches that each finish their own."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pvtrace_amd.engine import BundlePipeline, compile_scene, native
+from pvtrace_amd.engine.emit import EmitterTables, emit_bundle
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+INT_KEYS = ("rec_distinct", "rec_crossings", "rec_bins")
+
+
+def _host(t, compiled):
+    nrec, pad = int(compiled.rec_node.shape[0]), max(int(compiled.rec_node.shape[0]), 1)
+    ints = t["_ints"].cpu().numpy()
+    return {"rec_distinct": ints[:nrec], "rec_crossings": ints[pad:pad + nrec],
+            "rec_bins": ints[2 * pad:2 * pad + int(compiled.total_bins)],
+            "rec_sums": t["_sums"].cpu().numpy()[: nrec * 8].reshape(nrec, 4, 2)}
+
+
+@pytest.mark.parametrize("name", ["lsc_equivalent", "nested_cylinders", "kitchen_sink", "coated_slab"])
+def test_parked_photons_are_finished_by_the_next_launch_bit_for_bit(name):
+    import torch
+
+    scene = scenes.ALL_SCENES[name]()
+    compiled = compile_scene(scene)
+    n, seed = 30_011, 77
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=4)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, seed, 1000, 16, 0, 4, 0, math_mode=O.MATH_PORTABLE)
+    dscene = native.DeviceScene(compiled, device=0)
+    try:
+        dev = torch.device("cuda", 0)
+        rays = tuple(torch.from_numpy(a).to(dev) for a in (pos, dirs, wl))
+        tallies = dscene.new_tallies()
+        edges = [0, 9000, 9000 + 64, 21_000, n]           # four launches, the second a single chunk
+        for a, b in zip(edges[:-1], edges[1:]):
+            part = tuple(t[a:b] for t in rays)
+            dscene.trace(part, b - a, seed, tallies, ray_offset=a, carry_out=True)
+        torch.cuda.synchronize()
+        assert dscene.carry_pending()
+        partial = _host(tallies, compiled)
+        # something was left for later (every scene here has histories of several steps) ...
+        assert partial["rec_crossings"].sum() < cpu["rec_crossings"].sum()
+        # ... a history launch cannot take it over ...
+        log = dscene.new_event_log(64, 1, 16)
+        with pytest.raises(ValueError, match="parked"):
+            dscene.trace(tuple(t[:64] for t in rays), 64, seed, dscene.new_tallies(), log=log, record_every=1, max_events=16)
+        # ... a launch without new rays finishes it (array-input scene: no emitter, no rays)
+        dscene.trace(None, 0, 0, tallies)
+        torch.cuda.synchronize()
+        assert not dscene.carry_pending()
+        got = _host(tallies, compiled)
+        for key in INT_KEYS:
+            assert np.array_equal(got[key], cpu[key]), (name, key)
+        assert np.allclose(got["rec_sums"], cpu["rec_sums"], rtol=1e-11)
+        # nothing waiting: a launch of zero rays is a no-op
+        dscene.trace(None, 0, 0, tallies)
+        torch.cuda.synchronize()
+        assert np.array_equal(_host(tallies, compiled)["rec_distinct"], cpu["rec_distinct"])
+    finally:
+        dscene.close()
+
+
+def test_pipeline_totals_do_not_depend_on_carrying():
+    scene = scenes.lsc_equivalent()
+    compiled = compile_scene(scene)
+    dscene = native.DeviceScene(compiled, device=0, emitter=EmitterTables(scene))
+    try:
+        results = {}
+        for carry in (False, True):
+            pipe = BundlePipeline(dscene, depth=3, carry=carry)
+            at = 0
+            for k, m in enumerate((50_000, 70_001, 64, 30_000, 1, 120_000, 65_000)):
+                pipe.submit(None, m, seed=5, ray_offset=at, emit_seed=6, tail=(k == 6))
+                at += m
+            first = pipe.totals_host()
+            # a second job on the same pipeline must start clean: photons parked by warm-up style launches
+            # (no tail launch at all here) are finished by reset_totals, not tallied into what follows
+            pipe.reset_totals()
+            pipe.submit(None, 40_000, seed=5, ray_offset=at, emit_seed=6)
+            pipe.reset_totals()
+            for k in range(4):
+                pipe.submit(None, 25_000, seed=9, ray_offset=k * 25_000, emit_seed=6)
+            second = pipe.totals_host()
+            results[carry] = (first, second)
+        for a, b in zip(results[False], results[True]):
+            for key in INT_KEYS:
+                assert np.array_equal(a[key], b[key]), key
+            assert np.allclose(a["rec_sums"], b["rec_sums"], rtol=1e-11)
+        n_first = 50_000 + 70_001 + 64 + 30_000 + 1 + 120_000 + 65_000
+        names = list(compiled.recorder_names)
+        first, second = results[True]
+        assert first["rec_distinct"][names.index("entering")] + first["rec_distinct"][names.index("reflected")] == n_first
+        assert second["rec_distinct"][names.index("entering")] + second["rec_distinct"][names.index("reflected")] == 100_000
+    finally:
+        dscene.close()

@@ -12,8 +12,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = []
     for path in glob.glob("$R/gpurun_out/hist_pmc_%s/**/pmc_counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(path)):
-            if "trace_kernel" in r["Kernel_Name"]:
-                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"][:60], float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+            if "trace_kernel" in r["Kernel_Name"] or "unpack_log" in r["Kernel_Name"]:
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].replace("void (anonymous namespace)::", "")[:60], float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
     rows.sort()
     print(c)
     for d, k, v, ms in rows:
