@@ -102,7 +102,8 @@ struct PvtScene {
     // two buffers (the launch that resumes one may park into the other) and which of them holds parked photons
     struct Carry {
         unsigned long long* buf[2] = {nullptr, nullptr};
-        int parity = 0;            // the NEXT launch uses cursor block `parity` and parks into buf[parity]
+        int parity = 0;            // the NEXT launch parks into buf[parity]
+        int phase = 0;             // ... and uses cursor block `phase` of the slot's three (see trace_launch)
         bool pending = false;      // buf[parity ^ 1] holds photons parked by the previous launch
         long long bound = 0;       // at most this many
     };
@@ -511,6 +512,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         ~Owner() { if (p) pvt_scene_destroy(p); }
     } owner{new PvtScene()};
     PvtScene* s = owner.p;
+    s->stage.reserve(kCursorSlots); s->stage_bytes.reserve(kCursorSlots); s->carry.reserve(kCursorSlots);   // (references stay valid)
     s->device = device;
     s->lay = lay;
     s->nd = (int)gd.size();
@@ -536,6 +538,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMalloc(&s->d_gd, gd.size() * sizeof(double)));
     HIP_TRY(hipMalloc(&s->d_gi, gi.size() * sizeof(int)));
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
+    HIP_TRY(hipMemset(s->d_cursor, 0, 64 * kCursorSlots + 256));
     HIP_TRY(hipMalloc(&s->d_set_cursor, (size_t)kCursorSlots * kMaxSets * 4));
     if (!bvh_nodes.empty()) {
         HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
@@ -696,6 +699,12 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
         return fail(PVT_ERR_INVALID, "photons parked by the previous launch on this stream (PVT_FLAG_CARRY_OUT) are waiting: "
                                      "finish them with a plain tally launch (n_rays may be 0) first");
     long long n_sets = 0;
+    if (p->tally_bundle > 0) {
+        n_sets = (p->n_rays + p->tally_bundle - 1) / p->tally_bundle;
+        if (p->tally_bundle > 0x7fffffffLL || n_sets > kMaxSets)
+            return fail(PVT_ERR_INVALID, "at most 1024 tally sets per launch");
+        if (p->tally_stride_i64 < 0 || p->tally_stride_f64 < 0) return fail(PVT_ERR_INVALID, "negative tally stride");
+    }
     HIP_TRY(hipSetDevice(s->device));
 
     KArgs a = base_args(s, p);
@@ -716,16 +725,24 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
         const size_t nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
         HIP_TRY(hipMemsetAsync(log_counts, 0, nrec * 4, st));
     }
-    // the cursor belongs to the stream: two launches can only overlap on different streams.  A slot holds two
-    // blocks {ray cursor, claim cursor of the resumed photons, count of the photons parked} used alternately, so
-    // that a launch can read how many photons its predecessor parked while it counts its own
-    a.cursor = n_sets ? s->d_set_cursor + (size_t)kMaxSets * slot : s->d_cursor + 16 * slot + 4 * carry.parity;
-    HIP_TRY(hipMemsetAsync(a.cursor, 0, n_sets ? (size_t)n_sets * 4 : (PVT_STATS ? 256 : 12), st));
+    // the cursor belongs to the stream: two launches can only overlap on different streams.  A slot holds THREE
+    // blocks {ray cursor, claim cursor of the resumed photons, count of the photons parked} used in rotation:
+    // launch L counts in block L mod 3, reads how many photons its predecessor parked from block L-1, and clears
+    // block L+1 for its successor (all zero at scene creation) -- so no fill kernel sits between two launches
+    unsigned int* const blocks = s->d_cursor + 16 * slot;
+    if (n_sets) {
+        a.cursor = s->d_set_cursor + (size_t)kMaxSets * slot;
+        HIP_TRY(hipMemsetAsync(a.cursor, 0, (size_t)n_sets * 4, st));
+    } else {
+        a.cursor = blocks + 4 * carry.phase;
+        a.cursor_next = blocks + 4 * ((carry.phase + 1) % 3);
+    }
 #if PVT_STATS
     static unsigned long long* g_stats = nullptr;
     if (!g_stats) (void)hipMalloc(&g_stats, 256);
     (void)hipMemsetAsync(g_stats, 0, 256, st);
     a.cursor = reinterpret_cast<unsigned int*>(g_stats);  // dev build: counters live in their own buffer
+    a.cursor_next = nullptr;
 #endif
 
     // LDS budget: recorder accumulators + control words, tables if they fit, bins if they fit, then the
@@ -784,10 +801,20 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
         a.carry_cap = s->carry_cap;
         a.carry_in = carry.buf[carry.parity ^ 1];
         a.carry_out = carry.buf[carry.parity];
-        a.carry_in_count = s->d_cursor + 16 * slot + 4 * (carry.parity ^ 1) + 2;
+        a.carry_in_count = blocks + 4 * ((carry.phase + 2) % 3) + 2;
         a.carry_flags = (carry_in ? 1 : 0) | (carry_out ? 2 : 0);
     }
 
+#if PVT_TIMELINE
+    static unsigned long long* g_timeline = nullptr;
+    const size_t tl_bytes = (size_t)8 * 8 * kWaves * 8192;
+    if (!g_timeline) (void)hipMalloc(&g_timeline, tl_bytes);
+    const char* tl_path = getenv("PVT_TIMELINE_FILE");
+    static int tl_launch = 0;
+    const int tl_from = getenv("PVT_TIMELINE_FROM") ? atoi(getenv("PVT_TIMELINE_FROM")) : 0;
+    const bool tl_on = tl_path && tl_launch >= tl_from && tl_launch < tl_from + 12 && grid <= 8192;
+    if (tl_on) { (void)hipMemsetAsync(g_timeline, 0, tl_bytes, st); a.timeline = g_timeline; }
+#endif
     const bool emit = rays == nullptr && s->d_ed != nullptr;
     hipError_t e;
     if (record) {
@@ -798,6 +825,21 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
                     : launch_seen<false, false>(s->n_rec, emit, (int)grid, lds, st, a);
     }
     if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
+#if PVT_TIMELINE
+    if (tl_on) {   // (serialises the launches it records)
+        std::vector<unsigned long long> host((size_t)grid * kWaves * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(host.data(), g_timeline, host.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* fp = fopen(tl_path, "ab")) {
+            unsigned long long head[4] = {0xABCDull, (unsigned long long)tl_launch, (unsigned long long)grid, (unsigned long long)p->n_rays};
+            fwrite(head, 8, 4, fp);
+            fwrite(host.data(), 8, host.size(), fp);
+            fclose(fp);
+        }
+    }
+    tl_launch += 1;
+#endif
+    if (!n_sets) carry.phase = (carry.phase + 1) % 3;
     if (carry_in || carry_out) {
         carry.pending = carry_out;
         carry.bound = carry_out ? grid * kBlock : 0;

@@ -13,11 +13,28 @@
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
+// Developer-only: every wave writes wall-clock stamps (start, tables staged, first step, cursor dry, end) and its
+// iteration count to KArgs::timeline (tools/gpu_wave_timeline.py)
+#ifndef PVT_TIMELINE
+#define PVT_TIMELINE 0
+#endif
 
 namespace {
 
 constexpr int kBlock = 256;          // 4 wavefronts
-constexpr int kChunk = 64;           // rays claimed per wave per cursor atomic
+constexpr int kChunk = 64;           // rays a wave seeds and hands out at a time
+#ifndef PVT_CLAIM_CHUNKS
+#define PVT_CLAIM_CHUNKS 1
+#endif
+#ifndef PVT_END_CLAIM
+#define PVT_END_CLAIM 64
+#endif
+constexpr int kEndClaim = PVT_END_CLAIM;   // rays per claim in the last two rounds of a launch (see the refill)
+constexpr int kClaim = kChunk * PVT_CLAIM_CHUNKS;   // rays a wave claims per cursor atomic: every wave of a launch adds to the SAME
+                                     // word, and a device-scope atomic that returns a value costs the wave a round trip
+                                     // through the fabric; claiming several chunks at once takes the cursor off the critical
+                                     // path -- measured (round 3): 1, 2 and 4 chunks per claim give the same throughput at
+                                     // 10^6 and 4 10^6 photons per launch, serial and pipelined: the cursor is NOT a bottleneck
 constexpr int kWaves = kBlock / 64;
 constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
 constexpr int kMaxSets = 1024;       // tally sets (bundles of a stream) one launch may serve
@@ -88,7 +105,10 @@ struct KArgs {
     const double* dir;
     const double* wl;
     unsigned int n_rays;
-    unsigned int* cursor;   // [0] ray cursor; (PVT_STATS builds) [2..] u64 counters
+    unsigned int* cursor;   // [0] ray cursor, [1] claim cursor of resumed photons, [2] photons parked; (PVT_STATS builds) [2..] u64 counters
+    unsigned int* cursor_next;   // the block the NEXT launch on this stream will use: cleared by this launch (no memset
+                                 // kernel between launches: a one-workgroup fill cannot start while persistent workgroups
+                                 // hold every slot of the chip, and the launch behind it waits with it); null = leave alone
     unsigned long long seed;       // + ray_offset folded in by the host
     unsigned long long emit_seed;  // + nothing; global index added per ray
     unsigned long long ray_offset;
@@ -130,6 +150,7 @@ struct KArgs {
     const unsigned int* carry_in_count;
     unsigned int carry_cap;
     int carry_flags;   // 1: resume parked photons first   2: park at exhaustion
+    unsigned long long* timeline;   // (PVT_TIMELINE builds) 8 words per wave
 };
 constexpr int kCarryBase = 14;     // u64 words of a parked photon before its seen-mask
 constexpr int kCarryStride = 18;   // words per parked photon (room for the four-word mask of scenes with > 64 recorders)
@@ -586,6 +607,10 @@ struct Seen {
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
 __device__ __forceinline__ void trace_body(const KArgs& A) {
     extern __shared__ double smem[];
+#if PVT_TIMELINE
+    unsigned long long tl_t[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0};
+    unsigned long long tl_iters = 0;
+#endif
     const Lay L = A.lay;
     const bool coated = A.n_coat > 0;  // wave-uniform
 
@@ -611,6 +636,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                       + (threadIdx.x >> 6) * kTallyQ;
     int tq_n = 0;   // wave-uniform
     if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4 && A.cursor_next) A.cursor_next[threadIdx.x] = 0u;
     if constexpr (TAB_LDS) {
         for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
         for (int i = threadIdx.x; i < A.ni; i += kBlock) lds_i[i] = A.gi[i];
@@ -620,6 +646,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     if (A.bins_in_lds)
         for (int i = threadIdx.x; i < A.total_bins; i += kBlock) acc_bins[i] = 0u;
     __syncthreads();
+#if PVT_TIMELINE
+    tl_t[1] = wall_clock64();
+#endif
 
     Tables<TAB_LDS> T{(CDoubles)A.gd, (CInts)A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi, A.gd, A.gi};
 
@@ -658,7 +687,16 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #define PVT_COUNT(k, pred) do {} while (0)
 #endif
     // wave-uniform ray window claimed from the global cursor
-    unsigned int w_next = 0, w_end = 0, w_base = 0;
+    // (the waves of a launch -- of a tally set -- are numbered; wave k owns rays [k kClaim, (k+1) kClaim) and parked
+    // photons [64 k, 64 k + 64) without asking, everything beyond is claimed from the cursors)
+    const unsigned int wgs_in_set = A.set_size ? (unsigned int)A.wgs_per_set : gridDim.x;
+    const unsigned int waves_in_set = wgs_in_set * kWaves;
+    const unsigned int wave_in_set = (blockIdx.x - set * (A.set_size ? (unsigned int)A.wgs_per_set : 0u)) * kWaves + (threadIdx.x >> 6);
+    const unsigned int w_first = wave_in_set * (unsigned int)kClaim;
+    unsigned int w_next = w_first, w_end = w_first, w_base = 0;
+    unsigned int w_claim_end = w_first < n_local ? (n_local - w_first < (unsigned int)kClaim ? n_local : w_first + kClaim) : w_first;
+    unsigned int c_next = 0, c_end = 0;   // window of parked photons
+    bool c_first = true;
     bool exhausted = false;
     bool carry_in_live = !RECORD && (A.carry_flags & 1) != 0;   // (wave-uniform) parked photons may still be waiting
     // Per-wave pool of ready-made RNG states for the claimed chunk (4 x 64 u64 = 2 KB).  It lives
@@ -720,24 +758,39 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // ================= refill dead lanes ==============================
         unsigned long long need = __ballot(!alive);
         if constexpr (!RECORD) {
-            // photons parked by the previous launch on this stream come first (see KArgs::carry_in)
+            // photons parked by the previous launch on this stream come first (see KArgs::carry_in).  They are handed
+            // out like rays, 64 at a time: every wave starts with the slice its index names (no atomic -- the previous
+            // launch parked at most 64 per wave, so with an equal or larger grid that is all of them); only what lies
+            // beyond is claimed through the claim cursor, one atomic per 64.  (A claim per refill, for just the lanes
+            // that died in the last step, put a queue of ~10^5 same-address atomics in front of every step: measured
+            // 21 us per iteration instead of 11.)
             if (PVT_CARRY_IN && carry_in_live && need != 0ull) {
                 const __attribute__((address_space(4))) KArgs* ak =
                     (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(ak));
-                const unsigned int want = __popcll(need);
-                unsigned int b = 0;
-                if (lane == 0) b = atomicAdd(cursor + 1, want);
-                b = __builtin_amdgcn_readfirstlane(b);
                 const unsigned int have = *ak->carry_in_count;
-                if (b >= have) {
-                    carry_in_live = false;
-                } else {
-                    const unsigned int got = have - b < want ? have - b : want;
+                if (c_next >= c_end) {
+                    unsigned int b = ~0u;
+                    if (c_first) {
+                        c_first = false;
+                        b = wave_in_set * 64u;
+                    } else if (have > waves_in_set * 64u) {
+                        if (lane == 0) b = atomicAdd(cursor + 1, 64u);
+                        b = __builtin_amdgcn_readfirstlane(b) + waves_in_set * 64u;
+                    }
+                    if (b >= have) {
+                        carry_in_live = false;
+                    } else {
+                        c_next = b;
+                        c_end = have - b < 64u ? have : b + 64u;
+                    }
+                }
+                if (carry_in_live) {
+                    const unsigned int want = __popcll(need), got = c_end - c_next < want ? c_end - c_next : want;
                     const unsigned int rank = rank_in(need);
                     if (!alive && rank < got) {
                         // photon-major records: one base address, every word at an immediate offset
-                        const unsigned long long* src = ak->carry_in + (unsigned long long)(b + rank) * kCarryStride;
+                        const unsigned long long* src = ak->carry_in + (unsigned long long)(c_next + rank) * kCarryStride;
                         pos = V3{pvt_u2d(src[0]), pvt_u2d(src[1]), pvt_u2d(src[2])};
                         dir = V3{pvt_u2d(src[3]), pvt_u2d(src[4]), pvt_u2d(src[5])};
                         wl = pvt_u2d(src[6]); travelled = pvt_u2d(src[7]); duration = pvt_u2d(src[8]);
@@ -750,7 +803,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         nev = 0;
                         alive = true;
                     }
-                    if (got < want) carry_in_live = false;
+                    c_next += got;
                     need = __ballot(!alive);
                 }
             }
@@ -758,12 +811,25 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         for (int pass = 0; pass < 2 && need != 0ull; pass++) {
             if (w_next >= w_end) {
                 if (exhausted) break;
-                unsigned int b = 0;
-                if (lane == 0) b = atomicAdd(cursor, (unsigned int)kChunk);
-                b = __builtin_amdgcn_readfirstlane(b);
-                if (b >= n_local) { exhausted = true; break; }
+                unsigned int b = w_end;          // next chunk of the rays this wave has claimed ...
+                if (b >= w_claim_end) {          // ... or a new claim (the first one is the wave's own index: no atomic;
+                                                 // 4096 waves starting together on ONE word cost the launch ~50 us)
+                    // (Smaller claims towards the end of the rays -- a wave that takes the last 64 rays runs some six
+                    // iterations longer than its neighbours, which found the cursor dry -- were measured and NOT kept:
+                    // with PVT_END_CLAIM 32 / 16 in the last two rounds the pipelined bench lost 4 % / 13 %, the extra
+                    // same-address atomics cost more than the ragged end.  Between two claims of a wave every other
+                    // wave claims about once, so the cursor stands near w_claim_end + waves x 64 now.)
+                    const unsigned int claim = (n_local - w_claim_end > 2u * waves_in_set * (unsigned int)kClaim || w_claim_end > n_local)
+                                                   ? (unsigned int)kClaim : (unsigned int)kEndClaim;
+                    unsigned int c = 0;
+                    if (lane == 0) c = atomicAdd(cursor, claim);
+                    c = __builtin_amdgcn_readfirstlane(c) + waves_in_set * (unsigned int)kClaim;
+                    if (c >= n_local) { exhausted = true; break; }
+                    b = c;
+                    w_claim_end = (n_local - c < claim) ? n_local : c + claim;
+                }
                 w_next = b;
-                w_end = (n_local - b < (unsigned int)kChunk) ? n_local : b + kChunk;
+                w_end = (w_claim_end - b < (unsigned int)kChunk) ? w_claim_end : b + kChunk;
                 if (seed_pool) {
                     // Seed the whole chunk NOW, with every lane busy, instead of inside each later
                     // refill with only the dead lanes active (8 64-bit multiplies per seed): lane l
@@ -954,6 +1020,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
 #endif
 
+#if PVT_TIMELINE
+        if (tl_iters == 0) tl_t[2] = wall_clock64();
+        if (exhausted && tl_t[3] == 0) tl_t[3] = wall_clock64();
+        tl_iters += 1;
+#endif
         PVT_MARK(0);  // refill + drain bookkeeping
         PVT_COUNT(0, alive);
         // ================= one step for every live lane ==================
@@ -1739,6 +1810,17 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         for (int k = 0; k < 7; k++) atomicAdd(c + 8 + k, st_t[k]);
         atomicAdd(c + 15, solo ? 1ull : 0ull);
         for (int k = 0; k < 8; k++) atomicAdd(c + 16 + k, st_c[k]);
+    }
+#endif
+#if PVT_TIMELINE
+    if (A.timeline && lane == 0) {
+        unsigned long long* o = A.timeline + ((unsigned long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8;
+        o[0] = tl_t[0]; o[1] = tl_t[1]; o[2] = tl_t[2]; o[3] = tl_t[3]; o[4] = wall_clock64(); o[5] = tl_iters;
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned int hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[6] = ((unsigned long long)xcc << 32) | hwid; o[7] = 1;
     }
 #endif
     tally_flush();   // the first crossings still parked

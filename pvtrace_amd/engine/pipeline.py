@@ -24,6 +24,8 @@ class BundlePipeline:
         a launch does not trace its last, longest histories to completion but hands the photons still alive to the
         next launch on its stream (PVT_FLAG_CARRY_OUT); `reduce_totals()` / `reset_totals()` finish what is
         waiting, so totals always cover every photon submitted, completely traced."""
+        import os
+
         import torch
 
         if reduce not in ("end", "bundle"):
@@ -32,6 +34,10 @@ class BundlePipeline:
         self._reduced = False
         self._unordered = set()   # streams whose totals were zero-filled on streams[0] by the last reduce_totals()
         self.carry = bool(carry) and not (distributed and reduce == "bundle")
+        if os.environ.get("PVT_NO_CARRY"):   # developer A/B switch
+            self.carry = False
+        if not self.carry and self.depth == 2:
+            self.workgroups_per_cu = 3
         self._parked = {}         # stream index -> (maxsteps, max_events, emit_method) of the launch that parked photons
 
         self.torch = torch
@@ -41,9 +47,9 @@ class BundlePipeline:
         self.distributed = distributed
         self.group = group
         # launches that overlap run best with fewer persistent workgroups each (measured on the
-        # LSC, 10^6-photon bundles: 2 per CU with three in flight, 3 with two, 4 alone)
-        self.workgroups_per_cu = {1: 4, 2: 3}.get(self.depth, 2)
-        import os
+        # LSC, 10^6-photon bundles, photons carried between launches: 2 per CU with two or three in flight, 4 alone;
+        # without carrying -- launches that drain -- 3 per CU with two in flight)
+        self.workgroups_per_cu = {1: 4}.get(self.depth, 2)
         if os.environ.get("PVT_PIPE_WGS"):   # developer sweep
             self.workgroups_per_cu = int(os.environ["PVT_PIPE_WGS"])
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
