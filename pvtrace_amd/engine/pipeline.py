@@ -36,8 +36,6 @@ class BundlePipeline:
         self.carry = bool(carry) and not (distributed and reduce == "bundle")
         if os.environ.get("PVT_NO_CARRY"):   # developer A/B switch
             self.carry = False
-        if not self.carry and self.depth == 2:
-            self.workgroups_per_cu = 3
         self._parked = {}         # stream index -> (maxsteps, max_events, emit_method) of the launch that parked photons
 
         self.torch = torch
@@ -50,6 +48,8 @@ class BundlePipeline:
         # LSC, 10^6-photon bundles, photons carried between launches: 2 per CU with two or three in flight, 4 alone;
         # without carrying -- launches that drain -- 3 per CU with two in flight)
         self.workgroups_per_cu = {1: 4}.get(self.depth, 2)
+        if not self.carry and self.depth == 2:
+            self.workgroups_per_cu = 3
         if os.environ.get("PVT_PIPE_WGS"):   # developer sweep
             self.workgroups_per_cu = int(os.environ["PVT_PIPE_WGS"])
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
