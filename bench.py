@@ -308,22 +308,23 @@ def main():
             self.pipe = BundlePipeline(self.dscene, depth=args.streams, distributed=distributed, reduce=args.reduce)
             self.pipe.wait_for_inputs()
 
-        def step(self, k, timed, tail=False, m=None, offset=None, seed=None):
+        def step(self, k, timed, tail=False, m=None, offset=None, seed=None, closing=False):
             m = self.n if m is None else m
             rays = self.ray_sets[k % len(self.ray_sets)]
             if rays is not None and m != self.n:
                 rays = tuple(t[:m] for t in rays)
             self.pipe.submit(rays, m, seed=12345 + k * world * self.n if seed is None else seed,
                              ray_offset=rank * self.n if offset is None else offset, emit_seed=4242 + k * world * self.n,
-                             maxsteps=1000, max_events=128, emit_method=self.method, timed=timed, tail=tail)
+                             maxsteps=1000, max_events=128, emit_method=self.method, timed=timed, tail=tail,
+                             closing=closing)
 
         def window(self, first_step, steps, timed_events=False):
             """One independent window of `steps` steps, fenced on both sides -> seconds (max over ranks)."""
             self.pipe.reset_totals()
             fence(self.pipe)
             t0 = time.perf_counter()
-            for k in range(steps):
-                self.step(first_step + k, timed_events, tail=k >= steps - tail_wide)
+            for k in range(steps):   # (the last bundle on each stream finishes the photons carried along its stream)
+                self.step(first_step + k, timed_events, tail=k >= steps - tail_wide, closing=k >= steps - args.streams)
             self.pipe.reduce_totals()   # fold the streams' totals; RCCL all-reduce over the ranks (reduce="end")
             fence(self.pipe)
             return max_over_ranks(time.perf_counter() - t0)
@@ -396,7 +397,7 @@ def main():
         at, k = lo, 0
         while at < hi:
             m = min(n, hi - at)
-            leg.step(k, False, tail=at + m >= hi, m=m, offset=at, seed=777)
+            leg.step(k, False, tail=at + m >= hi, m=m, offset=at, seed=777, closing=at + m * args.streams >= hi)
             at += m
             k += 1
         leg.pipe.reduce_totals()

@@ -60,10 +60,13 @@ class BundlePipeline:
         self.wait_for_inputs()   # the zero-fills above ran on the current stream
 
     def submit(self, rays, n_rays, seed, ray_offset=0, emit_seed=0, maxsteps=1000, max_events=128,
-               emit_method=0, timed=True, tail=False):
+               emit_method=0, timed=True, tail=False, closing=False):
         """Enqueue one tally-mode bundle (record_every=0) on the next stream; returns its slot.
         `tail`: nothing will follow this bundle soon (the last one of a job): it is launched at the full width
-        of a lone launch, so that its own end does not run at the reduced width chosen for overlapping bundles."""
+        of a lone launch, so that its own end does not run at the reduced width chosen for overlapping bundles.
+        `closing`: no further bundle will follow on this bundle's stream before the totals are read (the last
+        `depth` bundles of a job): it finishes its own photons and the ones it resumed instead of parking them for a
+        launch that would carry no new rays."""
         torch = self.torch
         if self._reduced and self.distributed and self.reduce == "end":
             raise RuntimeError("totals already reduced over the ranks; call reset_totals() before submitting more bundles")
@@ -92,9 +95,9 @@ class BundlePipeline:
                               emit_seed=emit_seed, record_every=0, maxsteps=maxsteps,
                               max_events=max_events, emit_method=emit_method,
                               stream=stream.cuda_stream, workgroups_per_cu=4 if tail else self.workgroups_per_cu,
-                              carry_out=self.carry and not tail)
+                              carry_out=self.carry and not (tail or closing))
             if self.carry:
-                if tail:
+                if tail or closing:
                     self._parked.pop(k, None)   # a tail launch finishes what it resumed
                 else:
                     self._parked[k] = (maxsteps, max_events, emit_method)
@@ -219,7 +222,8 @@ def trace_stream(scene, num_rays, bundle, seed, emit_seed=0, maxsteps=1000, max_
                 n = min(bundle, num_rays - traced)
                 pipe.submit(None, n, seed=int(seed), ray_offset=traced, emit_seed=int(emit_seed),
                             maxsteps=maxsteps, max_events=max_events,
-                            emit_method=EMIT_METHODS[emit_method], timed=False, tail=traced + n >= num_rays)
+                            emit_method=EMIT_METHODS[emit_method], timed=False, tail=traced + n >= num_rays,
+                            closing=traced + n * depth >= num_rays)
                 traced += n
             data = pipe.totals_host()
             elapsed = time.perf_counter() - tic

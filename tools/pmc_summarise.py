@@ -15,6 +15,8 @@ if cfg != "cfg2":
     mode = f"{mode}_{cfg}"
 photons = 1_000_000
 sums = collections.defaultdict(list)
+launches = {}
+STEPS = 6   # tools/gpu_pmc.sh: --steps 6 --warmup 1
 kernel = None
 for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{mode}_*", "pmc_counter_collection.csv"))):
     rows = [r for r in csv.DictReader(open(path)) if "trace_kernel" in r["Kernel_Name"]]
@@ -23,8 +25,12 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{mode}_*", "
         per[r["Counter_Name"]].append(float(r["Counter_Value"]))
         kernel = r["Kernel_Name"]
     for name, vals in per.items():
+        # With photons carried between launches a launch finishes photons of its predecessors and the window ends
+        # with launches that take no new rays: the honest unit is the WINDOW -- every dispatch after the warm-up
+        # launch, divided by the steps of the window (6) -- not the single launch.
         vals = vals[1:] if len(vals) > 1 else vals           # drop the warm-up launch
-        sums[name] = sum(vals) / len(vals)
+        sums[name] = sum(vals) / STEPS
+        launches[name] = len(vals)
 c = dict(sums)
 read_b = c["FETCH_SIZE"] * 1024 * 2
 write_b = c["WRITE_SIZE"] * 1024
@@ -35,6 +41,8 @@ out = {
                + (" --streams 1" if mode.startswith("serial") else "") + " (one counter set per run; tools/gpu_pmc.sh " + mode.split("_")[0] + " " + cfg + "); "
                "rocprofv3 serialises dispatches while sampling counters",
     "kernel": kernel, "photons_per_launch": photons, "counters_mean_per_launch": c,
+    "counters_are": f"sums over the {max(launches.values()) if launches else 0} trace-kernel dispatches of the 6-step window "
+                    "(6 bundles + the launches that finish carried photons), divided by 6",
     "hbm_read_bytes_per_launch_corrected": read_b, "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
     "correction": "FETCH_SIZE doubled: gfx950 rocprofv3 reports 1/2 of a wide coalesced read stream "
