@@ -191,6 +191,16 @@ def load_pmc(name, value_per_gpu, cus):
             rate = per_photon * value_per_gpu
             side.update(valu_issue_rate_per_s=rate, valu_issue_peak_per_s=nominal, valu_issue_frac=rate / nominal,
                         valu_issue_achievable_per_s=achievable, valu_issue_frac_of_achievable=rate / achievable)
+            # VALU busy WHILE THE LAUNCHES OVERLAP: the instruction count per photon is a property of the work (PMC,
+            # the same whether dispatches are serialised or not), the photon rate is measured here, and the shader
+            # clock was measured inside overlapping launches (s_memtime against s_memrealtime in every wave,
+            # tools/gpu_clock_overlap.sh -> profiles/r03_c_clock_overlap.json) instead of assumed
+            clock = os.path.join(ROOT, "profiles", "r03_c_clock_overlap.json")
+            if os.path.exists(clock):
+                c = json.load(open(clock))
+                side["valu_busy_under_overlap"] = rate * 4.0 / (cus * 4 * c["shader_clock_mhz"] * 1e6)
+                side["shader_clock_mhz_measured_under_overlap"] = c["shader_clock_mhz"]
+                side["wave_slot_occupancy_measured_under_overlap"] = c["wave_slot_occupancy"]
         return summary.get("hbm_bytes_per_launch"), side
     except Exception:
         return None, None

@@ -67,6 +67,15 @@ int fail(int code, const std::string& msg) {
             return fail(PVT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+#if PVT_TIMELINE
+constexpr int kTlLaunches = 48, kTlWgs = 1024;
+constexpr size_t kTlBytes = (size_t)kTlLaunches * kTlWgs * kWaves * 8 * 8;
+unsigned long long* g_timeline = nullptr;
+int g_tl_launch = 0, g_tl_grid[kTlLaunches] = {0};
+long long g_tl_n[kTlLaunches] = {0};
+void timeline_dump();
+#endif
+
 template <class T>
 int push(std::vector<T>& blob, const T* src, size_t n) {
     int at = (int)blob.size();
@@ -586,6 +595,9 @@ int pvt_scene_set_emitter(PvtScene* s, const PvtEmitterTables* e) {
 
 void pvt_scene_destroy(PvtScene* s) {
     if (!s) return;
+#if PVT_TIMELINE
+    timeline_dump();
+#endif
     (void)hipSetDevice(s->device);
     if (s->d_gd) (void)hipFree(s->d_gd);
     if (s->d_gi) (void)hipFree(s->d_gi);
@@ -806,14 +818,17 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     }
 
 #if PVT_TIMELINE
-    static unsigned long long* g_timeline = nullptr;
-    const size_t tl_bytes = (size_t)8 * 8 * kWaves * 8192;
-    if (!g_timeline) (void)hipMalloc(&g_timeline, tl_bytes);
-    const char* tl_path = getenv("PVT_TIMELINE_FILE");
-    static int tl_launch = 0;
-    const int tl_from = getenv("PVT_TIMELINE_FROM") ? atoi(getenv("PVT_TIMELINE_FROM")) : 0;
-    const bool tl_on = tl_path && tl_launch >= tl_from && tl_launch < tl_from + 12 && grid <= 8192;
-    if (tl_on) { (void)hipMemsetAsync(g_timeline, 0, tl_bytes, st); a.timeline = g_timeline; }
+    // developer build: the first kTlLaunches launches after PVT_TIMELINE_FROM each get a region of the stamp buffer;
+    // nothing is synchronised (launches overlap as usual); pvt_timeline_dump() writes the file
+    if (getenv("PVT_TIMELINE_FILE")) {
+        if (!g_timeline) { (void)hipMalloc(&g_timeline, kTlBytes); (void)hipMemset(g_timeline, 0, kTlBytes); }
+        const int from = getenv("PVT_TIMELINE_FROM") ? atoi(getenv("PVT_TIMELINE_FROM")) : 0;
+        const int k = g_tl_launch++ - from;
+        if (k >= 0 && k < kTlLaunches && grid <= kTlWgs) {
+            a.timeline = g_timeline + (size_t)k * kTlWgs * kWaves * 8;
+            g_tl_grid[k] = (int)grid; g_tl_n[k] = p->n_rays;
+        }
+    }
 #endif
     const bool emit = rays == nullptr && s->d_ed != nullptr;
     hipError_t e;
@@ -825,20 +840,6 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
                     : launch_seen<false, false>(s->n_rec, emit, (int)grid, lds, st, a);
     }
     if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
-#if PVT_TIMELINE
-    if (tl_on) {   // (serialises the launches it records)
-        std::vector<unsigned long long> host((size_t)grid * kWaves * 8);
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(host.data(), g_timeline, host.size() * 8, hipMemcpyDeviceToHost);
-        if (FILE* fp = fopen(tl_path, "ab")) {
-            unsigned long long head[4] = {0xABCDull, (unsigned long long)tl_launch, (unsigned long long)grid, (unsigned long long)p->n_rays};
-            fwrite(head, 8, 4, fp);
-            fwrite(host.data(), 8, host.size(), fp);
-            fclose(fp);
-        }
-    }
-    tl_launch += 1;
-#endif
     if (!n_sets) carry.phase = (carry.phase + 1) % 3;
     if (carry_in || carry_out) {
         carry.pending = carry_out;
@@ -863,6 +864,25 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
 #endif
     return PVT_OK;
 }
+
+#if PVT_TIMELINE
+void timeline_dump() {
+    const char* path = getenv("PVT_TIMELINE_FILE");
+    if (!path || !g_timeline) return;
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> host(kTlBytes / 8);
+    (void)hipMemcpy(host.data(), g_timeline, kTlBytes, hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(path, "wb")) {
+        for (int k = 0; k < kTlLaunches; k++) {
+            if (!g_tl_grid[k]) continue;
+            unsigned long long head[4] = {0xABCDull, (unsigned long long)k, (unsigned long long)g_tl_grid[k], (unsigned long long)g_tl_n[k]};
+            fwrite(head, 8, 4, fp);
+            fwrite(host.data() + (size_t)k * kTlWgs * kWaves * 8, 8, (size_t)g_tl_grid[k] * kWaves * 8, fp);
+        }
+        fclose(fp);
+    }
+}
+#endif
 
 int unpack_launch(const unsigned long long* rows, const int* counts, long long n_recorded, int max_events,
                   const PvtEventLog* out, bool prefill, hipStream_t st) {

@@ -610,6 +610,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #if PVT_TIMELINE
     unsigned long long tl_t[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0};
     unsigned long long tl_iters = 0;
+    const unsigned long long tl_c0 = __builtin_readcyclecounter();   // shader clock (s_memtime); wall_clock64 is the constant 100 MHz one
 #endif
     const Lay L = A.lay;
     const bool coated = A.n_coat > 0;  // wave-uniform
@@ -1816,11 +1817,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     if (A.timeline && lane == 0) {
         unsigned long long* o = A.timeline + ((unsigned long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8;
         o[0] = tl_t[0]; o[1] = tl_t[1]; o[2] = tl_t[2]; o[3] = tl_t[3]; o[4] = wall_clock64(); o[5] = tl_iters;
-        unsigned int xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned int hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        o[6] = ((unsigned long long)xcc << 32) | hwid; o[7] = 1;
+        o[6] = __builtin_readcyclecounter() - tl_c0; o[7] = 1;
     }
 #endif
     tally_flush();   // the first crossings still parked

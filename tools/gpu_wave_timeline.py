@@ -1,27 +1,31 @@
-"""Developer tool: read the per-wave stamps a -DPVT_TIMELINE=1 build wrote (PVT_TIMELINE_FILE) and print, per launch,
-when workgroups started, when waves ran dry and when they ended (wall clock, 100 MHz)."""
+"""Developer tool: read the per-wave stamps a -DPVT_TIMELINE=1 build wrote (PVT_TIMELINE_FILE): per launch when
+workgroups started / ran dry / ended, and over all recorded launches the measured shader clock, the wave-slot
+occupancy and the iteration rate -- under whatever overlap the run had (nothing is serialised)."""
 import struct, sys
 import numpy as np
 data = open(sys.argv[1], "rb").read()
+verbose = len(sys.argv) > 2
 at = 0
+allw = []
 while at + 32 <= len(data):
     magic, launch, grid, n = struct.unpack_from("<4Q", data, at); at += 32
     assert magic == 0xABCD
     w = np.frombuffer(data, dtype=np.uint64, count=grid * 4 * 8, offset=at).reshape(grid * 4, 8).astype(np.int64); at += grid * 4 * 8 * 8
-    ok = w[:, 7] == 1
-    w = w[ok]
-    t0 = w[:, 0].min()
-    us = lambda c: (c - t0) / 100.0
-    start, staged, first, dry, end, iters = (w[:, k] for k in range(6))
-    def pct(x): return " ".join(f"{v:7.1f}" for v in np.percentile(us(x), [0, 5, 25, 50, 75, 95, 100]))
-    print(f"launch {launch} grid {grid} n {n}: waves {ok.sum()}  iterations/wave mean {iters.mean():.1f} (min {iters.min()}, max {iters.max()})")
-    print("   wave start      us [min p5 p25 p50 p75 p95 max]:", pct(start))
-    print("   tables staged   us                             :", pct(staged))
-    print("   first step      us                             :", pct(first))
-    d = dry[dry > 0]
-    if len(d): print("   cursor dry      us                             :", pct(d), f"({len(d)} waves)")
-    print("   wave end        us                             :", pct(end))
-    life = (end - start) / 100.0
-    print(f"   wave lifetime us: mean {life.mean():.1f} p5 {np.percentile(life,5):.1f} p95 {np.percentile(life,95):.1f}; "
-          f"us per iteration: {(life.sum() / max(iters.sum(),1)):.2f}; kernel span {us(end).max():.1f} us; "
-          f"sum(lifetimes)/(span x waves) = {life.sum() / (us(end).max() * len(life)):.3f}")
+    w = w[w[:, 7] == 1]
+    if len(w) == 0:
+        continue
+    allw.append(w)
+    if verbose:
+        t0 = w[:, 0].min()
+        us = lambda c: (c - t0) / 100.0
+        pct = lambda x: " ".join(f"{v:7.1f}" for v in np.percentile(us(x), [0, 5, 50, 95, 100]))
+        print(f"launch {launch} grid {grid} n {n}: waves {len(w)} iterations/wave {w[:,5].mean():.1f}; first step us [min p5 p50 p95 max] {pct(w[:,2])}; end {pct(w[:,4])}")
+w = np.concatenate(allw)
+start, end, iters, cyc = w[:, 0], w[:, 4], w[:, 5], w[:, 6]
+life_us = (end - start) / 100.0
+span_us = (end.max() - start.min()) / 100.0
+clock_mhz = cyc.sum() / life_us.sum()
+print(f"recorded launches {len(allw)}, waves {len(w)}, span {span_us:.1f} us")
+print(f"measured shader clock (s_memtime cycles per s_memrealtime microsecond, lifetime-weighted): {clock_mhz:.0f} MHz")
+print(f"wave-slot occupancy: sum of wave lifetimes / (span x 1024 SIMDs x 4 slots) = {life_us.sum() / (span_us * 4096):.3f}")
+print(f"wave-iterations {iters.sum()}  -> {iters.sum() / span_us:.1f} per us; mean {life_us.sum() / iters.sum():.2f} us per iteration per wave")
