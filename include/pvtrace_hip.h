@@ -146,7 +146,8 @@ typedef struct PvtSceneTables {
  * reference pvtrace/engine/emit.py:22-134).  Ray i is emitted by light
  * i % n_lights (scene.emit round-robin, scene/scene.py:141-151) from its own
  * RNG stream keyed by (emit_seed, global ray index).                        */
-enum { PVT_WL_CONSTANT = 0, PVT_WL_SPECTRUM = 1 };
+enum { PVT_WL_CONSTANT = 0, PVT_WL_SPECTRUM = 1,
+       PVT_WL_SPECTRUM_HIST = 2 /* histogram-sampled Distribution (material/distribution.py:171-176): x[#{cdf_i < u}], no interpolation */ };
 enum { PVT_POS_POINT = 0, PVT_POS_RECT = 1, PVT_POS_CIRCLE = 2, PVT_POS_CUBE = 3 };
 enum { PVT_DIR_Z = 0, PVT_DIR_CONE = 1, PVT_DIR_ISOTROPIC = 2, PVT_DIR_LAMBERTIAN = 3, PVT_DIR_HG = 4 };
 typedef struct PvtEmitterTables {

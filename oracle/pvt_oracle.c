@@ -829,6 +829,14 @@ static void emit_one(const PvtEmitterTables* E, const MathSel* M, uint64_t emit_
         double u = rng_uniform(&rng);
         *wl = interp_clamped(u, E->spec_cdf + E->wl_spec_start[li], E->spec_x + E->wl_spec_start[li],
                              E->wl_spec_n[li]);
+    } else if (E->wl_type[li] == PVT_WL_SPECTRUM_HIST) {
+        /* EXTENSION: histogram-sampled Distribution, pvtrace/material/distribution.py:171-176 --
+         * x[numpy.searchsorted(cdf, u)], the last abscissa when the index runs off the table */
+        double u = rng_uniform(&rng);
+        const double* cdf = E->spec_cdf + E->wl_spec_start[li];
+        int n = E->wl_spec_n[li], k = 0;
+        while (k < n && cdf[k] < u) k++;
+        *wl = E->spec_x[E->wl_spec_start[li] + (k < n ? k : n - 1)];
     } else {
         *wl = E->wl_value[li];
     }

@@ -416,10 +416,24 @@ __device__ __forceinline__ void emit_one(const KArgs& A, unsigned long long gi, 
     Rng rng;
     rng_seed(rng, (A.emit_seed + gi) ^ kEmitSalt);
     int li = (int)(gi % (unsigned long long)A.n_lights);
-    if (ei[E.wl_type + li] == PVT_WL_SPECTRUM) {
+    const int wt = ei[E.wl_type + li];
+    if (wt == PVT_WL_SPECTRUM || wt == PVT_WL_SPECTRUM_HIST) {
         double u = rng_uniform(rng);
         int s = ei[E.wl_spec_start + li];
-        wl = interp_global(ed + E.spec_cdf + s, ed + E.spec_x + s, ei[E.wl_spec_n + li], u);
+        const int n = ei[E.wl_spec_n + li];
+        if (wt == PVT_WL_SPECTRUM_HIST) {
+            // histogram-sampled spectrum: the abscissa at index #{cdf_i < u} (numpy.searchsorted, left), the last one
+            // when u lies above the table (pvtrace/material/distribution.py:171-176)
+            const double* cdf = ed + E.spec_cdf + s;
+            int lo = 0, hi = n;   // cdf[i] < u for i < lo, cdf[i] >= u for i >= hi
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] < u) lo = mid + 1; else hi = mid;
+            }
+            wl = ed[E.spec_x + s + (lo < n ? lo : n - 1)];
+        } else {
+            wl = interp_global(ed + E.spec_cdf + s, ed + E.spec_x + s, n, u);
+        }
     } else {
         wl = ed[E.wl_value + li];
     }

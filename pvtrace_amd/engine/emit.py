@@ -12,8 +12,9 @@ is lowered to a small `EmitterTables` record that either
 * the HIP emission kernel draws on the GPU from per-ray RNG streams, so a
   10^8-photon run never materialises a 5.6 GB host array.
 
-Unrecognised delegates keep working through the per-ray Python fallback
-(host mode only).
+A delegate that cannot be lowered (a lambda, a user function) keeps working in
+host mode: THAT delegate is called once per ray, the light's other delegates are
+still sampled vectorised and no Ray object is built per photon.
 """
 import functools
 
@@ -25,7 +26,7 @@ from pvtrace_amd import light as Lm
 from pvtrace_amd import material as Mm
 from pvtrace_amd.engine.compiler import UnsupportedSceneError
 
-WL_CONSTANT, WL_SPECTRUM = 0, 1
+WL_CONSTANT, WL_SPECTRUM, WL_SPECTRUM_HIST = 0, 1, 2
 POS_POINT, POS_RECT, POS_CIRCLE, POS_CUBE = 0, 1, 2, 3
 DIR_Z, DIR_CONE, DIR_ISOTROPIC, DIR_LAMBERTIAN, DIR_HG = 0, 1, 2, 3, 4
 
@@ -44,9 +45,15 @@ def classify_wavelength(d):
         return (WL_CONSTANT, 555.0, None)
     if isinstance(d, Lm.ConstantWavelengthMask):
         return (WL_CONSTANT, float(d.nanometers), None)
-    if isinstance(d, Lm.SpectrumWavelengthMask) and not d.distribution.hist \
-            and d.distribution._x is not None:
-        return (WL_SPECTRUM, 0.0, d.distribution)
+    dist = None
+    if isinstance(d, Lm.SpectrumWavelengthMask):
+        dist = d.distribution
+    elif getattr(d, "__func__", None) is Lm.SpectrumWavelengthMask.__call__:
+        dist = d.__self__.distribution          # the bound `mask.__call__`
+    if dist is not None:
+        if dist._x is None:     # a constant "distribution"
+            return (WL_CONSTANT, float(dist._y), None)
+        return (WL_SPECTRUM_HIST if dist.hist else WL_SPECTRUM, 0.0, dist)
     return None
 
 
@@ -110,6 +117,9 @@ class EmitterTables:
         self.dir_param = np.zeros(n, dtype=np.float64)
         self.light_to_world = np.zeros((n, 4, 4), dtype=np.float64)
         self.builtin = np.ones(n, dtype=bool)
+        # delegates the tables cannot express, per light: {"wavelength" | "position" | "direction": callable};
+        # the host sampler calls those once per ray and still samples the light's other delegates vectorised
+        self.custom = [dict() for _ in range(n)]
         sx, sc = [], []
         for i, node in enumerate(nodes):
             light = node.light
@@ -124,7 +134,15 @@ class EmitterTables:
                         "emission needs built-in wavelength/position/direction delegates."
                     )
                 self.builtin[i] = False
-                continue
+                if w is None:
+                    self.custom[i]["wavelength"] = light.wavelength
+                    w = (WL_CONSTANT, 0.0, None)
+                if p is None:
+                    self.custom[i]["position"] = light.position
+                    p = (POS_POINT, (0.0, 0.0, 0.0))
+                if d is None:
+                    self.custom[i]["direction"] = light.direction
+                    d = (DIR_Z, 0.0)
             self.wl_type[i], self.wl_value[i], dist = w
             if dist is not None:
                 self.wl_spec_start[i] = len(sx)
@@ -201,6 +219,9 @@ def _sample_light(tab, i, n, uniform):
     if tab.wl_type[i] == WL_SPECTRUM:
         s, m = tab.wl_spec_start[i], tab.wl_spec_n[i]
         wl = np.interp(uniform(n), tab.spec_cdf[s:s + m], tab.spec_x[s:s + m])
+    elif tab.wl_type[i] == WL_SPECTRUM_HIST:    # Distribution.sample, hist branch: x[searchsorted(cdf, p)]
+        s, m = tab.wl_spec_start[i], tab.wl_spec_n[i]
+        wl = tab.spec_x[s:s + m][np.minimum(np.searchsorted(tab.spec_cdf[s:s + m], uniform(n)), m - 1)]
     else:
         wl = np.full(n, tab.wl_value[i])
     pp = tab.pos_param[i]
@@ -258,16 +279,23 @@ def emit_bundle(scene, num_rays, seed=None):
         count = len(range(i, num_rays, tab.n_lights))
         if count == 0:
             continue
-        if not tab.builtin[i]:
-            # unknown delegate: one Python call per ray (uses global np.random)
-            for row, ray in zip(range(i, num_rays, tab.n_lights), node.emit(count)):
-                world = ray.representation(node, scene.root)
-                positions[row] = world.position
-                directions[row] = world.direction
-                wavelengths[row] = world.wavelength
-                sources[row] = world.source
-            continue
         pos, direc, wl = _sample_light(tab, i, count, uniform)
+        if not tab.builtin[i]:
+            # A delegate the tables cannot express (a lambda, a user function) is called once per ray, as the
+            # reference does for the whole light (pvtrace/engine/emit.py:116-124, via Light.emit) -- but only
+            # THAT delegate: the light's recognised delegates were sampled vectorised above, no Ray object is
+            # built per photon and the change of frame below is one matrix product for the whole bundle.
+            custom = tab.custom[i]
+            if "wavelength" in custom:
+                call = custom["wavelength"]
+                wl = np.fromiter((call() for _ in range(count)), dtype=np.float64, count=count)
+            if "position" in custom:
+                call = custom["position"]
+                pos = np.array([tuple(call()) for _ in range(count)], dtype=np.float64).reshape(count, 3)
+            if "direction" in custom:
+                call = custom["direction"]
+                direc = np.array([tuple(np.asarray(call()).tolist()) for _ in range(count)],
+                                 dtype=np.float64).reshape(count, 3)
         m = tab.light_to_world[i]
         positions[rows] = _to_world(pos, m, translate=True)
         directions[rows] = _to_world(direc, m, translate=False)

@@ -329,6 +329,20 @@ def hist_slab():
     return Scene(world)
 
 
+def hist_lamp():
+    """hist_slab lit by two lamps, one of them with a HISTOGRAM-sampled spectrum (PVT_WL_SPECTRUM_HIST)."""
+    scene = hist_slab()
+    world = scene.root
+    lines = Distribution(np.array([405.0, 436.0, 492.0, 546.0, 578.0, 615.0]), np.array([1.0, 3.0, 0.0, 4.0, 2.0, 0.5]),
+                         hist=True)
+    lamp = Node(name="line-lamp", parent=world,
+                light=Light(wavelength=SpectrumWavelengthMask(lines), position=CircularMask(1.5),
+                            direction=Cone(0.2), name="line-lamp"))
+    lamp.location = (0.5, -0.5, 5.0)
+    lamp.rotate(np.pi, (1, 0, 0))
+    return Scene(world)
+
+
 def mesh_lsc():
     """lsc_equivalent with the slab given as a 12-triangle mesh: must behave like the analytic
     box (same events; positions to ~1e-13 cm)."""
@@ -417,6 +431,7 @@ EXTENSION_SCENES = {   # need an extension: coatings, hist spectra, meshes
     "l_prism": l_prism,
     "lambertian_sheet": lambertian_sheet,
     "hist_slab": hist_slab,
+    "hist_lamp": hist_lamp,
     "mesh_lsc": mesh_lsc,
     "mesh_gem": mesh_gem,
 }

@@ -264,7 +264,7 @@ def test_streamed_bundles_equal_one_call():
     assert np.allclose(acc["rec_sums"], whole["rec_sums"], rtol=1e-11)
 
 
-@pytest.mark.parametrize("name", ["kitchen_sink", "lsc_equivalent", "coated_slab", "lambertian_sheet"])
+@pytest.mark.parametrize("name", ["kitchen_sink", "lsc_equivalent", "coated_slab", "lambertian_sheet", "hist_lamp"])
 def test_device_emission_matches_oracle_emitter(name):
     scene = scenes.ALL_SCENES[name]()
     compiled = compile_scene(scene)
