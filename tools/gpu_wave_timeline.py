@@ -19,7 +19,9 @@ while at + 32 <= len(data):
         t0 = w[:, 0].min()
         us = lambda c: (c - t0) / 100.0
         pct = lambda x: " ".join(f"{v:7.1f}" for v in np.percentile(us(x), [0, 5, 50, 95, 100]))
-        print(f"launch {launch} grid {grid} n {n}: waves {len(w)} iterations/wave {w[:,5].mean():.1f}; first step us [min p5 p50 p95 max] {pct(w[:,2])}; end {pct(w[:,4])}")
+        mhz = w[:, 6].sum() / ((w[:, 4] - w[:, 0]).sum() / 100.0)
+        print(f"launch {launch} grid {grid} n {n}: waves {len(w)} iterations/wave {w[:,5].mean():.1f}; shader clock {mhz:.0f} MHz; "
+              f"first step us [min p5 p50 p95 max] {pct(w[:,2])}; end {pct(w[:,4])}")
 w = np.concatenate(allw)
 start, end, iters, cyc = w[:, 0], w[:, 4], w[:, 5], w[:, 6]
 life_us = (end - start) / 100.0
