@@ -312,8 +312,9 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
  * pvt_shard_range(n_rays, g, n_devices, record_every) with ray_offset advanced accordingly, so every ray
  * keeps the RNG stream seed + ray_offset + global index and the result does not depend on the device
  * list.  One host thread, one resident scene and one stream per entry of `devices` (an id may appear
- * several times: its shards then share that GPU).  Integer tallies are summed exactly, the f64 moment
- * sums in shard order; each shard writes the rows of its own rays into the caller's event log (inner shard
+ * several times: its shards then share that GPU).  The tallies are summed on the devices (RCCL over
+ * xGMI) when the entries are different GPUs, else on the host: integer tallies exactly, the f64 moment sums up to
+ * the order of addition; each shard writes the rows of its own rays into the caller's event log (inner shard
  * boundaries are multiples of record_every, so the shards' logs together ARE the single-device log).
  * `kernel_ms` (nullable) receives the longest shard's kernel time.  The reference splits a bundle over
  * OpenMP threads instead (_kernel.pyx:1074-1095); there as here the output is independent of the split. */
@@ -321,6 +322,11 @@ int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables*
                            const PvtRays* rays, const PvtTraceParams* params,
                            const PvtTallies* tallies, const PvtEventLog* log,
                            const int* devices, int n_devices, double* kernel_ms);
+
+/* How the last pvt_trace_bundle_multi of THIS thread summed the shards' tallies: 0 none yet, 1 on the host,
+ * 2 on the devices with RCCL (ncclCommInitAll over the device list, ncclReduce to the first shard; taken when every
+ * entry of the list is a different GPU and librccl can be loaded; PVT_MULTI_REDUCE=host|rccl overrides). */
+int pvt_last_multi_reduce(void);
 
 /* [start, stop) of shard `shard` of `n_shards` over n_rays rays; inner boundaries are rounded down to
  * multiples of `align` (pass record_every; <= 1 means no alignment).  Pure host arithmetic. */

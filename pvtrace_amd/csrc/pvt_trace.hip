@@ -40,6 +40,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <thread>
 #include <mutex>
@@ -1088,114 +1089,231 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
     return PVT_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+thread_local int g_last_multi_reduce = 0;   // 0 none yet, 1 host sum, 2 RCCL on the devices (pvt_last_multi_reduce)
+
+// RCCL, loaded at run time (no link dependency: a process that already holds an RCCL -- PyTorch's -- keeps using
+// that copy): ncclReduce of `counts[k]` elements of bufs[k][r] (rank r = entry r of `devs`) into rank 0, all in
+// one group.  false + `why` when the library or a call is unavailable; the caller then sums on the host.
+bool rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*> (&bufs)[4], const size_t (&counts)[4],
+                          const bool (&is_f64)[4], std::string* why) {
+    typedef int (*InitAll)(void**, int, const int*);
+    typedef int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+    typedef int (*Void)();
+    typedef int (*Destroy)(void*);
+    static void* lib = nullptr;
+    static InitAll init_all = nullptr; static Reduce reduce = nullptr; static Void group_start = nullptr, group_end = nullptr;
+    static Destroy destroy = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!lib) {
+        const char* names[] = {getenv("PVT_RCCL_LIB"), "librccl.so", "librccl.so.1"};
+        for (const char* nm : names) if (nm && !lib) lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // a copy already mapped
+        for (const char* nm : names) if (nm && !lib) lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { *why = std::string("dlopen(librccl): ") + dlerror(); return false; }
+        init_all = (InitAll)dlsym(lib, "ncclCommInitAll"); reduce = (Reduce)dlsym(lib, "ncclReduce");
+        group_start = (Void)dlsym(lib, "ncclGroupStart"); group_end = (Void)dlsym(lib, "ncclGroupEnd");
+        destroy = (Destroy)dlsym(lib, "ncclCommDestroy");
+    }
+    if (!init_all || !reduce || !group_start || !group_end || !destroy) { *why = "RCCL symbols missing"; return false; }
+    const int n = (int)devs.size();
+    std::vector<void*> comms((size_t)n, nullptr);
+    if (int e = init_all(comms.data(), n, devs.data())) { *why = "ncclCommInitAll failed with " + std::to_string(e); return false; }
+    bool ok = true;
+    constexpr int kInt64 = 4, kFloat64 = 8, kSum = 0;   // rccl.h: ncclInt64, ncclFloat64, ncclSum
+    if (group_start()) ok = false;
+    for (int k = 0; k < 4 && ok; k++) {
+        if (!counts[k]) continue;
+        for (int r = 0; r < n && ok; r++) {
+            (void)hipSetDevice(devs[(size_t)r]);
+            if (reduce(bufs[k][(size_t)r], bufs[k][(size_t)r], counts[k], is_f64[k] ? kFloat64 : kInt64, kSum, 0, comms[(size_t)r], nullptr)) ok = false;
+        }
+    }
+    if (group_end()) ok = false;
+    for (int r = 0; r < n; r++) {
+        (void)hipSetDevice(devs[(size_t)r]);
+        if (hipStreamSynchronize(nullptr) != hipSuccess) ok = false;
+    }
+    for (void* c : comms) if (c) destroy(c);
+    if (!ok) *why = "an RCCL call failed";
+    return ok;
+}
+
+// One host-buffer bundle on one device, in phases (pvt_trace_bundle runs them back to back; pvt_trace_bundle_multi
+// runs one per device and can sum the tallies on the devices in between): upload + trace, fetch the tallies, fetch
+// the event log.
+struct HostBundle {
+    PvtScene* scene = nullptr;
+    std::vector<void*> bufs;
+    const PvtSceneTables* tables;
+    const PvtTraceParams* p;
+    size_t nR, nB, R, B, n_sets, si, sd;
+    void *t_i[3] = {nullptr, nullptr, nullptr}, *t_d = nullptr;   // distinct | crossings | bins, sums (device)
+    unsigned long long* rows = nullptr;                             // event records (device)
+    int* counts = nullptr;
+    size_t nrec = 0;
+    double ms = 0.0;
+
+    ~HostBundle() {
+        if (scene) (void)hipSetDevice(scene->device);
+        for (void* b : bufs) (void)hipFree(b);
+        if (scene) pvt_scene_destroy(scene);
+    }
+    hipError_t dalloc(size_t bytes, void** out) {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+        if (e == hipSuccess) bufs.push_back(*out);
+        return e;
+    }
+    hipError_t move(void* dst, const void* src, size_t pitch_elems, size_t width_elems, hipMemcpyKind kind) const {
+        if (width_elems == 0) return hipSuccess;
+        if (n_sets == 1) return hipMemcpy(dst, src, width_elems * 8, kind);
+        return hipMemcpy2D(dst, pitch_elems * 8, src, pitch_elems * 8, width_elems * 8, n_sets, kind);
+    }
+
+    // scene + rays + tallies (seeded with `seed`, or zero) on `device`, trace enqueued and finished
+    int trace(const PvtSceneTables* tb, const PvtEmitterTables* emitter, const PvtRays* rays, const PvtTraceParams* pp,
+              const PvtTallies* seed, bool want_log, int device) {
+        tables = tb; p = pp;
+        int rc = pvt_scene_create(tables, device, &scene);
+        if (rc != PVT_OK) return rc;
+        if (emitter) {
+            rc = pvt_scene_set_emitter(scene, emitter);
+            if (rc != PVT_OK) return rc;
+        }
+        const size_t n = (size_t)p->n_rays;
+        nR = (size_t)tables->n_recorders; nB = (size_t)tables->total_bins;
+        R = nR > 0 ? nR : 1; B = nB > 0 ? nB : 1;
+        PvtRays drays{};
+        if (rays) {
+            void *dp, *dd, *dw;
+            HIP_TRY(dalloc(n * 24, &dp)); HIP_TRY(dalloc(n * 24, &dd)); HIP_TRY(dalloc(n * 8, &dw));
+            HIP_TRY(hipMemcpy(dp, rays->position, n * 24, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dd, rays->direction, n * 24, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dw, rays->wavelength, n * 8, hipMemcpyHostToDevice));
+            drays = PvtRays{(const double*)dp, (const double*)dd, (const double*)dw};
+        }
+        // tally sets (PvtTraceParams.tally_bundle): the device copies keep the caller's strides, slices move as
+        // 2-D copies (one row per set)
+        n_sets = p->tally_bundle > 0 ? (size_t)((p->n_rays + p->tally_bundle - 1) / p->tally_bundle) : 1;
+        si = n_sets > 1 ? (size_t)p->tally_stride_i64 : 0; sd = n_sets > 1 ? (size_t)p->tally_stride_f64 : 0;
+        if (n_sets > 1 && (si < R || si < B || sd < R * 8)) return fail(PVT_ERR_INVALID, "tally strides smaller than a set");
+        const size_t bytes_i[3] = {((n_sets - 1) * si + R) * 8, ((n_sets - 1) * si + R) * 8, ((n_sets - 1) * si + B) * 8};
+        for (int k = 0; k < 3; k++) { HIP_TRY(dalloc(bytes_i[k], &t_i[k])); HIP_TRY(hipMemset(t_i[k], 0, bytes_i[k])); }
+        HIP_TRY(dalloc(((n_sets - 1) * sd + R * 8) * 8, &t_d));
+        HIP_TRY(hipMemset(t_d, 0, ((n_sets - 1) * sd + R * 8) * 8));
+        if (seed) {   // the trace ADDS into the caller's tallies: seed the device copies with them
+            HIP_TRY(move(t_i[0], seed->rec_distinct, si, nR, hipMemcpyHostToDevice));
+            HIP_TRY(move(t_i[1], seed->rec_crossings, si, nR, hipMemcpyHostToDevice));
+            HIP_TRY(move(t_d, seed->rec_sums, sd, nR * 8, hipMemcpyHostToDevice));
+            HIP_TRY(move(t_i[2], seed->rec_bins, si, nB, hipMemcpyHostToDevice));
+        }
+        PvtTallies dt{(int64_t*)t_i[0], (int64_t*)t_i[1], (double*)t_d, (int64_t*)t_i[2]};
+        PvtEventRecords rec{};
+        if (p->record_every > 0) {
+            if (!want_log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+            nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
+            void *b0, *b1;
+            HIP_TRY(dalloc(nrec * 4, &b0));
+            HIP_TRY(dalloc(nrec * (size_t)p->max_events * kRecWords * 8, &b1));
+            counts = (int*)b0; rows = (unsigned long long*)b1;
+            rec = PvtEventRecords{counts, reinterpret_cast<uint64_t*>(rows)};
+        }
+        hipEvent_t ev0, ev1;
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, nullptr));
+        rc = pvt_trace_device_records(scene, rays ? &drays : nullptr, p, &dt, p->record_every > 0 ? &rec : nullptr, nullptr);
+        if (rc != PVT_OK) return rc;
+        HIP_TRY(hipEventRecord(ev1, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ev0, ev1));
+        ms = t;
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        return PVT_OK;
+    }
+
+    int fetch_tallies(const PvtTallies* out) {
+        HIP_TRY(hipSetDevice(scene->device));
+        HIP_TRY(move(out->rec_distinct, t_i[0], si, nR, hipMemcpyDeviceToHost));
+        HIP_TRY(move(out->rec_crossings, t_i[1], si, nR, hipMemcpyDeviceToHost));
+        HIP_TRY(move(out->rec_sums, t_d, sd, nR * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(move(out->rec_bins, t_i[2], si, nB, hipMemcpyDeviceToHost));
+        return PVT_OK;
+    }
+
+    // The event log: the caller's column arrays get the reference's fill values on the host (memset / fill), the
+    // records the rays wrote cross PCIe PACKED -- `counts[j]` rows of recorded ray j, gathered on the device -- and
+    // are scattered into the columns by this thread.  (Moving the dense columns costs 117 bytes x max_events per
+    // recorded ray over PCIe, of which a ray writes a dozen rows: 15 GB for the reference's README case.)
+    int fetch_log(const PvtEventLog* log) {
+        if (!(p->record_every > 0)) return PVT_OK;
+        HIP_TRY(hipSetDevice(scene->device));
+        const size_t me = (size_t)p->max_events, total_rows = nrec * me;
+        HIP_TRY(hipMemcpy(log->counts, counts, nrec * 4, hipMemcpyDeviceToHost));
+        std::vector<long long> first(nrec + 1, 0);
+        for (size_t j = 0; j < nrec; j++) first[j + 1] = first[j] + log->counts[j];
+        const size_t used = (size_t)first[nrec];
+        std::memset(log->kind, 0, total_rows);
+        std::memset(log->hit, 0xFF, total_rows * 4); std::memset(log->container, 0xFF, total_rows * 4);
+        std::memset(log->adjacent, 0xFF, total_rows * 4); std::memset(log->component, 0xFF, total_rows * 4);
+        std::memset(log->source, 0xFF, total_rows * 4);
+        std::memset(log->position, 0, total_rows * 24); std::memset(log->direction, 0, total_rows * 24);
+        std::memset(log->normal, 0, total_rows * 24);
+        std::memset(log->wavelength, 0, total_rows * 8); std::memset(log->travelled, 0, total_rows * 8);
+        std::memset(log->duration, 0, total_rows * 8);
+        if (!used) return PVT_OK;
+        void *d_first, *d_packed;
+        HIP_TRY(dalloc((nrec + 1) * 8, &d_first));
+        HIP_TRY(dalloc(used * kRecWords * 8, &d_packed));
+        HIP_TRY(hipMemcpy(d_first, first.data(), (nrec + 1) * 8, hipMemcpyHostToDevice));
+        const int rays_per_block = me >= (size_t)kBlock ? 1 : (int)((size_t)kBlock / me);
+        const long long gx = ((long long)nrec + rays_per_block - 1) / rays_per_block;
+        const int gy = rays_per_block > 1 ? 1 : (int)((me + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(pack_log_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, nullptr, rows, counts,
+                           (const long long*)d_first, (unsigned long long*)d_packed, (long long)nrec, (int)me, rays_per_block);
+        HIP_TRY(hipGetLastError());
+        std::vector<unsigned long long> packed(used * kRecWords);
+        HIP_TRY(hipMemcpy(packed.data(), d_packed, used * kRecWords * 8, hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < nrec; j++) {
+            const unsigned long long* r = packed.data() + (size_t)first[j] * kRecWords;
+            size_t row = j * me;
+            for (int k = 0; k < log->counts[j]; k++, r += kRecWords, row++) {
+                log->hit[row] = (int32_t)(uint32_t)r[0]; log->container[row] = (int32_t)(uint32_t)(r[0] >> 32);
+                log->adjacent[row] = (int32_t)(uint32_t)r[1]; log->component[row] = (int32_t)(uint32_t)(r[1] >> 32);
+                log->source[row] = (int32_t)(uint32_t)r[2]; log->kind[row] = (uint8_t)(r[2] >> 32);
+                std::memcpy(log->position + 3 * row, r + 3, 24);
+                std::memcpy(log->direction + 3 * row, r + 6, 24);
+                std::memcpy(log->normal + 3 * row, r + 9, 24);
+                std::memcpy(log->wavelength + row, r + 12, 8);
+                std::memcpy(log->travelled + row, r + 13, 8);
+                std::memcpy(log->duration + row, r + 14, 8);
+            }
+        }
+        return PVT_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
 // Host-buffer entry: the literal stand-in for _kernel.trace_bundle.
 int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitter, const PvtRays* rays,
                      const PvtTraceParams* p, const PvtTallies* tl, const PvtEventLog* log, int device,
                      double* kernel_ms) {
     if (!tables || !p || !tl) return fail(PVT_ERR_INVALID, "null argument");
-    PvtScene* s = nullptr;
-    int rc = pvt_scene_create(tables, device, &s);
+    HostBundle hb;
+    int rc = hb.trace(tables, emitter, rays, p, tl, log != nullptr, device);
     if (rc != PVT_OK) return rc;
-    struct Guard {
-        PvtScene* s;
-        std::vector<void*> bufs;
-        ~Guard() {
-            for (void* b : bufs) (void)hipFree(b);
-            pvt_scene_destroy(s);
-        }
-    } g{s, {}};
-    if (emitter) {
-        rc = pvt_scene_set_emitter(s, emitter);
-        if (rc != PVT_OK) return rc;
-    }
-    auto dalloc = [&](size_t bytes, void** out) -> hipError_t {
-        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
-        if (e == hipSuccess) g.bufs.push_back(*out);
-        return e;
-    };
-    const size_t n = (size_t)p->n_rays;
-    const size_t R = (size_t)(tables->n_recorders > 0 ? tables->n_recorders : 1);
-    const size_t B = (size_t)(tables->total_bins > 0 ? tables->total_bins : 1);
-    PvtRays drays{};
-    if (rays) {
-        void *dp, *dd, *dw;
-        HIP_TRY(dalloc(n * 24, &dp)); HIP_TRY(dalloc(n * 24, &dd)); HIP_TRY(dalloc(n * 8, &dw));
-        HIP_TRY(hipMemcpy(dp, rays->position, n * 24, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dd, rays->direction, n * 24, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dw, rays->wavelength, n * 8, hipMemcpyHostToDevice));
-        drays = PvtRays{(const double*)dp, (const double*)dd, (const double*)dw};
-    }
-    // tally sets (PvtTraceParams.tally_bundle): the device copies keep the caller's strides, slices move as
-    // 2-D copies (one row per set)
-    const size_t n_sets = p->tally_bundle > 0 ? (size_t)((p->n_rays + p->tally_bundle - 1) / p->tally_bundle) : 1;
-    const size_t si = n_sets > 1 ? (size_t)p->tally_stride_i64 : 0, sd = n_sets > 1 ? (size_t)p->tally_stride_f64 : 0;
-    if (n_sets > 1 && (si < R || si < B || sd < R * 8)) return fail(PVT_ERR_INVALID, "tally strides smaller than a set");
-    const size_t nR = (size_t)tables->n_recorders, nB = (size_t)tables->total_bins;
-    PvtTallies dt{};
-    void *t0, *t1, *t2, *t3;
-    HIP_TRY(dalloc(((n_sets - 1) * si + R) * 8, &t0)); HIP_TRY(dalloc(((n_sets - 1) * si + R) * 8, &t1));
-    HIP_TRY(dalloc(((n_sets - 1) * sd + R * 8) * 8, &t2)); HIP_TRY(dalloc(((n_sets - 1) * si + B) * 8, &t3));
-    auto move = [&](void* dst, const void* src, size_t pitch_elems, size_t width_elems, hipMemcpyKind kind) -> hipError_t {
-        if (width_elems == 0) return hipSuccess;
-        if (n_sets == 1) return hipMemcpy(dst, src, width_elems * 8, kind);
-        return hipMemcpy2D(dst, pitch_elems * 8, src, pitch_elems * 8, width_elems * 8, n_sets, kind);
-    };
-    // the trace ADDS into the caller's tallies: seed the device copies with them
-    HIP_TRY(move(t0, tl->rec_distinct, si, nR, hipMemcpyHostToDevice));
-    HIP_TRY(move(t1, tl->rec_crossings, si, nR, hipMemcpyHostToDevice));
-    HIP_TRY(move(t2, tl->rec_sums, sd, nR * 8, hipMemcpyHostToDevice));
-    HIP_TRY(move(t3, tl->rec_bins, si, nB, hipMemcpyHostToDevice));
-    dt = PvtTallies{(int64_t*)t0, (int64_t*)t1, (double*)t2, (int64_t*)t3};
-
-    PvtEventLog dl{};
-    size_t nrec = 0, rows = 0;
-    const bool record = p->record_every > 0;
-    if (record) {
-        if (!log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
-        nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
-        rows = nrec * (size_t)p->max_events;
-        void* b[13];
-        const size_t sz[13] = {nrec * 4, rows, rows * 4, rows * 4, rows * 4, rows * 4, rows * 4,
-                               rows * 24, rows * 24, rows * 24, rows * 8, rows * 8, rows * 8};
-        for (int i = 0; i < 13; i++) HIP_TRY(dalloc(sz[i], &b[i]));
-        dl = PvtEventLog{(int32_t*)b[0], (uint8_t*)b[1], (int32_t*)b[2], (int32_t*)b[3], (int32_t*)b[4],
-                         (int32_t*)b[5], (int32_t*)b[6], (double*)b[7], (double*)b[8], (double*)b[9],
-                         (double*)b[10], (double*)b[11], (double*)b[12]};
-    }
-    hipEvent_t ev0, ev1;
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventRecord(ev0, nullptr));
-    rc = pvt_trace_device(s, rays ? &drays : nullptr, p, &dt, record ? &dl : nullptr, nullptr);
+    if (kernel_ms) *kernel_ms = hb.ms;
+    rc = hb.fetch_tallies(tl);
     if (rc != PVT_OK) return rc;
-    HIP_TRY(hipEventRecord(ev1, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    if (kernel_ms) *kernel_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-
-    HIP_TRY(move(tl->rec_distinct, t0, si, nR, hipMemcpyDeviceToHost));
-    HIP_TRY(move(tl->rec_crossings, t1, si, nR, hipMemcpyDeviceToHost));
-    HIP_TRY(move(tl->rec_sums, t2, sd, nR * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(move(tl->rec_bins, t3, si, nB, hipMemcpyDeviceToHost));
-    if (record) {
-        HIP_TRY(hipMemcpy(log->counts, dl.counts, nrec * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->kind, dl.kind, rows, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->hit, dl.hit, rows * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->container, dl.container, rows * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->adjacent, dl.adjacent, rows * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->component, dl.component, rows * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->source, dl.source, rows * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->position, dl.position, rows * 24, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->direction, dl.direction, rows * 24, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->normal, dl.normal, rows * 24, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->wavelength, dl.wavelength, rows * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->travelled, dl.travelled, rows * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(log->duration, dl.duration, rows * 8, hipMemcpyDeviceToHost));
-    }
-    return PVT_OK;
+    return hb.fetch_log(log);
 }
 
 int pvt_shard_range(int64_t n_rays, int shard, int n_shards, int64_t align, int64_t* start, int64_t* stop) {
@@ -1222,62 +1340,116 @@ int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables*
     const int ndev = pvt_device_count();
     for (int g = 0; g < n_devices; g++)
         if (devices[g] < 0 || devices[g] >= ndev) return fail(PVT_ERR_NO_DEVICE, "no such HIP device in the device list");
-    if (n_devices == 1) return pvt_trace_bundle(tables, emitter, rays, p, tl, log, devices[0], kernel_ms);
+    const char* how = getenv("PVT_MULTI_REDUCE");   // "host": never RCCL; "rccl": also for a single device (self-test)
+    const bool force_rccl = how && std::string(how) == "rccl", never_rccl = how && std::string(how) == "host";
+    if (n_devices == 1 && !force_rccl) return pvt_trace_bundle(tables, emitter, rays, p, tl, log, devices[0], kernel_ms);
     // the shards below own ONE tally set each (R / B / R*8 elements) and shard edges ignore bundle boundaries
     if (p->tally_bundle > 0)
         return fail(PVT_ERR_INVALID, "tally_bundle is not supported over a device list; trace the group on one device");
 
-    const size_t R = (size_t)(tables->n_recorders > 0 ? tables->n_recorders : 1);
-    const size_t B = (size_t)(tables->total_bins > 0 ? tables->total_bins : 1);
+    const size_t nR = (size_t)tables->n_recorders, nB = (size_t)tables->total_bins;
     struct Shard {
         int rc = PVT_OK;
         std::string error;
-        double ms = 0.0;
-        std::vector<int64_t> distinct, crossings, bins;
-        std::vector<double> sums;
+        bool traced = false;
+        HostBundle hb;
     };
     std::vector<Shard> shards((size_t)n_devices);
-    std::vector<std::thread> workers;
-    for (int g = 0; g < n_devices; g++) {
-        workers.emplace_back([&, g]() {
-            Shard& sh = shards[(size_t)g];
-            int64_t start = 0, stop = 0;
-            sh.rc = pvt_shard_range(p->n_rays, g, n_devices, p->record_every, &start, &stop);
-            if (sh.rc == PVT_OK && stop > start) {
-                sh.distinct.assign(R, 0); sh.crossings.assign(R, 0); sh.bins.assign(B, 0); sh.sums.assign(R * 8, 0.0);
-                PvtTraceParams q = *p;
-                q.n_rays = stop - start;
-                q.ray_offset = p->ray_offset + (uint64_t)start;
-                PvtRays r{};
-                if (rays) r = PvtRays{rays->position + 3 * start, rays->direction + 3 * start, rays->wavelength + start};
-                PvtTallies t{sh.distinct.data(), sh.crossings.data(), sh.sums.data(), sh.bins.data()};
-                PvtEventLog l{};
-                if (p->record_every > 0) {   // the shard's recorded rays start at global slot start / record_every
-                    const int64_t j0 = start / p->record_every, row0 = j0 * p->max_events;
-                    l = PvtEventLog{log->counts + j0, log->kind + row0, log->hit + row0, log->container + row0,
-                                    log->adjacent + row0, log->component + row0, log->source + row0,
-                                    log->position + 3 * row0, log->direction + 3 * row0, log->normal + 3 * row0,
-                                    log->wavelength + row0, log->travelled + row0, log->duration + row0};
-                }
-                sh.rc = pvt_trace_bundle(tables, emitter, rays ? &r : nullptr, &q, &t, p->record_every > 0 ? &l : nullptr,
-                                         devices[g], &sh.ms);
+    auto parallel = [&](auto&& body) {   // one host thread per device-list entry
+        std::vector<std::thread> workers;
+        for (int g = 0; g < n_devices; g++)
+            workers.emplace_back([&, g]() {
+                Shard& sh = shards[(size_t)g];
+                if (sh.rc == PVT_OK) sh.rc = body(sh, g);
+                if (sh.rc != PVT_OK && sh.error.empty()) sh.error = g_error;   // thread-local: carry it to the caller's thread
+            });
+        for (auto& w : workers) w.join();
+    };
+    auto first_error = [&]() -> int {
+        for (int g = 0; g < n_devices; g++)
+            if (shards[(size_t)g].rc != PVT_OK)
+                return fail(shards[(size_t)g].rc, "shard " + std::to_string(g) + " on device " + std::to_string(devices[g]) + ": " + shards[(size_t)g].error);
+        return PVT_OK;
+    };
+    // 1. every shard: its own scene, rays, zeroed tallies and event records on its device; traced to completion
+    parallel([&](Shard& sh, int g) -> int {
+        int64_t start = 0, stop = 0;
+        int rc = pvt_shard_range(p->n_rays, g, n_devices, p->record_every, &start, &stop);
+        if (rc != PVT_OK || stop <= start) return rc;
+        PvtTraceParams q = *p;
+        q.n_rays = stop - start;
+        q.ray_offset = p->ray_offset + (uint64_t)start;
+        PvtRays r{};
+        if (rays) r = PvtRays{rays->position + 3 * start, rays->direction + 3 * start, rays->wavelength + start};
+        // (the shard's params must outlive the bundle: keep a copy inside it)
+        sh.traced = true;
+        return sh.hb.trace(tables, emitter, rays ? &r : nullptr, new PvtTraceParams(q), nullptr, log != nullptr, devices[g]);
+    });
+    int rc = first_error();
+    // 2. the tallies: summed ON THE DEVICES with RCCL (one communicator per device-list entry, ncclReduce to the
+    //    first shard) when every entry is a different GPU and the library can be loaded -- else on the host
+    bool on_device = false;
+    std::vector<int> live;
+    for (int g = 0; g < n_devices; g++) if (shards[(size_t)g].traced) live.push_back(g);
+    if (rc == PVT_OK && !never_rccl && !live.empty() && (live.size() > 1 || force_rccl)) {
+        bool distinct = true;
+        for (size_t x = 0; x < live.size(); x++)
+            for (size_t y = x + 1; y < live.size(); y++)
+                if (devices[live[x]] == devices[live[y]]) distinct = false;
+        if (distinct) {
+            std::vector<int> devs;
+            std::vector<void*> bufs[4];
+            for (int g : live) {
+                devs.push_back(devices[g]);
+                HostBundle& hb = shards[(size_t)g].hb;
+                bufs[0].push_back(hb.t_i[0]); bufs[1].push_back(hb.t_i[1]); bufs[2].push_back(hb.t_i[2]); bufs[3].push_back(hb.t_d);
             }
-            if (sh.rc != PVT_OK) sh.error = g_error;   // thread-local: carry it to the caller's thread
-        });
+            const size_t counts[4] = {nR, nR, nB, nR * 8};
+            const bool is_f64[4] = {false, false, false, true};
+            std::string why;
+            on_device = rccl_reduce_to_first(devs, bufs, counts, is_f64, &why);
+            if (!on_device && force_rccl) rc = fail(PVT_ERR_HIP, "RCCL reduce requested (PVT_MULTI_REDUCE=rccl) but unavailable: " + why);
+        }
     }
-    for (auto& w : workers) w.join();
+    g_last_multi_reduce = on_device ? 2 : 1;
+    // 3. tallies to the host (one shard's after a device-side sum, every shard's otherwise), added to the caller's
+    if (rc == PVT_OK) {
+        std::vector<int64_t> distinct(nR ? nR : 1), crossings(nR ? nR : 1), bins(nB ? nB : 1);
+        std::vector<double> sums(nR ? nR * 8 : 1);
+        for (size_t x = 0; x < live.size() && rc == PVT_OK; x++) {
+            if (on_device && x > 0) break;
+            PvtTallies t{distinct.data(), crossings.data(), sums.data(), bins.data()};
+            rc = shards[(size_t)live[x]].hb.fetch_tallies(&t);
+            if (rc != PVT_OK) break;
+            for (size_t i = 0; i < nR; i++) { tl->rec_distinct[i] += distinct[i]; tl->rec_crossings[i] += crossings[i]; }
+            for (size_t i = 0; i < nR * 8; i++) tl->rec_sums[i] += sums[i];
+            for (size_t i = 0; i < nB; i++) tl->rec_bins[i] += bins[i];
+        }
+    }
+    // 4. each shard's rows of the event log, into the caller's arrays (inner shard edges are multiples of record_every)
+    if (rc == PVT_OK && p->record_every > 0) {
+        parallel([&](Shard& sh, int g) -> int {
+            if (!sh.traced) return PVT_OK;
+            int64_t start = 0, stop = 0;
+            (void)pvt_shard_range(p->n_rays, g, n_devices, p->record_every, &start, &stop);
+            const int64_t j0 = start / p->record_every, row0 = j0 * p->max_events;
+            PvtEventLog l{log->counts + j0, log->kind + row0, log->hit + row0, log->container + row0,
+                          log->adjacent + row0, log->component + row0, log->source + row0,
+                          log->position + 3 * row0, log->direction + 3 * row0, log->normal + 3 * row0,
+                          log->wavelength + row0, log->travelled + row0, log->duration + row0};
+            return sh.hb.fetch_log(&l);
+        });
+        rc = first_error();
+    }
     double longest = 0.0;
-    for (int g = 0; g < n_devices; g++) {
-        const Shard& sh = shards[(size_t)g];
-        if (sh.rc != PVT_OK) return fail(sh.rc, "shard " + std::to_string(g) + " on device " + std::to_string(devices[g]) + ": " + sh.error);
-        if (sh.distinct.empty()) continue;
-        for (int i = 0; i < tables->n_recorders; i++) { tl->rec_distinct[i] += sh.distinct[(size_t)i]; tl->rec_crossings[i] += sh.crossings[(size_t)i]; }
-        for (int i = 0; i < tables->n_recorders * 8; i++) tl->rec_sums[i] += sh.sums[(size_t)i];
-        for (int i = 0; i < tables->total_bins; i++) tl->rec_bins[i] += sh.bins[(size_t)i];
-        if (sh.ms > longest) longest = sh.ms;
+    for (int g : live) {
+        if (shards[(size_t)g].hb.ms > longest) longest = shards[(size_t)g].hb.ms;
+        delete shards[(size_t)g].hb.p;
     }
     if (kernel_ms) *kernel_ms = longest;
-    return PVT_OK;
+    return rc;
 }
+
+int pvt_last_multi_reduce(void) { return g_last_multi_reduce; }
 
 }  // extern "C"

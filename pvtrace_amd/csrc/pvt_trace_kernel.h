@@ -601,6 +601,24 @@ __global__ void __launch_bounds__(kBlock) unpack_log_kernel(const unsigned long 
     out.wavelength[row] = dd(12); out.travelled[row] = dd(13); out.duration[row] = dd(14);
 }
 
+// Records -> PACKED records: the counts[j] rows of recorded ray j, rays one after the other (`first[j]` = rows of the
+// rays before j, an exclusive prefix sum made by the host); same thread mapping as unpack_log_kernel.  What the
+// host-buffer entry moves over PCIe.
+__global__ void __launch_bounds__(kBlock) pack_log_kernel(const unsigned long long* __restrict__ rows_in,
+                                                          const int* __restrict__ counts, const long long* __restrict__ first,
+                                                          unsigned long long* __restrict__ packed, long long n_recorded,
+                                                          int max_events, int rays_per_block) {
+    const int t = threadIdx.x;
+    const int jr = rays_per_block > 1 ? t / max_events : 0;
+    const int k = (rays_per_block > 1 ? t - jr * max_events : t) + (int)blockIdx.y * kBlock;
+    const long long j = (long long)blockIdx.x * rays_per_block + jr;
+    if (jr >= rays_per_block || j >= n_recorded || k >= max_events || k >= counts[j]) return;
+    const u32x4* src = reinterpret_cast<const u32x4*>(rows_in + (j * max_events + k) * kRecWords);
+    u32x4* dst = reinterpret_cast<u32x4*>(packed + (first[j] + k) * kRecWords);
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 // LDS accumulator layout (per workgroup), after the table copies:
 //   f64 sums[n_rec*8] | u64 cross[n_rec] | u32 distinct[n_rec] | u32 bins[total_bins] (if they fit)
 struct Accum {

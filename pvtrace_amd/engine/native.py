@@ -232,6 +232,7 @@ def declare_signatures(lib, names):
             [vp, C.POINTER(PvtRays), C.POINTER(PvtTraceParams), C.POINTER(PvtTallies),
              C.POINTER(PvtEventRecords), vp], C.c_int),
         "pvt_scene_carry_pending": ([vp, vp], C.c_int),
+        "pvt_last_multi_reduce": ([], C.c_int),
         "pvt_unpack_records_device": (
             [C.POINTER(PvtEventRecords), C.c_int64, C.c_int32, C.POINTER(PvtEventLog), C.c_int, vp], C.c_int),
         "pvt_trace_bundle": (
@@ -264,7 +265,7 @@ ABI_SYMBOLS = (
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
     "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
-    "pvt_scene_carry_pending",
+    "pvt_scene_carry_pending", "pvt_last_multi_reduce",
 )
 
 _lib = None

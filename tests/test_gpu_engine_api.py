@@ -354,6 +354,28 @@ def test_the_INTEGRATION_md_stub_splits_a_bundle_over_a_device_list():
             assert_bundles_identical(many, one, sums_rtol=1e-12, what=f"devices={devices} record_every={record_every}")
 
 
+def test_device_list_entry_sums_the_tallies_with_rccl_when_asked(monkeypatch):
+    """pvt_trace_bundle_multi sums the shards' tallies ON THE DEVICES (ncclCommInitAll over the device list +
+    ncclReduce) when every entry is a different GPU.  The one-GPU test box can only run that path as a communicator
+    of ONE rank (PVT_MULTI_REDUCE=rccl forces it): RCCL really loads, builds the communicator, reduces the four
+    buffers and the result is the single-device result.  Two entries on the same GPU fall back to the host sum."""
+    from pvtrace_amd.engine import _kernel, native
+
+    scene = scenes.bench_slab(recorders=True)
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, 3001, seed=4)
+    lib = native.load_library()
+    one = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, 7)
+    monkeypatch.setenv("PVT_MULTI_REDUCE", "rccl")
+    forced = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, 7, devices=[0])
+    assert lib.pvt_last_multi_reduce() == 2                     # summed on the device by RCCL
+    assert_bundles_identical(forced, one, sums_rtol=1e-12, what="rccl, one rank")
+    monkeypatch.delenv("PVT_MULTI_REDUCE")
+    two = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, 7, devices=[0, 0])
+    assert lib.pvt_last_multi_reduce() == 1                     # same GPU twice: host sum
+    assert_bundles_identical(two, one, sums_rtol=1e-12, what="host sum")
+
+
 @pytest.mark.parametrize("emission", ["host", "device"])
 def test_simulate_over_a_device_list_equals_one_device(emission):
     scene = scenes.bench_slab(recorders=True)
