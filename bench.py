@@ -139,6 +139,9 @@ def parse_args():
                     help="comma list of further configs timed after the cfg2 legs ('none' = skip)")
     ap.add_argument("--config-photons", type=int, default=10_000_000,
                     help="photons per GPU per window of an extra config (BASELINE: 10^7)")
+    ap.add_argument("--config-sustained-s", type=float, default=2.0,
+                    help="seconds of back-to-back bundles per extra config (its steady-state rate, without the closing "
+                         "drain of a fenced window); 0 = skip")
     ap.add_argument("--rccl-timeout-s", type=float, default=180.0)
     return ap.parse_args()
 
@@ -450,13 +453,21 @@ def main():
         dts.sort()
         photons = n * world * bundles
         v = photons / dts[len(dts) // 2]
+        sus = None
+        if args.config_sustained_s > 0:
+            sus_steps = max(bundles, int(args.config_sustained_s / (dts[len(dts) // 2] / bundles)))
+            dt = other.window(100_000, sus_steps)
+            sus = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt, "value": n * world * sus_steps / dt}
         _, side = load_pmc(name, v / world, cus)
         extra[name] = {
             "workload": CONFIGS[name]["workload"], "photons_per_gpu": n * bundles, "bundles": bundles,
             "emission": "device (in the trace kernel)", "bundles_in_flight": args.streams,
             "value": v, "unit": "photons/s", "windows": len(dts), "min": photons / dts[-1], "max": photons / dts[0],
             "ms_per_window": dts[len(dts) // 2] * 1e3, "kernel_ms_mean": sum(kms) / len(kms),
-            "launch": other.dscene.launch_info(), "instruction_side": side, "tallies": frac,
+            "launch": other.dscene.launch_info(), "instruction_side": side, "tallies": frac, "sustained": sus,
+            "note": "a fenced window ends with the longest history of its last bundles traced alone (cfg4: photons "
+                    "trapped by total internal reflection for hundreds of steps at ~4.3 us each, DESIGN.md §6); "
+                    "`sustained` is the same stream without intermediate fences",
         }
         other.close()
 
