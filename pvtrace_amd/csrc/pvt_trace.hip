@@ -772,7 +772,7 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     size_t lds = acc_bytes + tq_bytes + (tab_lds ? tab_bytes : 0);
     a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
     if (a.bins_in_lds) lds += bins_bytes;
-    const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 3 : 0);
+    const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 1 : 0);
     const size_t xbytes = (size_t)kXSlots * xw * 8;
     a.xslots = 0;
     if (s->consolidate && lds + xbytes <= 40 * 1024 && lds + xbytes <= s->lds_limit) {

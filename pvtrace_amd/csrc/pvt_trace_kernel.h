@@ -18,6 +18,12 @@
 #ifndef PVT_TIMELINE
 #define PVT_TIMELINE 0
 #endif
+#ifndef PVT_WAVE_SCALAR
+#define PVT_WAVE_SCALAR 1
+#endif
+#ifndef PVT_LOG_STORES
+#define PVT_LOG_STORES 16   // bytes per store of an event record (8: from the value registers; 16: assembled vectors)
+#endif
 
 namespace {
 
@@ -533,18 +539,32 @@ __device__ __forceinline__ u32x4 pack_dd(double a, double b) {
     return u32x4{(unsigned int)ua, (unsigned int)(ua >> 32), (unsigned int)ub, (unsigned int)(ub >> 32)};
 }
 template <bool RECORD>
-__device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev, int kind, int hit,
+__device__ __forceinline__ void log_row(const KArgs& A, int rec_slot, int& nev, int kind, int hit,
                                         int container, int adjacent, int component, int source,
                                         const V3& pos, const V3& dir, bool has_normal, const V3& nrm,
                                         double wl, double travelled, double duration) {
     if constexpr (RECORD) {
-        if (base < 0 || nev >= A.max_events) return;
-        const long long row = base + nev;
+        if (rec_slot < 0 || nev >= A.max_events) return;   // rec_slot: index of the recorded ray, -1 = not recorded
+        const long long row = (long long)rec_slot * A.max_events + nev;
         // the log pointer is read from the kernel-argument segment at the point of use (scalar load) instead of
         // living in two scalar registers across the whole loop
         const __attribute__((address_space(4))) KArgs* ak =
             (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ak));
+#if PVT_LOG_STORES == 8
+        // eight-byte stores straight from the registers the values live in (no 16-byte vectors to assemble: the
+        // history variants sit at the register limit, and every spilled register is HBM write traffic of its own)
+        unsigned long long* dst = ak->log_rows + row * kRecWords;
+        const V3 n = has_normal ? nrm : V3{0.0, 0.0, 0.0};
+        dst[0] = (unsigned long long)(unsigned int)hit | ((unsigned long long)(unsigned int)container << 32);
+        dst[1] = (unsigned long long)(unsigned int)adjacent | ((unsigned long long)(unsigned int)component << 32);
+        dst[2] = (unsigned long long)(unsigned int)source | ((unsigned long long)(unsigned int)kind << 32);
+        dst[3] = pvt_d2u(pos.x); dst[4] = pvt_d2u(pos.y); dst[5] = pvt_d2u(pos.z);
+        dst[6] = pvt_d2u(dir.x); dst[7] = pvt_d2u(dir.y); dst[8] = pvt_d2u(dir.z);
+        dst[9] = pvt_d2u(n.x); dst[10] = pvt_d2u(n.y); dst[11] = pvt_d2u(n.z);
+        dst[12] = pvt_d2u(wl); dst[13] = pvt_d2u(travelled); dst[14] = pvt_d2u(duration);
+        dst[15] = (unsigned long long)row;
+#else
         u32x4* dst = reinterpret_cast<u32x4*>(ak->log_rows + row * kRecWords);
         const unsigned long long p0 = pvt_d2u(pos.x);
         const V3 n = has_normal ? nrm : V3{0.0, 0.0, 0.0};
@@ -556,6 +576,7 @@ __device__ __forceinline__ void log_row(const KArgs& A, long long base, int& nev
         dst[5] = pack_dd(n.y, n.z);
         dst[6] = pack_dd(wl, travelled);
         dst[7] = pack_dd(duration, pvt_u2d((unsigned long long)row));
+#endif
         nev += 1;
     }
 }
@@ -659,10 +680,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     unsigned int* acc_distinct = reinterpret_cast<unsigned int*>(acc_cross + A.n_rec);
     unsigned int* acc_bins = acc_distinct + ((A.n_rec + 1) & ~1);   // (keeps what follows 8-byte aligned)
     int* ctl = reinterpret_cast<int*>(acc_bins + ((A.bins_in_lds ? A.total_bins : 0) + 1 & ~1));
-    unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [14 + SEENW (+3 when RECORD)][xslots] u64 words
+    unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(ctl + CTL_WORDS);  // [14 + SEENW (+1 when RECORD)][xslots] u64 words
     // per-wave queue of first crossings awaiting their statistics: [4 (+3 with positions)][kTallyQ] doubles
     // + [kTallyQ] recorder ids
-    constexpr int kXWords = 14 + SEENW + (RECORD ? 3 : 0);
+    constexpr int kXWords = 14 + SEENW + (RECORD ? 1 : 0);
     const int tq_doubles = A.tq_pos ? 7 : 4;
     double* const tq_d = reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + (threadIdx.x >> 6) * (tq_doubles * kTallyQ);
     int* const tq_r = reinterpret_cast<int*>(reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + kWaves * tq_doubles * kTallyQ)
@@ -703,8 +724,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     double wl = 0.0, travelled = 0.0, duration = 0.0;
     Rng rng{0, 0, 0, 0};
     int count = 0, source = -1, nev = 0;
-    long long base = -1;
-    long long rec_slot = 0;
+    int rec_slot = -1;   // recorded rays: index among them (row block rec_slot * max_events), else -1
     Seen<SEENW> seen;
 #pragma unroll
     for (int w = 0; w < SEENW; w++) seen.w[w] = 0ull;
@@ -724,7 +744,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     // photons [64 k, 64 k + 64) without asking, everything beyond is claimed from the cursors)
     const unsigned int wgs_in_set = A.set_size ? (unsigned int)A.wgs_per_set : gridDim.x;
     const unsigned int waves_in_set = wgs_in_set * kWaves;
-    const unsigned int wave_in_set = (blockIdx.x - set * (A.set_size ? (unsigned int)A.wgs_per_set : 0u)) * kWaves + (threadIdx.x >> 6);
+    const unsigned int wave_in_set = (blockIdx.x - set * (A.set_size ? (unsigned int)A.wgs_per_set : 0u)) * kWaves +
+                                     (PVT_WAVE_SCALAR ? (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (threadIdx.x >> 6));
     const unsigned int w_first = wave_in_set * (unsigned int)kClaim;
     unsigned int w_next = w_first, w_end = w_first, w_base = 0;
     unsigned int w_claim_end = w_first < n_local ? (n_local - w_first < (unsigned int)kClaim ? n_local : w_first + kClaim) : w_first;
@@ -914,12 +935,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 for (int w = 0; w < SEENW; w++) seen.w[w] = 0ull;
                 alive = true;
                 if constexpr (RECORD) {
-                    base = -1;
-                    if (A.record_every > 0 && (long long)i % A.record_every == 0) {
-                        rec_slot = (long long)i / A.record_every;
-                        base = rec_slot * A.max_events;
-                    }
-                    log_row<RECORD>(A, base, nev, PVT_EV_GENERATE, -1, -1, -1, -1, source, pos, dir, false,
+                    rec_slot = -1;
+                    if (A.record_every > 0 && (long long)i % A.record_every == 0) rec_slot = (int)((long long)i / A.record_every);
+                    log_row<RECORD>(A, rec_slot, nev, PVT_EV_GENERATE, -1, -1, -1, -1, source, pos, dir, false,
                                     pos, wl, travelled, duration);
                 }
             }
@@ -1010,9 +1028,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #pragma unroll
                     for (int w = 0; w < SEENW; w++) xbuf[(14 + w) * X + slot] = seen.w[w];
                     if constexpr (RECORD) {
-                        xbuf[(14 + SEENW) * X + slot] = (unsigned long long)base;
-                        xbuf[(15 + SEENW) * X + slot] = (unsigned long long)rec_slot;
-                        xbuf[(16 + SEENW) * X + slot] = (unsigned long long)(unsigned int)nev;
+                        xbuf[(14 + SEENW) * X + slot] = (unsigned long long)(unsigned int)rec_slot | ((unsigned long long)(unsigned int)nev << 32);
                     }
                 }
                 __syncthreads();  // B
@@ -1031,9 +1047,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #pragma unroll
                     for (int w = 0; w < SEENW; w++) seen.w[w] = xbuf[(14 + w) * X + slot];
                     if constexpr (RECORD) {
-                        base = (long long)xbuf[(14 + SEENW) * X + slot];
-                        rec_slot = (long long)xbuf[(15 + SEENW) * X + slot];
-                        nev = (int)(unsigned int)xbuf[(16 + SEENW) * X + slot];
+                        const unsigned long long rn_ = xbuf[(14 + SEENW) * X + slot];
+                        rec_slot = (int)(unsigned int)rn_;
+                        nev = (int)(unsigned int)(rn_ >> 32);
                     }
                 }
                 // the set shrinks to its `keep` lowest members
@@ -1081,7 +1097,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         if (alive) {
             count += 1;
             bool budget_kill = false;
-            if constexpr (RECORD) budget_kill = (base >= 0 && nev >= A.max_events - 1);
+            if constexpr (RECORD) budget_kill = (rec_slot >= 0 && nev >= A.max_events - 1);
             if (budget_kill) {
                 // event budget exhausted: KILL row, no tally (_kernel.pyx:658-663)
                 ev_kind = PVT_EV_KILL;
@@ -1419,7 +1435,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             if (target <= running) { comp = cbase + k; break; }
                         }
                     }
-                    log_row<RECORD>(A, base, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
+                    log_row<RECORD>(A, rec_slot, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
                                     dir, false, pos, wl, travelled, duration);
                     ev_component = comp;
                     cls = CLS_ABS;
@@ -1734,7 +1750,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         PVT_MARK(5);  // fresnel / reflect / refract
         // ================= deferred event: log row + tallies ==============
         if (alive && ev_kind >= 0)
-            log_row<RECORD>(A, base, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
+            log_row<RECORD>(A, rec_slot, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
                             dir, ev_normal, nrm, wl, travelled, duration);
 
         // Lane-parallel tally.  Each lane walks the (host-precomputed) list of recorders that
@@ -1828,7 +1844,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         PVT_MARK(6);  // log + tally
         if (alive && terminal) {
             if constexpr (RECORD) {
-                if (base >= 0) A.log_counts[rec_slot] = nev;
+                if (rec_slot >= 0) A.log_counts[rec_slot] = nev;
             }
             alive = false;
         }
