@@ -101,7 +101,8 @@ struct KArgs {
     const double* ed;   // emitter blobs (may be null)
     const int* ei;
     const pvt::BvhNode* bvh;    // triangle meshes (null when the scene has none): stay in HBM/L2
-    const pvt::MeshTri* tris;
+    const pvt::MeshTri* tris;          // vertices (hot)
+    const pvt::MeshTriCold* tris_cold; // face normal + face id (read for the crossings found)
     Lay lay;
     EmitOff eoff;
     int nd, ni;         // blob lengths
@@ -1194,7 +1195,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 } else if (MESH && gt == PVT_GEOM_MESH) {
                     // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
                     // forward crossing of the node's triangles, found by a stack-free walk of
-                    // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
+                    // the depth-first 4-wide BVH (pvt_bvh.h: bvh_walk).  Crossings of one mesh are ordered by
                     // (t, face) so the result does not depend on the walk order.
                     const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
                     const double ax = pvt_fabs(d.x), ay = pvt_fabs(d.y), az = pvt_fabs(d.z);
@@ -1213,19 +1214,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #pragma unroll
                     for (int a = 0; a < 3; a++) minv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
                     long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
-                    int i = T.iu(node * NI + NI_MESH);
-                    const int end = A.bvh[i].skip;
-                    while (i < end) {
-                        const pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
-                        double tmin = -INFINITY, tmax = INFINITY;
-#pragma unroll
-                        for (int a = 0; a < 3; a++) {
-                            const double ta = ((double)b.lo[a] - oo[a]) * minv[a], tb = ((double)b.hi[a] - oo[a]) * minv[a];
-                            tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
-                            tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
-                        }
-                        if (tmax < tmin || tmax < 0.0) { i = b.skip; continue; }
-                        const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
+                    pvt::bvh_walk(A.bvh, T.iu(node * NI + NI_MESH), oo, minv, [&](int tri_start, int tn) {
                         const pvt::MeshTri* tr = A.tris + tri_start;
                         for (int k = 0; k < tn; k++, tr++) {
                             double va[3], vb[3], vc[3];
@@ -1250,8 +1239,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
                             const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
                             if (!(t > kEps)) continue;
-                            const long long face = tr->face;
                             const int tri = tri_start + k;
+                            const long long face = A.tris_cold[tri].face;
                             if (nl == 0 || t < tfirst) tfirst = t;
                             nl += 1;
                             if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
@@ -1260,8 +1249,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
                             nhits += 1;
                         }
-                        i += 1;
-                    }
+                    });
                 } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
                 double tmin = -INFINITY, tmax = INFINITY;
                 bool miss = false;
@@ -1559,7 +1547,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             const int gp = t_node * ND + ND_PARAMS;
             const int gt = T.iv(t_node * NI + NI_GEOM);
             if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
-                const pvt::MeshTri* tr = A.tris + tri1;
+                const pvt::MeshTriCold* tr = A.tris_cold + tri1;
                 return V3{tr->n[0], tr->n[1], tr->n[2]};
             }
             if (gt == PVT_GEOM_BOX) {
