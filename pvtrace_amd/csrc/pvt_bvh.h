@@ -60,23 +60,30 @@ constexpr int kSmallMesh = 32, kSmallLeaf = 8, kLargeLeaf = 1;
 // miss would lose a crossing).  `minv` = 1/d per axis, a huge finite number for a direction component below 1e-300:
 // inside the slab the two plane distances then have opposite signs (interval covers everything), outside the same
 // sign (pushed out of range, or a harmless false hit), and 0 * inf = NaN can never arise.
-PVT_BVH_HD bool bvh_box_hit(const float* lo, const float* hi, const double* oo, const double* minv) {
+// `om` = oo * minv per axis: the plane distances are ONE fused multiply-add each, (plane * minv) - om.  The fused
+// rounding differs from (plane - o) * minv in the last bits only, which the padding of the boxes covers a billion
+// times over -- culling is the one place of the engine where the last bit cannot matter.
+PVT_BVH_HD bool bvh_box_hit(const float* lo, const float* hi, const double* om, const double* minv) {
     double tmin = -INFINITY, tmax = INFINITY;
     for (int a = 0; a < 3; a++) {
-        const double ta = ((double)lo[a] - oo[a]) * minv[a], tb = ((double)hi[a] - oo[a]) * minv[a];
+        const double ta = __builtin_fma((double)lo[a], minv[a], -om[a]), tb = __builtin_fma((double)hi[a], minv[a], -om[a]);
         tmin = fmax(tmin, fmin(ta, tb));
         tmax = fmin(tmax, fmax(ta, tb));
     }
     return !(tmax < tmin || tmax < 0.0);
 }
 
-// The walk: calls leaf(first triangle, count) for every leaf whose box (and whose ancestors' boxes) the ray hits.
-template <class Leaf>
-PVT_BVH_HD void bvh_walk(const BvhNode* nodes, int root, const double* oo, const double* minv, Leaf&& leaf) {
+// The walk: calls leaf(first triangle, count) for every leaf whose box (and whose ancestors' boxes) the ray hits;
+// tick() runs at the top of every iteration (the kernel empties its queue of pending triangle tests there: at most
+// four leaves are reported between two ticks).
+struct BvhNoTick { PVT_BVH_HD void operator()() const {} };
+template <class Leaf, class Tick = BvhNoTick>
+PVT_BVH_HD void bvh_walk(const BvhNode* nodes, int root, const double* om, const double* minv, Leaf&& leaf, Tick&& tick = Tick()) {
     int i = root;
     const int end = nodes[root].skip;
     unsigned long long trail = 0ull;   // bit 4 L + k: child k of the current ancestor at level L was hit (inner children)
     while (i < end) {
+        tick();
         const BvhNode& N = nodes[i];
         const int level = N.level;
         if (level > 0 && !((trail >> (4 * (level - 1) + N.slot)) & 1ull)) {   // the parent's test left this child out
@@ -87,7 +94,7 @@ PVT_BVH_HD void bvh_walk(const BvhNode* nodes, int root, const double* oo, const
         int first = 0;
         for (int k = 0; k < 4; k++) {
             const int c = N.child[k];
-            if (c == 0 || !bvh_box_hit(N.lo[k], N.hi[k], oo, minv)) continue;
+            if (c == 0 || !bvh_box_hit(N.lo[k], N.hi[k], om, minv)) continue;
             if (c < 0) {
                 leaf((-c - 1) >> 4, (-c - 1) & 15);
             } else {

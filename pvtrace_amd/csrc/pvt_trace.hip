@@ -771,7 +771,8 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     const size_t budget = 64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit;  // keep >= 2 workgroups per CU
     // per-wave queues of first crossings awaiting their statistics (kernel: tally_flush)
     a.tq_pos = s->hist_reads_position ? 1 : 0;
-    const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((a.tq_pos ? 7 : 4) * 8 + 4);
+    // (+ the mesh walk's per-lane queues of leaves, kernel: mesh_q, directly after them)
+    const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((a.tq_pos ? 7 : 4) * 8 + 4) + (s->d_bvh ? (size_t)kMeshQ * kBlock * 4 : 0);
     if (acc_bytes + tq_bytes > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
     const bool tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget;
     size_t lds = acc_bytes + tq_bytes + (tab_lds ? tab_bytes : 0);
@@ -1126,15 +1127,16 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
             if (ray % 7 == 0) d[ray % 3] = 0.0;                            // axis-parallel components
             if (ray % 11 == 0) { d[0] = 0.0; d[1] = 0.0; d[2] = ray % 2 ? 1.0 : -1.0; }
             for (int a = 0; a < 3; a++) minv[a] = std::fabs(d[a]) < 1e-300 ? 1e300 : 1.0 / d[a];
+            const double om[3] = {o[0] * minv[0], o[1] * minv[1], o[2] * minv[2]};
             a_set.clear(); b_set.clear();
-            pvt::bvh_walk(nodes.data(), 0, o, minv, [&](int first, int count) { for (int q = 0; q < count; q++) a_set.push_back(first + q); });
+            pvt::bvh_walk(nodes.data(), 0, om, minv, [&](int first, int count) { for (int q = 0; q < count; q++) a_set.push_back(first + q); });
             std::vector<int> stack{0};
             while (!stack.empty()) {
                 const pvt::BvhNode& b = nodes[(size_t)stack.back()];
                 stack.pop_back();
                 for (int k = 0; k < 4; k++) {
                     const int c = b.child[k];
-                    if (c == 0 || !pvt::bvh_box_hit(b.lo[k], b.hi[k], o, minv)) continue;
+                    if (c == 0 || !pvt::bvh_box_hit(b.lo[k], b.hi[k], om, minv)) continue;
                     if (c > 0) stack.push_back(c);
                     else for (int q = 0; q < ((-c - 1) & 15); q++) b_set.push_back(((-c - 1) >> 4) + q);
                 }
