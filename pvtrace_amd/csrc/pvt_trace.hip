@@ -98,7 +98,6 @@ struct PvtScene {
     int* d_ei = nullptr;
     pvt::BvhNode* d_bvh = nullptr;      // triangle meshes: BVH nodes + gathered triangles
     pvt::MeshTri* d_tris = nullptr;
-    pvt::MeshTriCold* d_cold = nullptr;
     unsigned int* d_set_cursor = nullptr;   // kCursorSlots x kMaxSets cursors: launches with tally sets
     unsigned int* d_cursor = nullptr;   // kCursorSlots cursors (64 B apart), one per stream: launches on
                                         // different streams may overlap, each needs its own
@@ -180,7 +179,6 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     const int N = t->n_nodes, C = t->n_components, R = t->n_recorders, H = t->n_hists, K = t->n_coatings;
     std::vector<pvt::BvhNode> bvh_nodes;
     std::vector<pvt::MeshTri> bvh_tris;
-    std::vector<pvt::MeshTriCold> bvh_cold;
     for (int n = 0; n < N; n++) {
         const int g = t->geom_type[n];
         if (g < PVT_GEOM_BOX || g > PVT_GEOM_MESH) return fail(PVT_ERR_INVALID, "unknown geometry type");
@@ -381,7 +379,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         }
         if (t->geom_type[n] == PVT_GEOM_MESH) {
             const int f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
-            q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris, bvh_cold)
+            q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris)
                              .add_mesh(f0, fc);
         }
     }
@@ -555,8 +553,6 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     if (!bvh_nodes.empty()) {
         HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
         HIP_TRY(hipMalloc(&s->d_tris, bvh_tris.size() * sizeof(pvt::MeshTri)));
-        HIP_TRY(hipMalloc(&s->d_cold, bvh_cold.size() * sizeof(pvt::MeshTriCold)));
-        HIP_TRY(hipMemcpy(s->d_cold, bvh_cold.data(), bvh_cold.size() * sizeof(pvt::MeshTriCold), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->d_bvh, bvh_nodes.data(), bvh_nodes.size() * sizeof(pvt::BvhNode), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->d_tris, bvh_tris.data(), bvh_tris.size() * sizeof(pvt::MeshTri), hipMemcpyHostToDevice));
     }
@@ -612,7 +608,6 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_set_cursor) (void)hipFree(s->d_set_cursor);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->d_tris) (void)hipFree(s->d_tris);
-    if (s->d_cold) (void)hipFree(s->d_cold);
     for (auto* b : s->stage) if (b) (void)hipFree(b);
     for (auto& c : s->carry) for (auto* b : c.buf) if (b) (void)hipFree(b);
     delete s;
@@ -625,7 +620,7 @@ namespace {
 KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
     KArgs a{};
     a.gd = s->d_gd; a.gi = s->d_gi; a.ed = s->d_ed; a.ei = s->d_ei;
-    a.bvh = s->d_bvh; a.tris = s->d_tris; a.tris_cold = s->d_cold;
+    a.bvh = s->d_bvh; a.tris = s->d_tris;
     a.lay = s->lay; a.eoff = s->eoff;
     a.nd = s->nd; a.ni = s->ni;
     a.n_nodes = s->n_nodes; a.root = s->root; a.n_rec = s->n_rec; a.total_bins = s->total_bins;
@@ -771,8 +766,7 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     const size_t budget = 64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit;  // keep >= 2 workgroups per CU
     // per-wave queues of first crossings awaiting their statistics (kernel: tally_flush)
     a.tq_pos = s->hist_reads_position ? 1 : 0;
-    // (+ the mesh walk's per-lane queues of leaves, kernel: mesh_q, directly after them)
-    const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((a.tq_pos ? 7 : 4) * 8 + 4) + (s->d_bvh ? (size_t)kMeshQ * kBlock * 4 : 0);
+    const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((a.tq_pos ? 7 : 4) * 8 + 4);
     if (acc_bytes + tq_bytes > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
     const bool tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget;
     size_t lds = acc_bytes + tq_bytes + (tab_lds ? tab_bytes : 0);
@@ -1050,102 +1044,45 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
     if (fc <= 0 || f0 < 0 || f0 + fc > t->n_mesh_faces) return fail(PVT_ERR_INVALID, "mesh face range out of bounds");
     std::vector<pvt::BvhNode> nodes;
     std::vector<pvt::MeshTri> tris;
-    std::vector<pvt::MeshTriCold> cold;
-    const int root = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, nodes, tris, cold).add_mesh(f0, fc);
+    const int root = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, nodes, tris).add_mesh(f0, fc);
     if (root != 0 || nodes.empty() || nodes[0].skip != (int)nodes.size()) return fail(PVT_ERR_INVALID, "root skip link");
-    if (tris.size() != cold.size()) return fail(PVT_ERR_INVALID, "hot and cold triangle records differ in number");
     std::vector<int> seen(fc, 0);
     int leaves = 0, max_depth = 0;
-    // structure: depth-first layout, children inside their parent's subtree and in slot order, levels and slots as
-    // the walk's trail expects them, every face in exactly one leaf and inside that leaf's box
+    // walk the depth-first layout with an explicit ancestor stack (end index of each open subtree)
+    std::vector<int> open_end, open_id;
     for (int i = 0; i < (int)nodes.size(); i++) {
+        while (!open_end.empty() && open_end.back() <= i) { open_end.pop_back(); open_id.pop_back(); }
         const pvt::BvhNode& b = nodes[i];
         if (b.skip <= i || b.skip > (int)nodes.size()) return fail(PVT_ERR_INVALID, "skip link does not move forward");
-        if (b.level < 0 || b.level >= pvt::kMaxLevels) return fail(PVT_ERR_INVALID, "level outside the trail");
-        max_depth = std::max(max_depth, (int)b.level + 1);
-        int expect = i + 1;   // inner children follow the node, one subtree after the other
-        bool any = false;
-        for (int k = 0; k < 4; k++) {
-            const int c = b.child[k];
-            if (c == 0) {
-                if (b.lo[k][0] <= b.hi[k][0]) return fail(PVT_ERR_INVALID, "empty slot with a box");
-                continue;
-            }
-            any = true;
-            for (int a = 0; a < 3; a++)
-                if (!(b.lo[k][a] <= b.hi[k][a])) return fail(PVT_ERR_INVALID, "empty box");
-            if (c > 0) {
-                if (c != expect || c >= b.skip) return fail(PVT_ERR_INVALID, "child subtree out of depth-first order");
-                const pvt::BvhNode& ch = nodes[c];
-                if (ch.level != b.level + 1 || ch.slot != k) return fail(PVT_ERR_INVALID, "child level / slot");
-                if (ch.skip > b.skip) return fail(PVT_ERR_INVALID, "subtree leaves its parent");
-                for (int q = 0; q < 4; q++)
-                    if (ch.child[q])
-                        for (int a = 0; a < 3; a++)
-                            if (ch.lo[q][a] < b.lo[k][a] || ch.hi[q][a] > b.hi[k][a])
-                                return fail(PVT_ERR_INVALID, "grandchild box not inside the child's box");
-                expect = ch.skip;
-            } else {
-                leaves += 1;
-                const int first = (-c - 1) >> 4, count = (-c - 1) & 15;
-                if (count < 1 || first < 0 || first + count > (int)tris.size()) return fail(PVT_ERR_INVALID, "leaf triangle range");
-                for (int q = 0; q < count; q++) {
-                    const pvt::MeshTri& tr = tris[(size_t)first + q];
-                    const long long local = cold[(size_t)first + q].face - f0;
-                    if (local < 0 || local >= fc || seen[local]++) return fail(PVT_ERR_INVALID, "face missing or duplicated");
-                    for (int v = 0; v < 3; v++)
-                        for (int a = 0; a < 3; a++) {
-                            const double x = tr.v[3 * v + a];
-                            if (x != t->mesh_vertices[3 * (size_t)t->mesh_faces[3 * (size_t)cold[(size_t)first + q].face + v] + a])
-                                return fail(PVT_ERR_INVALID, "gathered vertex differs from the table");
-                            if (x < b.lo[k][a] || x > b.hi[k][a]) return fail(PVT_ERR_INVALID, "triangle outside its leaf box");
-                        }
-                }
-            }
+        if (!open_end.empty() && b.skip > open_end.back()) return fail(PVT_ERR_INVALID, "subtree leaves its parent");
+        for (int a = 0; a < 3; a++) {
+            if (!(b.lo[a] <= b.hi[a])) return fail(PVT_ERR_INVALID, "empty box");
+            if (!open_id.empty() && (b.lo[a] < nodes[open_id.back()].lo[a] || b.hi[a] > nodes[open_id.back()].hi[a]))
+                return fail(PVT_ERR_INVALID, "child box not inside its parent");
         }
-        if (!any) return fail(PVT_ERR_INVALID, "node without children");
-        if (expect != b.skip) return fail(PVT_ERR_INVALID, "skip link is not the end of the last child");
+        max_depth = std::max(max_depth, (int)open_end.size() + 1);
+        if ((b.leaf & 15) > 0) {
+            if (b.skip != i + 1) return fail(PVT_ERR_INVALID, "leaf with a subtree");
+            leaves += 1;
+            for (int k = 0; k < (b.leaf & 15); k++) {
+                const pvt::MeshTri& tr = tris[(b.leaf >> 4) + k];
+                const long long local = tr.face - f0;
+                if (local < 0 || local >= fc || seen[local]++) return fail(PVT_ERR_INVALID, "face missing or duplicated");
+                for (int c = 0; c < 3; c++)
+                    for (int a = 0; a < 3; a++) {
+                        if (tr.v[3 * c + a] != t->mesh_vertices[3 * (size_t)t->mesh_faces[3 * (size_t)tr.face + c] + a])
+                            return fail(PVT_ERR_INVALID, "gathered vertex differs from the table");
+                        if (tr.v[3 * c + a] < b.lo[a] || tr.v[3 * c + a] > b.hi[a])
+                            return fail(PVT_ERR_INVALID, "triangle outside its leaf box");
+                    }
+            }
+        } else {
+            if (b.skip == i + 1) return fail(PVT_ERR_INVALID, "inner node without children");
+            open_end.push_back(b.skip);
+            open_id.push_back(i);
+        }
     }
     for (int k = 0; k < fc; k++) if (seen[k] != 1) return fail(PVT_ERR_INVALID, "face missing from the tree");
-    // the walk: for random rays the trail walk (the one the kernel runs) must call exactly the leaves a plain
-    // recursive descent with the same box test reaches
-    {
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (const auto& tr : tris)
-            for (int v = 0; v < 3; v++)
-                for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], tr.v[3 * v + a]); hi[a] = std::max(hi[a], tr.v[3 * v + a]); }
-        unsigned long long st = 0x9E3779B97F4A7C15ull;
-        auto uni = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
-        std::vector<int> a_set, b_set;
-        for (int ray = 0; ray < 3000; ray++) {
-            double o[3], d[3], minv[3];
-            for (int a = 0; a < 3; a++) {
-                const double span = hi[a] - lo[a] + 1e-9;
-                o[a] = lo[a] - 0.6 * span + 2.2 * span * uni();          // inside and around the mesh
-                d[a] = 2.0 * uni() - 1.0;
-            }
-            if (ray % 7 == 0) d[ray % 3] = 0.0;                            // axis-parallel components
-            if (ray % 11 == 0) { d[0] = 0.0; d[1] = 0.0; d[2] = ray % 2 ? 1.0 : -1.0; }
-            for (int a = 0; a < 3; a++) minv[a] = std::fabs(d[a]) < 1e-300 ? 1e300 : 1.0 / d[a];
-            const double om[3] = {o[0] * minv[0], o[1] * minv[1], o[2] * minv[2]};
-            a_set.clear(); b_set.clear();
-            pvt::bvh_walk(nodes.data(), 0, om, minv, [&](int first, int count) { for (int q = 0; q < count; q++) a_set.push_back(first + q); });
-            std::vector<int> stack{0};
-            while (!stack.empty()) {
-                const pvt::BvhNode& b = nodes[(size_t)stack.back()];
-                stack.pop_back();
-                for (int k = 0; k < 4; k++) {
-                    const int c = b.child[k];
-                    if (c == 0 || !pvt::bvh_box_hit(b.lo[k], b.hi[k], om, minv)) continue;
-                    if (c > 0) stack.push_back(c);
-                    else for (int q = 0; q < ((-c - 1) & 15); q++) b_set.push_back(((-c - 1) >> 4) + q);
-                }
-            }
-            std::sort(a_set.begin(), a_set.end());
-            std::sort(b_set.begin(), b_set.end());
-            if (a_set != b_set) return fail(PVT_ERR_INVALID, "the trail walk and a recursive descent reach different leaves");
-        }
-    }
     if (n_bvh_nodes) *n_bvh_nodes = (int32_t)nodes.size();
     if (n_leaves) *n_leaves = leaves;
     if (depth_out) *depth_out = max_depth;

@@ -44,7 +44,6 @@ constexpr int kClaim = kChunk * PVT_CLAIM_CHUNKS;   // rays a wave claims per cu
 constexpr int kWaves = kBlock / 64;
 constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
 constexpr int kMaxSets = 1024;       // tally sets (bundles of a stream) one launch may serve
-constexpr int kMeshQ = 8;            // leaves a lane may hold back before their triangles are tested (mesh scenes; LDS)
 constexpr int kTallyQ = 64;          // first crossings a wave parks before it computes their statistics together
 constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a draining workgroup (>= 64: the
                                      // last stage packs the survivors into one wave; >= 69 so that the 8 KB of
@@ -102,8 +101,7 @@ struct KArgs {
     const double* ed;   // emitter blobs (may be null)
     const int* ei;
     const pvt::BvhNode* bvh;    // triangle meshes (null when the scene has none): stay in HBM/L2
-    const pvt::MeshTri* tris;          // vertices (hot)
-    const pvt::MeshTriCold* tris_cold; // face normal + face id (read for the crossings found)
+    const pvt::MeshTri* tris;
     Lay lay;
     EmitOff eoff;
     int nd, ni;         // blob lengths
@@ -690,9 +688,6 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     double* const tq_d = reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + (threadIdx.x >> 6) * (tq_doubles * kTallyQ);
     int* const tq_r = reinterpret_cast<int*>(reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + kWaves * tq_doubles * kTallyQ)
                       + (threadIdx.x >> 6) * kTallyQ;
-    // (mesh scenes) per-lane queue of leaves awaiting their triangle tests: [kMeshQ][kBlock] u32, after the tally queues
-    unsigned int* const mesh_q = reinterpret_cast<unsigned int*>(
-        reinterpret_cast<int*>(reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + kWaves * tq_doubles * kTallyQ) + kWaves * kTallyQ);
     int tq_n = 0;   // wave-uniform
     if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 4 && A.cursor_next) A.cursor_next[threadIdx.x] = 0u;
@@ -1199,7 +1194,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 } else if (MESH && gt == PVT_GEOM_MESH) {
                     // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
                     // forward crossing of the node's triangles, found by a stack-free walk of
-                    // the depth-first 4-wide BVH (pvt_bvh.h: bvh_walk).  Crossings of one mesh are ordered by
+                    // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
                     // (t, face) so the result does not depend on the walk order.
                     const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
                     const double ax = pvt_fabs(d.x), ay = pvt_fabs(d.y), az = pvt_fabs(d.z);
@@ -1217,16 +1212,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     double minv[3];
 #pragma unroll
                     for (int a = 0; a < 3; a++) minv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
-                    const double om[3] = {oo[0] * minv[0], oo[1] * minv[1], oo[2] * minv[2]};
                     long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
-                    // The walk only COLLECTS the leaves whose boxes the ray hits (a queue of kMeshQ entries per lane in
-                    // LDS); the triangle tests run afterwards, every lane on its k-th candidate at the same time.  With
-                    // the test inside the walk, whichever iteration had a lane at a leaf paid the ~120 instructions of
-                    // the watertight test for the whole wave -- nearly every iteration, since lanes reach their leaves
-                    // at different depths -- on top of the box tests.
-                    unsigned int* const mq = mesh_q + threadIdx.x;
-                    int mq_n = 0;
-                    auto test_leaf = [&](int tri_start, int tn) {
+                    int i = T.iu(node * NI + NI_MESH);
+                    const int end = A.bvh[i].skip;
+                    while (i < end) {
+                        const pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
+                        double tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const double ta = ((double)b.lo[a] - oo[a]) * minv[a], tb = ((double)b.hi[a] - oo[a]) * minv[a];
+                            tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                            tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                        }
+                        if (tmax < tmin || tmax < 0.0) { i = b.skip; continue; }
+                        const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
                         const pvt::MeshTri* tr = A.tris + tri_start;
                         for (int k = 0; k < tn; k++, tr++) {
                             double va[3], vb[3], vc[3];
@@ -1251,8 +1250,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
                             const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
                             if (!(t > kEps)) continue;
+                            const long long face = tr->face;
                             const int tri = tri_start + k;
-                            const long long face = A.tris_cold[tri].face;
                             if (nl == 0 || t < tfirst) tfirst = t;
                             nl += 1;
                             if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
@@ -1261,21 +1260,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
                             nhits += 1;
                         }
-                    };
-                    auto flush = [&]() {
-                        for (int r = 0;; r++) {
-                            if (__ballot(r < mq_n) == 0ull) break;
-                            if (r < mq_n) {
-                                const unsigned int e = mq[r * kBlock];
-                                test_leaf((int)(e >> 4), (int)(e & 15u));
-                            }
-                        }
-                        mq_n = 0;
-                    };
-                    pvt::bvh_walk(A.bvh, T.iu(node * NI + NI_MESH), om, minv,
-                                  [&](int tri_start, int tn) { mq[mq_n * kBlock] = ((unsigned int)tri_start << 4) | (unsigned int)tn; mq_n += 1; },
-                                  [&]() { if (__ballot(mq_n > kMeshQ - 4) != 0ull) flush(); });
-                    flush();
+                        i += 1;
+                    }
                 } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
                 double tmin = -INFINITY, tmax = INFINITY;
                 bool miss = false;
@@ -1573,7 +1559,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             const int gp = t_node * ND + ND_PARAMS;
             const int gt = T.iv(t_node * NI + NI_GEOM);
             if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
-                const pvt::MeshTriCold* tr = A.tris_cold + tri1;
+                const pvt::MeshTri* tr = A.tris + tri1;
                 return V3{tr->n[0], tr->n[1], tr->n[2]};
             }
             if (gt == PVT_GEOM_BOX) {
