@@ -54,7 +54,14 @@ class BundlePipeline:
             self.workgroups_per_cu = int(os.environ["PVT_PIPE_WGS"])
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self.slots = [dscene.new_tallies() for _ in range(self.depth)]
-        self.totals = [dscene.new_tallies() for _ in range(self.depth)]
+        # The kernel ADDS its tallies with atomics (one per non-zero slot per workgroup), so the launches of every
+        # stream can add into ONE running total: nothing to fold when the totals are read (the fold was eight tiny
+        # kernels and two cross-stream waits at the end of every job).  Per-bundle all-reduces add each bundle's own
+        # numbers with a plain torch `+=` on the bundle's stream, which is not atomic: they keep a total per stream.
+        if distributed and reduce == "bundle":
+            self.totals = [dscene.new_tallies() for _ in range(self.depth)]
+        else:
+            self.totals = [dscene.new_tallies()] * self.depth
         self.events = []       # (start, stop) HIP events of every trace launch
         self.submitted = 0
         self.wait_for_inputs()   # the zero-fills above ran on the current stream
@@ -141,9 +148,10 @@ class BundlePipeline:
     def reset_totals(self):
         self.finish_parked()      # photons of earlier bundles must not be tallied into what follows
         self.synchronize()
-        for t in self.totals:
-            t["_ints"].zero_()
-            t["_sums"].zero_()
+        for k, t in enumerate(self.totals):
+            if k == 0 or t is not self.totals[0]:
+                t["_ints"].zero_()
+                t["_sums"].zero_()
         self.events = []
         self._reduced = False
         self._unordered = set()
@@ -161,12 +169,17 @@ class BundlePipeline:
         for s in self.streams[1:]:
             first.wait_stream(s)
         with torch.cuda.stream(first):
+            folded = False
             for t in self.totals[1:]:
+                if t is self.totals[0]:
+                    continue
                 self.totals[0]["_ints"] += t["_ints"]
                 self.totals[0]["_sums"] += t["_sums"]
                 t["_ints"].zero_()
                 t["_sums"].zero_()
-            self._unordered = set(range(1, self.depth))
+                folded = True
+            if folded:
+                self._unordered = set(range(1, self.depth))
             if self.distributed and self.reduce == "end":
                 from pvtrace_amd.engine.distributed import all_reduce_tallies
 
