@@ -124,8 +124,10 @@ def parse_args():
     ap.add_argument("--repeats", type=int, default=15,
                     help="extra, independent timed windows of --steps steps after the first one; `value` is the "
                          "median of all of them")
-    ap.add_argument("--sustained-s", type=float, default=12.0,
-                    help="length of the sustained leg (back-to-back bundles) in seconds of GPU work; 0 = skip")
+    ap.add_argument("--sustained-s", type=float, default=12.5,
+                    help="length of the sustained leg (back-to-back bundles) in seconds of GPU work (sized from the "
+                         "sustained step time of a short probe, so that it really lasts this long: >= two ticks of a "
+                         "5-s utilisation sampler); 0 = skip")
     ap.add_argument("--total-photons", type=int, default=100_000_000,
                     help="strong-scaling leg (BASELINE configs[2]): ONE job of this many photons split over the "
                          "ranks by index range, tallies all-reduced once; 0 = skip")
@@ -391,7 +393,11 @@ def main():
 
     sustained = None
     if args.sustained_s > 0:
-        sus_steps = max(args.steps, int(args.sustained_s / (median_dt / args.steps)))
+        # a short probe gives the step time without the fixed cost of a 20-step window
+        probe_steps = 10 * args.steps
+        probe = leg.window(next_step, probe_steps) if args.sustained_s >= 1.0 else median_dt / args.steps * probe_steps
+        next_step += probe_steps
+        sus_steps = max(args.steps, int(args.sustained_s / (probe / probe_steps)))
         dt = leg.window(next_step, sus_steps)
         next_step += sus_steps
         sustained = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt,
