@@ -340,8 +340,7 @@ int pvt_emit_device(PvtScene* scene, const PvtTraceParams* params, double* posit
  * fn: 0 log, 1 sin, 2 cos, 3 asin, 4 acos, 5 sqrt, 6 1/x, 7 sin*cos via sincos,
  * 8 second xoshiro256+ uniform of stream (uint64)x, 9 x/(x+3), 10-13 known-divisor divisions,
  * 14/15 sin/cos(2 pi x) and 16 sqrt((1-x)(1+x)) (composed functions of pvt_math.h), 17-19 the short
- * 1/x, x/y and sqrt(x) sequences of the kernel (operands in their normal ranges), 20-22 the guarded x/y, 1.5/x and
- * sqrt(x) of the sphere / cylinder code (any operand).  Lets the tests prove the bit-reproducibility premise of
+ * 1/x, x/y and sqrt(x) sequences of the kernel (operands in their normal ranges).  Lets the tests prove the bit-reproducibility premise of
  * csrc/pvt_math.h on gfx950. */
 int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, int device);
 

@@ -152,8 +152,7 @@ def emit(emitter, n_rays, emit_seed, ray_offset=0, math_mode=MATH_PORTABLE):
 MATH_FN = {"log": 0, "sin": 1, "cos": 2, "asin": 3, "acos": 4, "sqrt": 5, "rcp": 6,
            "sincos_product": 7, "uniform2": 8, "ratio": 9,
            "div_c": 10, "div_n": 11, "div_hist": 12, "div_any": 13,
-           "sin2pi": 14, "cos2pi": 15, "sqrt1m2": 16, "rcp_normal": 17, "div_normal": 18, "sqrt_normal": 19,
-           "guard_div_x": 20, "guard_div_y": 21, "guard_sqrt": 22}
+           "sin2pi": 14, "cos2pi": 15, "sqrt1m2": 16, "rcp_normal": 17, "div_normal": 18, "sqrt_normal": 19}
 
 
 def math(fn, x, math_mode=MATH_PORTABLE):

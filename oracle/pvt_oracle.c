@@ -912,11 +912,6 @@ void pvt_oracle_math(int fn, int math_mode, const double* x, double* y, long n) 
             case 16: y[i] = M.mode ? pvt_sqrt1m2(x[i]) : sin(acos(x[i])); break;
             case 19: y[i] = sqrt(x[i]); break;   /* the device's short square-root sequence must equal IEEE sqrt */
             case 17: y[i] = 1.0 / x[i]; break;   /* the device's short reciprocal sequence must equal IEEE division */
-            /* the device's guarded divisions / square roots (short sequence when the whole wave holds ordinary
-             * operands, the general one otherwise) must equal the plain operation for EVERY operand */
-            case 20: y[i] = x[i] / (x[i] * 0.7310585786300049 + 0.25); break;
-            case 21: y[i] = 1.5 / x[i]; break;
-            case 22: y[i] = sqrt(x[i]); break;
             default: { double d = x[i] * 0.7310585786300049 + 0.25; y[i] = x[i] / d; break; }
         }
     }

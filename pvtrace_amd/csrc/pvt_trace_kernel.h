@@ -238,26 +238,6 @@ __device__ __forceinline__ double rcp_normal(double x) {
     return __builtin_fma(e, r, r);
 }
 
-// RN(x / y) for operands of ANY kind, at the price of div_normal whenever every lane of the wave holds ordinary
-// ones: y in (1e-150, 1e150), x zero or in that range -- the quotient is then normal, no intermediate of the short
-// sequence can overflow or lose bits to a subnormal, and it returns what the compiler's general sequence (operand
-// scaling, special-case fix-up: ~25 instructions against 8) returns.  One lane with anything else -- a ray within
-// 1e-150 of parallel to a cylinder's axis, infinities, NaN -- sends the wave through the general division.
-__device__ __forceinline__ double div_any(double x, double y) {
-    const double ax = pvt_fabs(x), ay = pvt_fabs(y);
-    const bool ordinary = ay > 1e-150 && ay < 1e150 && (x == 0.0 || (ax > 1e-150 && ax < 1e150));
-    if (__ballot(!ordinary) != 0ull) return x / y;
-    return div_normal(x, y);
-}
-
-// RN(sqrt(x)) likewise: the short sequence when every lane holds zero or something in (1e-200, 1e300), else the
-// library's general one.
-__device__ __forceinline__ double sqrt_any(double x) {
-    const bool ordinary = x == 0.0 || (x > 1e-200 && x < 1e300);
-    if (__ballot(!ordinary) != 0ull) return pvt_sqrt(x);
-    return sqrt_normal(x);
-}
-
 // ------------------------------------------------------------ table access
 // TAB_LDS: divergent reads come from the LDS copy; uniform reads always come
 // from the global blob so the compiler can use scalar loads.
@@ -537,9 +517,6 @@ __global__ void __launch_bounds__(kBlock) math_kernel(int fn, const double* x, d
         case 17: r = rcp_normal(v); break;
         case 18: r = div_normal(v, v * 0.7310585786300049 + 0.25); break;
         case 19: r = sqrt_normal(v); break;
-        case 20: r = div_any(v, v * 0.7310585786300049 + 0.25); break;
-        case 21: r = div_any(1.5, v); break;
-        case 22: r = sqrt_any(v); break;
         default: { double d = v * 0.7310585786300049 + 0.25; r = div_known(v, d, 1.0 / d); break; }
     }
     y[i] = r;
@@ -1328,10 +1305,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
                     double disc = b * b - 4.0 * a * c;
                     if (!(disc < 0.0)) {
-                        double sq = sqrt_any(disc);
-                        double t = div_any(-b - sq, 2.0 * a);
+                        double sq = pvt_sqrt(disc);
+                        double t = (-b - sq) / (2.0 * a);
                         if (t > kEps) fold(t);
-                        t = div_any(-b + sq, 2.0 * a);
+                        t = (-b + sq) / (2.0 * a);
                         if (t > kEps) fold(t);
                     }
                 } else {  // capped z cylinder (:301-345)
@@ -1342,20 +1319,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         double c = o.x * o.x + o.y * o.y - radius * radius;
                         double disc = b * b - 4.0 * a * c;
                         if (disc >= 0.0) {
-                            double sq = sqrt_any(disc);
-                            double t = div_any(-b - sq, 2.0 * a);
+                            double sq = pvt_sqrt(disc);
+                            double t = (-b - sq) / (2.0 * a);
                             double z = o.z + t * d.z;
                             if (z > -half && z < half && t > kEps) fold(t);
-                            t = div_any(-b + sq, 2.0 * a);
+                            t = (-b + sq) / (2.0 * a);
                             z = o.z + t * d.z;
                             if (z > -half && z < half && t > kEps) fold(t);
                         }
                     }
                     if (pvt_fabs(d.z) > 1e-300) {
-                        double t = div_any(-half - o.z, d.z);
+                        double t = (-half - o.z) / d.z;
                         double x = o.x + t * d.x, y = o.y + t * d.y;
                         if (x * x + y * y <= radius * radius && t > kEps) fold(t);
-                        t = div_any(half - o.z, d.z);
+                        t = (half - o.z) / d.z;
                         x = o.x + t * d.x;
                         y = o.y + t * d.y;
                         if (x * x + y * y <= radius * radius && t > kEps) fold(t);
@@ -1602,15 +1579,15 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 return V3{(!use_y && !use_z) ? sx : 0.0, (use_y && !use_z) ? sy : 0.0, use_z ? sz : 0.0};
             }
             if (gt == PVT_GEOM_SPHERE) {
-                double mag = sqrt_any(dot3(lp, lp));
-                return V3{div_any(lp.x, mag), div_any(lp.y, mag), div_any(lp.z, mag)};
+                double mag = pvt_sqrt(dot3(lp, lp));
+                return V3{lp.x / mag, lp.y / mag, lp.z / mag};
             }
             double half = 0.5 * T.dv(gp);
             double tol = 1e-8 + 1e-5 * pvt_fabs(half);
             if (pvt_fabs(lp.z + half) <= tol) return V3{0.0, 0.0, -1.0};
             if (pvt_fabs(lp.z - half) <= tol) return V3{0.0, 0.0, 1.0};
-            double r = sqrt_any(lp.x * lp.x + lp.y * lp.y);
-            return V3{div_any(lp.x, r), div_any(lp.y, r), 0.0};
+            double r = pvt_sqrt(lp.x * lp.x + lp.y * lp.y);
+            return V3{lp.x / r, lp.y / r, 0.0};
         };
         if (alive && t_normal) {
             const V3 nloc = local_normal(local_point());

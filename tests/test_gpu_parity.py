@@ -41,8 +41,7 @@ def _division_operands(rng, n, divisor):
 
 @pytest.mark.parametrize("fn", ["log", "sin", "cos", "asin", "acos", "sqrt", "rcp",
                                 "sincos_product", "uniform2", "ratio", "div_c", "div_n", "div_hist", "div_any",
-                                "sin2pi", "cos2pi", "sqrt1m2", "rcp_normal", "div_normal", "sqrt_normal",
-                                "guard_div_x", "guard_div_y", "guard_sqrt"])
+                                "sin2pi", "cos2pi", "sqrt1m2", "rcp_normal", "div_normal", "sqrt_normal"])
 def test_device_arithmetic_is_bit_identical_to_host(fn):
     """The premise of everything below: IEEE divide/sqrt, u64->f64 and pvt_math.h give the
     same bits on gfx950 (hipcc, -ffp-contract=off) as on the host (gcc)."""
@@ -57,7 +56,6 @@ def test_device_arithmetic_is_bit_identical_to_host(fn):
         "div_c": _division_operands(rng, n, 2.99792458e10), "div_n": _division_operands(rng, n, 1.5),
         "div_hist": _division_operands(rng, n, 400.0),
         "div_any": _division_operands(rng, n, lambda q: q * 0.7310585786300049 + 0.25),
-        "guard_div_x": rng.random(4), "guard_div_y": rng.random(4), "guard_sqrt": rng.random(4),   # (built below)
         "sin2pi": rng.random(n), "cos2pi": rng.random(n), "sqrt1m2": rng.random(n) * 2 - 1, "div_normal": rng.random(n),
         # squares and their neighbours (ties and near-ties of the final rounding), the whole range, 0 and +inf
         "sqrt_normal": np.concatenate((
@@ -71,20 +69,9 @@ def test_device_arithmetic_is_bit_identical_to_host(fn):
             np.ldexp(np.nextafter(2.0, 0.0), rng.integers(-996, 1000, 2000)), np.ldexp(np.nextafter(1.0, 2.0), rng.integers(-996, 1000, 2000)),
             np.ldexp(1.0, np.arange(-996, 1000)), -np.ldexp(np.nextafter(2.0, 0.0), rng.integers(-996, 1000, 2000)))),
     }[fn]
-    if fn.startswith("guard_"):
-        # every kind of operand, in runs long and short: waves of ordinary operands take the short sequence, a wave
-        # that holds one tiny / huge / zero / infinite / NaN operand the general one -- both must be the plain operation
-        body = np.concatenate((rng.normal(size=n) * 10.0 ** rng.uniform(-12, 12, n), rng.random(n),
-                               rng.normal(size=n // 4) * 10.0 ** rng.uniform(-320, 308, n // 4),
-                               np.ldexp(np.nextafter(2.0, 0.0), rng.integers(-1070, 1020, 4000)).astype(np.float64),
-                               [0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, 1e-150, 1e150, 1e-200, 1e300, -0.3424657534246575]))
-        odd = rng.choice(body, 3000)
-        x = np.concatenate((body, np.where(rng.random(200_000) < 0.01, rng.choice(odd, 200_000), rng.random(200_000) * 7.0)))
-        if fn == "guard_sqrt":
-            x = np.abs(x)
     if fn == "div_normal":    # x / (0.73 x + 0.25): quotients from 1e-280 to 1.37, both signs of x below the pole
         x = np.concatenate((rng.random(n) * 100, rng.random(n), 10.0 ** rng.uniform(-280, 2, n), -rng.random(n) * 0.3, [0.0]))
-    if not fn.startswith(("div_", "guard_")):   # (a subnormal quotient is outside div_known's stated domain)
+    if not fn.startswith("div_"):   # (a subnormal quotient is outside div_known's stated domain)
         x = np.concatenate((x, [1.0, 0.5, 1e-300, 0.9999999999999999]))
     if fn == "rcp_normal":
         x = x[(np.abs(x) >= 1e-300) & (np.abs(x) <= 1e300)]
