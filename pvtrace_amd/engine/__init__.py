@@ -17,10 +17,11 @@ from pvtrace_amd.engine.api import (
     simulate,
     simulate_stream,
     Session,
+    release_resident_scenes,
 )
 
 __all__ = [
     "CompiledScene", "UnsupportedSceneError", "compile_scene", "Recorder", "Histogram",
     "Heatmap", "EngineResult", "RecorderResult", "EngineUnavailableError", "is_available",
-    "simulate", "simulate_stream", "Session", "tally_histories", "BundlePipeline", "trace_stream", "auto_recorders", "instrument", "recorders_from_spec",
+    "simulate", "simulate_stream", "Session", "tally_histories", "BundlePipeline", "trace_stream", "auto_recorders", "instrument", "recorders_from_spec", "release_resident_scenes",
 ]

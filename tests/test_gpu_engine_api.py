@@ -490,3 +490,38 @@ def _kernel_module():
     from pvtrace_amd.engine import _kernel
 
     return _kernel
+
+
+def test_resident_scenes_are_reused_and_an_edited_scene_is_a_new_one():
+    """`simulate` keeps the last few scenes resident on the GPU (digest of every flat table).  Same scene again: the
+    same device scene, same results; a scene edited in between: a different digest, hence different tables on the
+    device and the results of the EDITED scene; two sessions at once never share one resident scene."""
+    from pvtrace_amd.engine import api
+
+    engine.release_resident_scenes()
+    scene = scenes.bench_slab(recorders=True)
+    kw = dict(seed=3, emit_seed=4, record_every=0, emission="device")
+    a = engine.simulate(scene, 20_000, **kw)
+    assert len(api._RESIDENT) == 1
+    handle = api._RESIDENT[0][1].handle.value
+    b = engine.simulate(scene, 20_000, **kw)
+    assert len(api._RESIDENT) == 1 and api._RESIDENT[0][1].handle.value == handle       # reused
+    assert_bundles_identical(b.data, a.data, sums_rtol=1e-12, what="reused scene")
+    slab = [n for n in scene.root.children if n.geometry is not None][0]
+    slab.geometry.material.refractive_index = 1.7                                         # edit the scene
+    c = engine.simulate(scene, 20_000, **kw)
+    fresh = engine.simulate(scenes.bench_slab(recorders=True), 20_000, **kw)
+    assert len(api._RESIDENT) == 2
+    assert not np.array_equal(c.data["rec_distinct"], a.data["rec_distinct"])            # n = 1.7 reflects more
+    assert_bundles_identical(fresh.data, a.data, sums_rtol=1e-12, what="original scene again")
+    with engine.Session(scene, device=0) as s1, engine.Session(scene, device=0) as s2:
+        assert s1.dscene is not s2.dscene
+        r1, r2 = s1.run(5000, 1, record_every=0, emit_seed=2), s2.run(5000, 1, record_every=0, emit_seed=2)
+        assert_bundles_identical(r1.data, r2.data, sums_rtol=1e-12, what="two sessions")
+    for _ in range(6):     # the cache is bounded
+        other = scenes.bench_slab(recorders=True)
+        [n for n in other.root.children if n.geometry is not None][0].geometry.material.refractive_index = 1.1 + 0.1 * _
+        engine.simulate(other, 100, **kw)
+    assert len(api._RESIDENT) <= api._RESIDENT_MAX
+    engine.release_resident_scenes()
+    assert api._RESIDENT == []
