@@ -256,12 +256,18 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
     # decoded into columns on the GPU (slices of the gathered records), so that what crosses PCIe and lands in
     # host memory is already the reference's contiguous arrays
     picked = log["rows"][:rows].index_select(0, index)
-    i32, f64 = picked.view(torch.int32), picked.view(torch.float64)
-    columns = {"kind": i32[:, 5].to(torch.uint8), "hit": i32[:, 0], "container": i32[:, 1], "adjacent": i32[:, 2],
-               "component": i32[:, 3], "source": i32[:, 4], "position": f64[:, 3:6], "direction": f64[:, 6:9],
-               "normal": f64[:, 9:12], "wavelength": f64[:, 12], "travelled": f64[:, 13], "duration": f64[:, 14]}
-    written = {name: col.contiguous().cpu().numpy() for name, col in columns.items()}
-    del picked, i32, f64, columns
+    if used * 128 <= (8 << 20):
+        # a sampled log (a few thousand rows): one transfer, decoded on the host -- twelve small device kernels and
+        # twelve small transfers cost more than the rows themselves
+        written = native.decode_records(picked.cpu().numpy())
+        picked = None
+    i32, f64 = (picked.view(torch.int32), picked.view(torch.float64)) if picked is not None else (None, None)
+    if picked is not None:
+        columns = {"kind": i32[:, 5].to(torch.uint8), "hit": i32[:, 0], "container": i32[:, 1], "adjacent": i32[:, 2],
+                   "component": i32[:, 3], "source": i32[:, 4], "position": f64[:, 3:6], "direction": f64[:, 6:9],
+                   "normal": f64[:, 9:12], "wavelength": f64[:, 12], "travelled": f64[:, 13], "duration": f64[:, 14]}
+        written = {name: col.contiguous().cpu().numpy() for name, col in columns.items()}
+        del picked, i32, f64, columns
     if packed:
         data.update(written)
         return data
@@ -292,14 +298,15 @@ def _scene_key(compiled, emitter, device):
 
     h = hashlib.blake2b(digest_size=16)
     h.update(repr(int(device)).encode())
-    for name, value in sorted(compiled.tables().items()):
-        a = np.ascontiguousarray(value)
-        h.update(name.encode()); h.update(str(a.dtype).encode()); h.update(repr(a.shape).encode()); h.update(a.tobytes())
+    for name in compiled.TABLE_FIELDS:
+        a = np.ascontiguousarray(getattr(compiled, name))
+        h.update(a.dtype.str.encode()); h.update(repr(a.shape).encode()); h.update(a.data if a.size else b"")
+    h.update(repr((int(compiled.root_id), int(compiled.total_bins))).encode())
     if emitter is not None:
         for name in ("wl_type", "wl_value", "wl_spec_start", "wl_spec_n", "pos_type", "pos_param", "dir_type",
                      "dir_param", "light_to_world", "spec_x", "spec_cdf"):
             a = np.ascontiguousarray(getattr(emitter, name))
-            h.update(name.encode()); h.update(a.tobytes())
+            h.update(repr(a.shape).encode()); h.update(a.data if a.size else b"")
     return h.digest()
 
 
