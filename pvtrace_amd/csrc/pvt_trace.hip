@@ -1152,9 +1152,10 @@ bool rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*>
 struct HostBundle {
     PvtScene* scene = nullptr;
     std::vector<void*> bufs;
-    const PvtSceneTables* tables;
-    const PvtTraceParams* p;
-    size_t nR, nB, R, B, n_sets, si, sd;
+    const PvtSceneTables* tables = nullptr;
+    PvtTraceParams params{};            // (a copy: a shard's parameters live as long as its bundle)
+    const PvtTraceParams* p = &params;
+    size_t nR = 0, nB = 0, R = 1, B = 1, n_sets = 1, si = 0, sd = 0;
     void *t_i[3] = {nullptr, nullptr, nullptr}, *t_d = nullptr;   // distinct | crossings | bins, sums (device)
     unsigned long long* rows = nullptr;                             // event records (device)
     int* counts = nullptr;
@@ -1180,7 +1181,8 @@ struct HostBundle {
     // scene + rays + tallies (seeded with `seed`, or zero) on `device`, trace enqueued and finished
     int trace(const PvtSceneTables* tb, const PvtEmitterTables* emitter, const PvtRays* rays, const PvtTraceParams* pp,
               const PvtTallies* seed, bool want_log, int device) {
-        tables = tb; p = pp;
+        tables = tb;
+        params = *pp;
         int rc = pvt_scene_create(tables, device, &scene);
         if (rc != PVT_OK) return rc;
         if (emitter) {
@@ -1387,7 +1389,7 @@ int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables*
         if (rays) r = PvtRays{rays->position + 3 * start, rays->direction + 3 * start, rays->wavelength + start};
         // (the shard's params must outlive the bundle: keep a copy inside it)
         sh.traced = true;
-        return sh.hb.trace(tables, emitter, rays ? &r : nullptr, new PvtTraceParams(q), nullptr, log != nullptr, devices[g]);
+        return sh.hb.trace(tables, emitter, rays ? &r : nullptr, &q, nullptr, log != nullptr, devices[g]);
     });
     int rc = first_error();
     // 2. the tallies: summed ON THE DEVICES with RCCL (one communicator per device-list entry, ncclReduce to the
@@ -1448,7 +1450,6 @@ int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables*
     double longest = 0.0;
     for (int g : live) {
         if (shards[(size_t)g].hb.ms > longest) longest = shards[(size_t)g].hb.ms;
-        delete shards[(size_t)g].hb.p;
     }
     if (kernel_ms) *kernel_ms = longest;
     return rc;
