@@ -156,3 +156,37 @@ def test_last_error_is_per_thread(built):
     assert "shard" in seen["shard"] and "null" in seen["create"]
     assert seen["shard"] != seen["create"]
     assert lib.pvt_last_error().decode() == mine   # untouched by the workers' failures
+
+
+def test_event_record_layout_round_trips_on_the_host():
+    """`native.decode_records` reads the 128-byte event records of include/pvtrace_hip.h (PvtEventRecords): build
+    rows by hand in that layout and get the reference's columns back, dtypes included."""
+    import numpy as np
+
+    from pvtrace_amd.engine import native
+
+    rng = np.random.default_rng(3)
+    m = 257
+    cols = {
+        "hit": rng.integers(-1, 120, m).astype(np.int32), "container": rng.integers(-1, 120, m).astype(np.int32),
+        "adjacent": rng.integers(-1, 120, m).astype(np.int32), "component": rng.integers(-1, 40, m).astype(np.int32),
+        "source": rng.integers(-1, 40, m).astype(np.int32), "kind": rng.integers(0, 10, m).astype(np.uint8),
+        "position": rng.normal(size=(m, 3)), "direction": rng.normal(size=(m, 3)), "normal": rng.normal(size=(m, 3)),
+        "wavelength": rng.uniform(300, 900, m), "travelled": rng.uniform(0, 50, m), "duration": rng.uniform(0, 1e-8, m),
+    }
+    rows = np.zeros((m, native.RECORD_WORDS), dtype=np.int64)
+    i32 = rows.view(np.int32).reshape(m, 2 * native.RECORD_WORDS)
+    f64 = rows.view(np.float64).reshape(m, native.RECORD_WORDS)
+    i32[:, 0], i32[:, 1], i32[:, 2], i32[:, 3], i32[:, 4] = (cols[k] for k in ("hit", "container", "adjacent", "component", "source"))
+    i32[:, 5] = cols["kind"]
+    f64[:, 3:6], f64[:, 6:9], f64[:, 9:12] = cols["position"], cols["direction"], cols["normal"]
+    f64[:, 12], f64[:, 13], f64[:, 14] = cols["wavelength"], cols["travelled"], cols["duration"]
+    rows[:, 15] = np.arange(m)
+    got = native.decode_records(rows)
+    assert set(got) == {name for name, _, _ in native.EVENT_LOG_COLUMNS}
+    for name, dtype, width in native.EVENT_LOG_COLUMNS:
+        assert got[name].dtype == np.dtype(dtype) and np.array_equal(got[name], cols[name]), name
+        assert got[name].flags["C_CONTIGUOUS"]
+    assert C.sizeof(native.PvtEventRecords) == 16
+    text = open(HEADER).read()
+    assert "typedef struct PvtEventRecords" in text and "_kernel.pyx:1035-1047" in text
