@@ -238,16 +238,6 @@ __device__ __forceinline__ double rcp_normal(double x) {
     return __builtin_fma(e, r, r);
 }
 
-// Operands "in the middle of the range": |v| in (1e-100, 1e100) -- or zero, for numerators.  The quadratic and cap
-// intersections of spheres and cylinders and their normals use the short division and square-root sequences above
-// (8 and 9 instructions; the compiler's general ones: ~25 and ~20) when EVERY lane of the wave holds such operands,
-// ONE check per quadratic / pair of caps / normal; the quotients and roots are then far inside the normal range (a
-// difference of two mid-range numbers is zero or at least 2^-53 of the larger one), which is all the short sequences
-// need to return the general sequences' bits.  A wave with one lane outside (a ray within 1e-100 of parallel to a
-// cylinder's axis, an overflowed intermediate, NaN) takes the general code.
-__device__ __forceinline__ bool pvt_mid(double v) { const double a = pvt_fabs(v); return a > 1e-100 && a < 1e100; }
-__device__ __forceinline__ bool pvt_mid0(double v) { return v == 0.0 || pvt_mid(v); }
-
 // ------------------------------------------------------------ table access
 // TAB_LDS: divergent reads come from the LDS copy; uniform reads always come
 // from the global blob so the compiler can use scalar loads.
@@ -1315,17 +1305,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
                     double disc = b * b - 4.0 * a * c;
                     if (!(disc < 0.0)) {
-                        const double a2 = 2.0 * a;
-                        double ta, tb;
-                        if (__ballot(!(pvt_mid(a2) && pvt_mid0(b) && pvt_mid0(disc))) == 0ull) {
-                            const double sq = sqrt_normal(disc);
-                            ta = div_normal(-b - sq, a2); tb = div_normal(-b + sq, a2);
-                        } else {
-                            const double sq = pvt_sqrt(disc);
-                            ta = (-b - sq) / a2; tb = (-b + sq) / a2;
-                        }
-                        if (ta > kEps) fold(ta);
-                        if (tb > kEps) fold(tb);
+                        double sq = pvt_sqrt(disc);
+                        double t = (-b - sq) / (2.0 * a);
+                        if (t > kEps) fold(t);
+                        t = (-b + sq) / (2.0 * a);
+                        if (t > kEps) fold(t);
                     }
                 } else {  // capped z cylinder (:301-345)
                     double half = 0.5 * T.du(gp), radius = T.du(gp + 1);
@@ -1335,34 +1319,23 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         double c = o.x * o.x + o.y * o.y - radius * radius;
                         double disc = b * b - 4.0 * a * c;
                         if (disc >= 0.0) {
-                            const double a2 = 2.0 * a;
-                            double ta, tb;
-                            if (__ballot(!(pvt_mid(a2) && pvt_mid0(b) && pvt_mid0(disc))) == 0ull) {
-                                const double sq = sqrt_normal(disc);
-                                ta = div_normal(-b - sq, a2); tb = div_normal(-b + sq, a2);
-                            } else {
-                                const double sq = pvt_sqrt(disc);
-                                ta = (-b - sq) / a2; tb = (-b + sq) / a2;
-                            }
-                            double z = o.z + ta * d.z;
-                            if (z > -half && z < half && ta > kEps) fold(ta);
-                            z = o.z + tb * d.z;
-                            if (z > -half && z < half && tb > kEps) fold(tb);
+                            double sq = pvt_sqrt(disc);
+                            double t = (-b - sq) / (2.0 * a);
+                            double z = o.z + t * d.z;
+                            if (z > -half && z < half && t > kEps) fold(t);
+                            t = (-b + sq) / (2.0 * a);
+                            z = o.z + t * d.z;
+                            if (z > -half && z < half && t > kEps) fold(t);
                         }
                     }
                     if (pvt_fabs(d.z) > 1e-300) {
-                        const double na = -half - o.z, nb = half - o.z;
-                        double ta, tb;
-                        if (__ballot(!(pvt_mid(d.z) && pvt_mid0(na) && pvt_mid0(nb))) == 0ull) {
-                            ta = div_normal(na, d.z); tb = div_normal(nb, d.z);
-                        } else {
-                            ta = na / d.z; tb = nb / d.z;
-                        }
-                        double x = o.x + ta * d.x, y = o.y + ta * d.y;
-                        if (x * x + y * y <= radius * radius && ta > kEps) fold(ta);
-                        x = o.x + tb * d.x;
-                        y = o.y + tb * d.y;
-                        if (x * x + y * y <= radius * radius && tb > kEps) fold(tb);
+                        double t = (-half - o.z) / d.z;
+                        double x = o.x + t * d.x, y = o.y + t * d.y;
+                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                        t = (half - o.z) / d.z;
+                        x = o.x + t * d.x;
+                        y = o.y + t * d.y;
+                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
                     }
                 }
                     // The container is the nearest node the ray starts inside of: crossed exactly once for the
@@ -1606,24 +1579,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 return V3{(!use_y && !use_z) ? sx : 0.0, (use_y && !use_z) ? sy : 0.0, use_z ? sz : 0.0};
             }
             if (gt == PVT_GEOM_SPHERE) {
-                const double m2 = dot3(lp, lp);
-                if (__ballot(!(pvt_mid(m2) && pvt_mid0(lp.x) && pvt_mid0(lp.y) && pvt_mid0(lp.z))) == 0ull) {
-                    const double mag = sqrt_normal(m2);
-                    return V3{div_normal(lp.x, mag), div_normal(lp.y, mag), div_normal(lp.z, mag)};
-                }
-                const double mag = pvt_sqrt(m2);
+                double mag = pvt_sqrt(dot3(lp, lp));
                 return V3{lp.x / mag, lp.y / mag, lp.z / mag};
             }
             double half = 0.5 * T.dv(gp);
             double tol = 1e-8 + 1e-5 * pvt_fabs(half);
             if (pvt_fabs(lp.z + half) <= tol) return V3{0.0, 0.0, -1.0};
             if (pvt_fabs(lp.z - half) <= tol) return V3{0.0, 0.0, 1.0};
-            const double r2 = lp.x * lp.x + lp.y * lp.y;
-            if (__ballot(!(pvt_mid(r2) && pvt_mid0(lp.x) && pvt_mid0(lp.y))) == 0ull) {
-                const double r = sqrt_normal(r2);
-                return V3{div_normal(lp.x, r), div_normal(lp.y, r), 0.0};
-            }
-            const double r = pvt_sqrt(r2);
+            double r = pvt_sqrt(lp.x * lp.x + lp.y * lp.y);
             return V3{lp.x / r, lp.y / r, 0.0};
         };
         if (alive && t_normal) {
