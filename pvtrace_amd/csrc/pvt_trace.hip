@@ -307,6 +307,17 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             gi[at + b] = i;
         }
     };
+    // unrotated: the 3x3 blocks of both matrices of a node are the identity, bit for bit (+0.0 off the diagonal)
+    auto unrotated = [&](int n) {
+        const double one = 1.0, zero = 0.0;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                const double* want = r == c ? &one : &zero;
+                if (std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], want, 8) != 0) return false;
+                if (std::memcmp(&t->local_to_world[n * 16 + r * 4 + c], want, 8) != 0) return false;
+            }
+        return true;
+    };
     {   // recorders grouped by the (node, selector) they listen to.  A facet recorder whose facet
         // has a clearly dominant component, alone in its (axis, sign) bin, goes to the bin table;
         // the rest (no facet, oblique facets, bin collisions) to the walked list, ascending id.
@@ -331,12 +342,27 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
                 int b = bin_of(r);
                 if (b >= 0) { if (owner[b] >= 0) clash[b] = true; else owner[b] = r; }
             }
-            for (int b = 0; b < 6; b++) rec[2 + b] = (owner[b] >= 0 && !clash[b]) ? owner[b] : -1;
+            // kRecPlain on an entry: the lane need not read the recorder's row at all -- no source filter, and either no
+            // facet, or a facet that IS the bin's axis (exactly +-1 on it, zeros elsewhere) on an unrotated box, whose
+            // world normals are exactly such unit vectors: |facet - normal| is exactly 0 for every normal of the bin
+            const int node_of_key = key / 7;
+            const bool exact_normals = t->geom_type[node_of_key] == PVT_GEOM_BOX && unrotated(node_of_key);
+            auto unfiltered = [&](int r) { return !t->rec_source_mode || t->rec_source_mode[r] == 0; };
+            auto axis_facet = [&](int r, int b) {
+                const double* f = t->rec_facet + r * 3;
+                for (int a = 0; a < 3; a++)
+                    if (f[a] != (a == b / 2 ? (b % 2 ? 1.0 : -1.0) : 0.0)) return false;
+                return t->rec_atol[r] >= 0.0;
+            };
+            for (int b = 0; b < 6; b++) {
+                rec[2 + b] = (owner[b] >= 0 && !clash[b]) ? owner[b] : -1;
+                if (rec[2 + b] >= 0 && exact_normals && unfiltered(owner[b]) && axis_facet(owner[b], b)) rec[2 + b] |= kRecPlain;
+            }
             for (int r = 0; r < R; r++) {
                 if (t->rec_node[r] * 7 + t->rec_event[r] != key) continue;
                 int b = bin_of(r);
                 if (b >= 0 && !clash[b]) continue;  // served by the bin table
-                gi[lay.cand_list + at++] = r;
+                gi[lay.cand_list + at++] = r | ((unfiltered(r) && !t->rec_has_facet[r]) ? kRecPlain : 0);
             }
             rec[1] = at - rec[0];
         }
@@ -358,17 +384,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[NI_KSTART] = K > 0 ? t->coat_start[n] : 0;
         q[NI_KCOUNT] = K > 0 ? t->coat_count[n] : 0;
         q[NI_MESH] = -1;
-        {   // unrotated: the 3x3 blocks of both matrices are the identity, bit for bit (+0.0 off the diagonal)
-            bool ident = true;
-            const double one = 1.0, zero = 0.0;
-            for (int r = 0; r < 3; r++)
-                for (int c = 0; c < 3; c++) {
-                    const double* want = r == c ? &one : &zero;
-                    if (std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], want, 8) != 0) ident = false;
-                    if (std::memcmp(&t->local_to_world[n * 16 + r * 4 + c], want, 8) != 0) ident = false;
-                }
-            q[NI_IDENT] = ident ? 1 : 0;
-        }
+        q[NI_IDENT] = unrotated(n) ? 1 : 0;
         q[NI_ROT] = n;   // first node whose world->local rotation (the 3x3 block) has the same bits
         for (int e = 0; e < n; e++) {
             bool same = true;

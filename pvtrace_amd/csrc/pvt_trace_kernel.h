@@ -44,6 +44,7 @@ constexpr int kClaim = kChunk * PVT_CLAIM_CHUNKS;   // rays a wave claims per cu
 constexpr int kWaves = kBlock / 64;
 constexpr int kCursorSlots = 64;     // distinct HIP streams that may trace one scene concurrently
 constexpr int kMaxSets = 1024;       // tally sets (bundles of a stream) one launch may serve
+constexpr int kRecPlain = 1 << 30;   // flag on a recorder id in the candidate tables: matches without reading its row (host: scene_create)
 constexpr int kTallyQ = 64;          // first crossings a wave parks before it computes their statistics together
 constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a draining workgroup (>= 64: the
                                      // last stage packs the survivors into one wave; >= 69 so that the 8 KB of
@@ -1788,16 +1789,18 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 bool push = false;
                 int push_r = 0;
                 if (j < ntrips) {
-                    const int r = j < nb ? rbin : T.iv(L.cand_list + cs + j - nb);
+                    const int entry = j < nb ? rbin : T.iv(L.cand_list + cs + j - nb);
+                    const int r = entry & (kRecPlain - 1);
                     const int ri = L.rec_i + r * RI;
                     bool match = true;
-                    const int smode = T.iv(ri + RI_SRC_MODE);  // source filter (extension)
+                    const bool plain = (entry & kRecPlain) != 0;   // nothing to check (see kRecPlain)
+                    const int smode = plain ? 0 : T.iv(ri + RI_SRC_MODE);  // source filter (extension)
                     if (smode != 0) {
                         if (smode == 1) match = source < 0;
                         else if (smode == 2) match = source >= 0;
                         else match = source == T.iv(ri + RI_SRC_ID);
                     }
-                    if (match && T.iv(ri + RI_HAS_FACET) != 0) {
+                    if (!plain && match && T.iv(ri + RI_HAS_FACET) != 0) {
                         const int rd = L.rec_d + r * RD;
                         const double atol = T.dv(rd + RD_ATOL);
                         if (!t_normal) match = false;
