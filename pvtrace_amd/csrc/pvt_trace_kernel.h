@@ -66,6 +66,7 @@ enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND_RN = 26, ND = 27 }
 enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI_ROT, NI_IDENT, NI };  // node ints (NI_MESH: BVH root, -1 = none;
                                                                                           // NI_ROT: first node whose world->local rotation has the same bits;
                                                                                           // NI_IDENT: that rotation is the identity matrix, bit for bit)
+enum { HOT_T = 0, HOT_PARAMS = 3, HOT_BITS = 7 };   // Lay::hot_d records
 enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C,
        CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD_ABS_W, CD_EMS_W, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN;
                                                             // *_W: the spacing w when additionally xs[i] == xs[0] + i*w bit for bit, else NaN)
@@ -87,6 +88,10 @@ struct Lay {  // record bases (elements) inside the blobs; spectra follow the re
     int cand_list;  // recorder ids, ascending within each (node, selector)
     int crit_d;     // (n_nodes x n_nodes) critical angles asin(n[a]/n[c]) (+inf where n[a] >= n[c]),
                     // or -1 when the scene has too many nodes for the table
+    int hot_d;      // n_nodes x 8 doubles, 64-byte aligned: what the intersection loop reads of a node -- translation of
+                    // world->local (HOT_T), shape parameters (HOT_PARAMS), and one word of {identity rotation, geometry
+                    // type, rotation class} (HOT_BITS) -- so that a wave fetches a node with ONE scalar load and one wait
+                    // instead of six dependent ones (a lone wave spent a third of its step waiting for those)
     int ccrit_d;    // same shape: the cosine below which pvt_acos(cosine) exceeds that angle (host-proven
                     // threshold, NaN where it could not be proven, -inf where there is no critical angle)
 };
@@ -889,7 +894,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // Seed the whole chunk NOW, with every lane busy, instead of inside each later
                     // refill with only the dead lanes active (8 64-bit multiplies per seed): lane l
                     // prepares the stream of ray b + l and parks it in this wave's slice of LDS.
-                    unsigned long long st = A.seed + (unsigned long long)ray_lo + (unsigned long long)b + (unsigned long long)lane;
+                    // (the lane number behind an opaque copy: hoisted out of the loop, seed + ray_lo + lane would sit in two
+                    // vector registers for the whole kernel, which has none to spare)
+                    unsigned int lane_here = (unsigned int)lane;
+                    asm volatile("" : "+v"(lane_here));
+                    unsigned long long st = A.seed + (unsigned long long)ray_lo + (unsigned long long)b + (unsigned long long)lane_here;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {   // one word at a time: keeps the live range short
                         xbuf[pool_at + k * 64 + lane] = splitmix64(st);
@@ -1130,18 +1139,23 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
                     // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,
                     // quotient or stored value below can see.
-                    const bool ident = T.iu(node * NI + NI_IDENT) != 0;   // wave-uniform
+                    // the node's 64-byte record: one scalar load, all of it in SGPRs
+                    const int hn = L.hot_d + node * 8;
+                    const double tx = T.du(hn + HOT_T), ty = T.du(hn + HOT_T + 1), tz = T.du(hn + HOT_T + 2);
+                    const double gpar[3] = {T.du(hn + HOT_PARAMS), T.du(hn + HOT_PARAMS + 1), T.du(hn + HOT_PARAMS + 2)};
+                    const unsigned long long hbits = pvt_d2u(T.du(hn + HOT_BITS));
+                    const bool ident = (hbits & 1ull) != 0;   // wave-uniform
                     V3 o;
                     if (ident) {
-                        o.x = pos.x + T.du(m + 3); o.y = pos.y + T.du(m + 7); o.z = pos.z + T.du(m + 11);
+                        o.x = pos.x + tx; o.y = pos.y + ty; o.z = pos.z + tz;
                     } else {
-                        o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + T.du(m + 3);
-                        o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + T.du(m + 7);
-                        o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + T.du(m + 11);
+                        o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + tx;
+                        o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + ty;
+                        o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + tz;
                     }
                     // Nodes whose world->local rotations are bit-identical (the host files them under the
                     // first such node) see the same local direction: it and its reciprocals are reused.
-                    const int rc = T.iu(node * NI + NI_ROT);
+                    const int rc = (int)(unsigned int)(hbits >> 32);
                     if (rc != rot) {
                         if (ident) {
                             d = dir;
@@ -1153,8 +1167,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         rot = rc;
                         inv_ok = false;
                     }
-                const int gp = node * ND + ND_PARAMS;
-                const int gt = T.iu(node * NI + NI_GEOM);
+                const int gt = (int)((unsigned int)hbits >> 8);
                 // Hits are folded as they are found, in the reference's (node, k)
                 // order, so no per-ray hit list exists; the tie-breaks equal the
                 // reference's argmin scans over its hit arrays (:684-714).
@@ -1164,11 +1177,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (lazy_root && node == A.root) {
                     double bound;   // <= distance to the root's surface along any direction
                     if (lazy_root == 1) {
-                        const double mx = 0.5 * T.du(gp) - pvt_fabs(o.x), my = 0.5 * T.du(gp + 1) - pvt_fabs(o.y),
-                                     mz = 0.5 * T.du(gp + 2) - pvt_fabs(o.z);
+                        const double mx = 0.5 * gpar[0] - pvt_fabs(o.x), my = 0.5 * gpar[1] - pvt_fabs(o.y),
+                                     mz = 0.5 * gpar[2] - pvt_fabs(o.z);
                         bound = __builtin_fmin(__builtin_fmin(mx, my), mz);
                     } else {   // (R^2 - |o|^2) / (2R) <= R - |o|
-                        const double radius = T.du(gp);
+                        const double radius = gpar[0];
                         bound = (radius * radius - dot3(o, o)) * A.lazy_k;
                     }
                     const bool undecided = !(bound > 0.0) || (nhits > 0 && !(t1 < bound)) || (nhits >= 2 && !(t2 < bound)) ||
@@ -1277,7 +1290,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (__ballot(pvt_fabs(dd[0]) < 1e-300 || pvt_fabs(dd[1]) < 1e-300 || pvt_fabs(dd[2]) < 1e-300) == 0ull) {
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
-                        const double sz = T.du(gp + a);
+                        const double sz = gpar[a];
                         const double ta = (-0.5 * sz - oo[a]) * inv[a], tb = (0.5 * sz - oo[a]) * inv[a];
                         tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
                         tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
@@ -1285,7 +1298,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 } else
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    double sz = T.du(gp + a);
+                    double sz = gpar[a];
                     double lo = -0.5 * sz, hi = 0.5 * sz;
                     if (pvt_fabs(dd[a]) < 1e-300) {
                         if (oo[a] < lo || oo[a] > hi) miss = true;
@@ -1302,7 +1315,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (tmax > kEps) fold(tmax);
                 }
             } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
-                    double radius = T.du(gp);
+                    double radius = gpar[0];
                     double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
                     double disc = b * b - 4.0 * a * c;
                     if (!(disc < 0.0)) {
@@ -1313,7 +1326,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         if (t > kEps) fold(t);
                     }
                 } else {  // capped z cylinder (:301-345)
-                    double half = 0.5 * T.du(gp), radius = T.du(gp + 1);
+                    double half = 0.5 * gpar[0], radius = gpar[1];
                     double a = d.x * d.x + d.y * d.y;
                     if (a > 1e-300) {
                         double b = 2.0 * (o.x * d.x + o.y * d.y);
@@ -1380,9 +1393,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             }
         }
         // ---- container properties + volume absorption coefficient (:746-760) -----------------------
-        // The container takes few distinct values across a wave (two in a one-slab scene), so the
-        // wave walks them: node and component records then come through the scalar cache as SGPR
-        // operands instead of chains of dependent per-lane LDS reads.
+        // (node and component records are per-lane LDS reads)
         // alpha = sum of the components' coefficients; the running partial sums ARE the cumulative
         // thresholds the reference recomputes when it picks the absorbing component (:768-781): the first
         // one is kept (it decides for containers of two components; more are re-walked when a lane needs it)
