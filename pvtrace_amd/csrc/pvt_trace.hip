@@ -279,7 +279,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + N * N : -1;
     // after everything else: one 64-byte record per node with what the intersection loop reads of it (see Lay::hot_d)
     lay.hot_d = (int)(((size_t)spec_end + (lay.crit_d >= 0 ? (size_t)2 * N * N : 0) + 1 + 7) / 8 * 8);
-    std::vector<double> gd((size_t)lay.hot_d + (size_t)N * 8, 0.0);
+    std::vector<double> gd((size_t)lay.hot_d + (size_t)N * HOT, 0.0);
     if (lay.crit_d >= 0)
         for (int c = 0; c < N; c++)
             for (int a = 0; a < N; a++) {
@@ -396,9 +396,11 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             if (same) { q[NI_ROT] = e; break; }
         }
         {
-            double* h = gd.data() + lay.hot_d + n * 8;
+            double* h = gd.data() + lay.hot_d + n * HOT;
             for (int r = 0; r < 3; r++) h[HOT_T + r] = t->world_to_local[n * 16 + r * 4 + 3];
-            for (int c = 0; c < 4; c++) h[HOT_PARAMS + c] = t->geom_params[n * 4 + c];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) h[HOT_ROT + r * 3 + c] = t->world_to_local[n * 16 + r * 4 + c];
+            for (int c = 0; c < 3; c++) h[HOT_PARAMS + c] = t->geom_params[n * 4 + c];
             const unsigned long long bits = (unsigned long long)(unsigned int)((q[NI_IDENT] ? 1 : 0) | (q[NI_GEOM] << 8)) |
                                             ((unsigned long long)(unsigned int)q[NI_ROT] << 32);
             std::memcpy(&h[HOT_BITS], &bits, 8);

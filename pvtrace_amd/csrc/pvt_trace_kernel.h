@@ -66,7 +66,7 @@ enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND_RN = 26, ND = 27 }
 enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI_ROT, NI_IDENT, NI };  // node ints (NI_MESH: BVH root, -1 = none;
                                                                                           // NI_ROT: first node whose world->local rotation has the same bits;
                                                                                           // NI_IDENT: that rotation is the identity matrix, bit for bit)
-enum { HOT_T = 0, HOT_PARAMS = 3, HOT_BITS = 7 };   // Lay::hot_d records
+enum { HOT_T = 0, HOT_PARAMS = 3, HOT_BITS = 6, HOT_ROT = 7, HOT = 16 };   // Lay::hot_d records (HOT doubles apart; three shape parameters: no shape has four)
 enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C,
        CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD_ABS_W, CD_EMS_W, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN;
                                                             // *_W: the spacing w when additionally xs[i] == xs[0] + i*w bit for bit, else NaN)
@@ -88,10 +88,11 @@ struct Lay {  // record bases (elements) inside the blobs; spectra follow the re
     int cand_list;  // recorder ids, ascending within each (node, selector)
     int crit_d;     // (n_nodes x n_nodes) critical angles asin(n[a]/n[c]) (+inf where n[a] >= n[c]),
                     // or -1 when the scene has too many nodes for the table
-    int hot_d;      // n_nodes x 8 doubles, 64-byte aligned: what the intersection loop reads of a node -- translation of
+    int hot_d;      // n_nodes x HOT doubles, 64-byte aligned: what the intersection loop reads of a node -- translation of
                     // world->local (HOT_T), shape parameters (HOT_PARAMS), and one word of {identity rotation, geometry
                     // type, rotation class} (HOT_BITS) -- so that a wave fetches a node with ONE scalar load and one wait
-                    // instead of six dependent ones (a lone wave spent a third of its step waiting for those)
+                    // instead of six dependent ones (a lone wave spent a third of its step waiting for those); the nine
+                    // rotation entries of world->local follow (HOT_ROT, row-major), read for rotated nodes only
     int ccrit_d;    // same shape: the cosine below which pvt_acos(cosine) exceeds that angle (host-proven
                     // threshold, NaN where it could not be proven, -inf where there is no critical angle)
 };
@@ -1135,12 +1136,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 const int lazy_root = (MESH || RECORD) ? 0 : A.lazy_root;   // wave-uniform (tally launches only)
                 for (int k = 0; k < A.n_nodes; k++) {
                     const int node = !lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1));
-                    const int m = node * ND + ND_W2L;
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
                     // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,
                     // quotient or stored value below can see.
                     // the node's 64-byte record: one scalar load, all of it in SGPRs
-                    const int hn = L.hot_d + node * 8;
+                    const int hn = L.hot_d + node * HOT;
                     const double tx = T.du(hn + HOT_T), ty = T.du(hn + HOT_T + 1), tz = T.du(hn + HOT_T + 2);
                     const double gpar[3] = {T.du(hn + HOT_PARAMS), T.du(hn + HOT_PARAMS + 1), T.du(hn + HOT_PARAMS + 2)};
                     const unsigned long long hbits = pvt_d2u(T.du(hn + HOT_BITS));
@@ -1149,9 +1149,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (ident) {
                         o.x = pos.x + tx; o.y = pos.y + ty; o.z = pos.z + tz;
                     } else {
-                        o.x = T.du(m + 0) * pos.x + T.du(m + 1) * pos.y + T.du(m + 2) * pos.z + tx;
-                        o.y = T.du(m + 4) * pos.x + T.du(m + 5) * pos.y + T.du(m + 6) * pos.z + ty;
-                        o.z = T.du(m + 8) * pos.x + T.du(m + 9) * pos.y + T.du(m + 10) * pos.z + tz;
+                        const int rm = hn + HOT_ROT;
+                        o.x = T.du(rm + 0) * pos.x + T.du(rm + 1) * pos.y + T.du(rm + 2) * pos.z + tx;
+                        o.y = T.du(rm + 3) * pos.x + T.du(rm + 4) * pos.y + T.du(rm + 5) * pos.z + ty;
+                        o.z = T.du(rm + 6) * pos.x + T.du(rm + 7) * pos.y + T.du(rm + 8) * pos.z + tz;
                     }
                     // Nodes whose world->local rotations are bit-identical (the host files them under the
                     // first such node) see the same local direction: it and its reciprocals are reused.
@@ -1160,9 +1161,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         if (ident) {
                             d = dir;
                         } else {
-                            d.x = T.du(m + 0) * dir.x + T.du(m + 1) * dir.y + T.du(m + 2) * dir.z;
-                            d.y = T.du(m + 4) * dir.x + T.du(m + 5) * dir.y + T.du(m + 6) * dir.z;
-                            d.z = T.du(m + 8) * dir.x + T.du(m + 9) * dir.y + T.du(m + 10) * dir.z;
+                            const int rm = hn + HOT_ROT;
+                            d.x = T.du(rm + 0) * dir.x + T.du(rm + 1) * dir.y + T.du(rm + 2) * dir.z;
+                            d.y = T.du(rm + 3) * dir.x + T.du(rm + 4) * dir.y + T.du(rm + 5) * dir.z;
+                            d.z = T.du(rm + 6) * dir.x + T.du(rm + 7) * dir.y + T.du(rm + 8) * dir.z;
                         }
                         rot = rc;
                         inv_ok = false;

@@ -31,8 +31,8 @@ for name in names:
         for k in range(steps):
             pipe.submit(sets[k % 4], n, seed=1 + k * n, timed=False, closing=k >= steps - 3, tail=k == steps - 1)
         pipe.reduce_totals(); pipe.synchronize()
-    run(30)
-    steps = 300
+    steps = int(os.environ.get("PVT_STREAM_STEPS", "300"))
+    run(max(3, steps // 10))
     torch.cuda.synchronize(); t = time.perf_counter(); run(steps); dt = time.perf_counter() - t
     print(f"{name:12s} {steps * n / dt:.4e} photons/s   {dt / steps * 1e3:.4f} ms per 10^6", flush=True)
     ds.close()
