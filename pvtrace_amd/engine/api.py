@@ -600,7 +600,9 @@ def merge_shards(results):
     for key in first.data:
         if key not in data:
             data[key] = np.concatenate([r.data[key] for r in results])
-    sources = [s for r in results for s in r.sources]
+    from pvtrace_amd.engine.emit import ChainedSources
+
+    sources = ChainedSources([r.sources for r in results])
     kernel_ms = [r.kernel_ms for r in results if r.kernel_ms is not None]
     return EngineResult(first.compiled, data, sources, first.max_events, first.record_every,
                         max(r.elapsed for r in results), kernel_ms=max(kernel_ms) if kernel_ms else None)
@@ -693,10 +695,13 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
         if per_group > 1:   # the lights are sampled bundle by bundle, in the reference's order, then traced together
             from pvtrace_amd.engine import emit as emit_mod
 
-            parts = [emit_mod.emit_bundle(scene, min(bundle, n - at),
-                                          seed=None if state["emit_seed"] is None else int(state["emit_seed"]) + traced + at)
-                     for at in range(0, n, bundle)]
-            host = tuple(np.concatenate([p[k] for p in parts]) for k in range(3)) + ([x for p in parts for x in p[3]],)
+            starts = range(0, n, bundle)
+            if state["emit_seed"] is None:   # the global numpy generator: drawn in order
+                parts = [emit_mod.emit_bundle(scene, min(bundle, n - at), seed=None) for at in starts]
+            else:   # every bundle has its own generator: the bundles of the group are sampled side by side
+                parts = emit_mod.emit_bundles(scene, [min(bundle, n - at) for at in starts],
+                                              [int(state["emit_seed"]) + traced + at for at in starts])
+            host = tuple(np.concatenate([p[k] for p in parts]) for k in range(3)) + (emit_mod.ChainedSources([p[3] for p in parts]),)
             return session, session.submit(n, int(seed) + traced, ray_offset=base_offset, workgroups_per_cu=3,
                                            host_rays=host, **group, **kwargs), n
         bundle_emit_seed = None if state["emit_seed"] is None else int(state["emit_seed"]) + traced
@@ -708,7 +713,10 @@ def simulate_stream(scene, num_rays, bundle=50000, seed=None, **kwargs):
     try:
         for d in (devices if devices is not None else [device]):   # inside the try: a failing k-th Session must not
             sessions.append(Session(scene, device=d, emission=emission))   # leak the k-1 resident scenes before it
-        if sessions[0].emission == "device" and state["emit_seed"] is None:
+        if state["emit_seed"] is None:
+            # one draw from the global generator seeds the whole stream's emission (reproducible under
+            # np.random.seed): device emission needs a seed anyway, and on the host the bundles of a group can then
+            # be sampled side by side from their own generators instead of one after the other from the global one
             state["emit_seed"] = np.random.randint(0, 2 ** 31 - 1)
         window = 2 * len(sessions)
         while traced < num_rays or in_flight:

@@ -307,6 +307,22 @@ def emit_bundle(scene, num_rays, seed=None):
     return positions, directions, wavelengths, sources.tolist()
 
 
+def emit_bundles(scene, counts, seeds):
+    """`emit_bundle(scene, counts[k], seeds[k])` for every k, on the emission worker threads (numpy's elementwise
+    kernels release the GIL; each bundle has its own generator, so the results do not depend on the schedule).
+    Scenes with a per-ray Python delegate are sampled one bundle after the other (user code is not assumed
+    thread-safe)."""
+    global _POOL
+    jobs = list(zip(counts, seeds))
+    if len(jobs) < 2 or not all(EmitterTables(scene, strict=False).builtin):
+        return [emit_bundle(scene, c, seed=sd) for c, sd in jobs]
+    import concurrent.futures
+
+    if _POOL is None:
+        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=8, thread_name_prefix="pvt-emit")
+    return list(_POOL.map(lambda job: emit_bundle(scene, job[0], seed=job[1]), jobs))
+
+
 class RoundRobinSources(collections.abc.Sequence):
     """The `sources` list of a bundle -- ray i comes from light ``(offset + i) % n_lights``
     (reference emit.py:112-116 builds the list eagerly; 10^6 Python strings cost more than
@@ -334,7 +350,7 @@ class RoundRobinSources(collections.abc.Sequence):
         return self.names[(self.offset + index) % len(self.names)]
 
     def __eq__(self, other):
-        if isinstance(other, (list, tuple, RoundRobinSources)):
+        if isinstance(other, (list, tuple, collections.abc.Sequence)) and not isinstance(other, str):
             return len(other) == self.length and all(a == b for a, b in zip(self, other))
         return NotImplemented
 
@@ -343,6 +359,52 @@ class RoundRobinSources(collections.abc.Sequence):
 
     def __repr__(self):
         return f"RoundRobinSources({self.names!r}, {self.length})"
+
+
+class ChainedSources(collections.abc.Sequence):
+    """Several `sources` sequences one after the other (the bundles of a group, the shards of a split bundle),
+    without materialising 10^6 Python strings: an index is looked up in the part that holds it, a slice that lies
+    inside one part is that part's slice.  Compares equal to the equivalent list."""
+
+    def __init__(self, parts):
+        self.parts = [p for p in parts if len(p)]
+        self.starts = np.concatenate(([0], np.cumsum([len(p) for p in self.parts]))).astype(np.int64)
+
+    def __len__(self):
+        return int(self.starts[-1])
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            start, stop, step = index.indices(len(self))
+            if step == 1 and stop > start:
+                k = int(np.searchsorted(self.starts, start, side="right")) - 1
+                if stop <= self.starts[k + 1]:
+                    return self.parts[k][start - int(self.starts[k]):stop - int(self.starts[k])]
+                pieces, at = [], start
+                while at < stop:
+                    k = int(np.searchsorted(self.starts, at, side="right")) - 1
+                    upto = min(stop, int(self.starts[k + 1]))
+                    pieces.append(self.parts[k][at - int(self.starts[k]):upto - int(self.starts[k])])
+                    at = upto
+                return ChainedSources(pieces)
+            return [self[i] for i in range(start, stop, step)]
+        if index < 0:
+            index += len(self)
+        if not 0 <= index < len(self):
+            raise IndexError("ray index out of range")
+        k = int(np.searchsorted(self.starts, index, side="right")) - 1
+        return self.parts[k][index - int(self.starts[k])]
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, RoundRobinSources, ChainedSources)):
+            return len(other) == len(self) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    def tolist(self):
+        return [x for p in self.parts for x in p]
+
+    def __repr__(self):
+        return f"ChainedSources({len(self.parts)} parts, {len(self)})"
 
 
 def sources_for(scene, num_rays, offset=0):

@@ -419,3 +419,30 @@ def test_only_the_unrecognised_delegate_is_called_per_ray():
     cos_t = dirs[0::2, 2]
     assert cos_t.min() >= np.cos(0.3) - 1e-12 and np.allclose(np.linalg.norm(dirs, axis=1), 1.0)
     assert np.allclose(dirs[1::2], (0.0, 0.0, -1.0))
+
+
+def test_bundles_of_a_group_sampled_side_by_side_equal_one_after_the_other():
+    from pvtrace_amd.engine.emit import emit_bundles
+    from tests import scenes
+
+    scene = scenes.lsc_equivalent()
+    counts, seeds = [3000, 3000, 3000, 1234], [11, 3011, 6011, 9011]
+    together = emit_bundles(scene, counts, seeds)
+    for (count, seed), got in zip(zip(counts, seeds), together):
+        want = emit_bundle(scene, count, seed=seed)
+        assert all(np.array_equal(got[k], want[k]) for k in range(3)) and list(got[3][:5]) == list(want[3][:5])
+
+
+def test_chained_sources_behave_like_the_concatenated_list():
+    from pvtrace_amd.engine.emit import ChainedSources, RoundRobinSources
+
+    a, b, c = RoundRobinSources(["x", "y", "z"], 7), ["q", "r"], RoundRobinSources(["x", "y", "z"], 5, offset=2)
+    chained, flat = ChainedSources([a, b, [], c]), list(a) + b + list(c)
+    assert len(chained) == 14 and list(chained) == flat and chained == flat and chained.tolist() == flat
+    assert chained[-1] == flat[-1] and chained[7] == "q"
+    with pytest.raises(IndexError):
+        chained[14]
+    for lo, hi in ((2, 6), (5, 12), (7, 9), (0, 14), (3, 3), (9, 14)):
+        assert list(chained[lo:hi]) == flat[lo:hi]
+    assert chained[::3] == flat[::3]
+    assert isinstance(chained[2:6], RoundRobinSources)      # a slice inside one part is that part's own slice
