@@ -17,6 +17,7 @@ host mode: THAT delegate is called once per ray, the light's other delegates are
 still sampled vectorised and no Ray object is built per photon.
 """
 import functools
+import threading
 
 import collections.abc
 
@@ -156,13 +157,14 @@ class EmitterTables:
 
 
 _POOL = None
+_IN_WORKER = threading.local()
 
 
 def _chunked(fn, n, min_rows=200_000):
     """Run `fn(lo, hi)` over row ranges covering [0, n): on a few worker threads when the bundle is large
     (numpy's elementwise kernels release the GIL).  The draws themselves stay sequential, so the result does
     not depend on the split."""
-    if n < 2 * min_rows:
+    if n < 2 * min_rows or getattr(_IN_WORKER, "active", False):   # (never wait on the pool from one of its workers)
         fn(0, n)
         return
     global _POOL
@@ -320,7 +322,14 @@ def emit_bundles(scene, counts, seeds):
 
     if _POOL is None:
         _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=8, thread_name_prefix="pvt-emit")
-    return list(_POOL.map(lambda job: emit_bundle(scene, job[0], seed=job[1]), jobs))
+    def one(job):
+        _IN_WORKER.active = True
+        try:
+            return emit_bundle(scene, job[0], seed=job[1])
+        finally:
+            _IN_WORKER.active = False
+
+    return list(_POOL.map(one, jobs))
 
 
 class RoundRobinSources(collections.abc.Sequence):
