@@ -77,6 +77,74 @@ class RecorderResult:
                 f"crossings={self.crossings})")
 
 
+class LazyLogColumns(dict):
+    """The reference's `data` dict whose DENSE event-log columns (`recorded * max_events` rows each, pre-filled
+    like the reference's) are built when they are first looked at.  What came off the GPU are the rows that were
+    written (`packed_rows`: the columns, `row_start`: first packed row of each recorded ray); scattering them into
+    twelve dense host arrays is most of the time of a default `simulate()` call and 15 GB of page faults for
+    10^6 rays x 128 events -- spent only on the columns somebody indexes.  Everything else behaves like the dict
+    the reference returns (iteration, `items()`, equality, pickling materialise what they need)."""
+
+    def __init__(self, eager, builders, row_start, packed_rows):
+        super().__init__(eager)
+        self._builders = dict(builders)
+        for name in self._builders:
+            super().__setitem__(name, None)
+        self.row_start, self.packed_rows = row_start, packed_rows
+
+    def _build(self, name):
+        build = self._builders.pop(name, None)
+        if build is not None:
+            super().__setitem__(name, build())
+
+    def _build_all(self):
+        for name in list(self._builders):
+            self._build(name)
+
+    def __getitem__(self, name):
+        self._build(name)
+        return super().__getitem__(name)
+
+    def __setitem__(self, name, value):
+        self._builders.pop(name, None)
+        super().__setitem__(name, value)
+
+    def __delitem__(self, name):
+        self._builders.pop(name, None)
+        super().__delitem__(name)
+
+    def __iter__(self):   # (also keeps dict(self) / {**self} off the C fast path that would copy the placeholders)
+        return iter(list(super().keys()))
+
+    def get(self, name, default=None):
+        return self[name] if name in self else default
+
+    def pop(self, name, *default):
+        self._build(name)
+        return super().pop(name, *default)
+
+    def items(self):
+        self._build_all()
+        return super().items()
+
+    def values(self):
+        self._build_all()
+        return super().values()
+
+    def copy(self):
+        self._build_all()
+        return dict(super().items())
+
+    def __eq__(self, other):
+        self._build_all()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))
+
+
 class EngineResult:
     """Outcome of one bundle (reference api.py:81-194).
 
@@ -145,8 +213,9 @@ class EngineResult:
         counts = self.data["counts"]
         if len(counts) == 0:
             return collections.Counter()
-        if self.packed:
-            values, tallies = np.unique(self.data["kind"], return_counts=True)
+        if self.packed or isinstance(self.data, LazyLogColumns):   # the written rows are at hand: no mask over the dense log
+            kinds = self.data["kind"] if self.packed else self.data.packed_rows["kind"]
+            values, tallies = np.unique(kinds, return_counts=True)
             return collections.Counter({Event(int(v)): int(t) for v, t in zip(values, tallies)})
         kinds = self.data["kind"].reshape(self.num_recorded, self.max_events)
         valid = np.arange(self.max_events)[None, :] < counts[:, None]
@@ -163,8 +232,11 @@ class EngineResult:
         """One list of (Ray, Event, metadata) per recorded ray."""
         d = self.data
         which = self.recorded_indices
+        lazy = isinstance(d, LazyLogColumns)
+        if lazy:   # walk the written rows themselves instead of building twelve dense columns for it
+            starts, d = d.row_start, d.packed_rows
         for j in range(self.num_recorded):
-            rows = self.rows_of(j)
+            rows = slice(int(starts[j]), int(starts[j + 1])) if lazy else self.rows_of(j)
             steps = []
             for row in range(rows.start, rows.stop):
                 sid = int(d["source"][row])
@@ -272,15 +344,22 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
         data.update(written)
         return data
     index_host = index.cpu().numpy()
-    for name, dtype, width in native.EVENT_LOG_COLUMNS:
-        fill = -1 if name in native._ID_COLUMNS else 0
-        shape = (rows, 3) if width == 3 else (rows,)
-        # zero columns stay uncommitted (calloc); the -1 fill is the reference's eager cost too
-        host = np.zeros(shape, dtype=dtype) if fill == 0 else np.full(shape, fill, dtype=dtype)
-        if used:
-            host[index_host] = written[name]
-        data[name] = host
-    return data
+
+    def dense(name, dtype, width):
+        def build():
+            fill = -1 if name in native._ID_COLUMNS else 0
+            shape = (rows, 3) if width == 3 else (rows,)
+            # zero columns stay uncommitted (calloc) where no row was written; the -1 fill is the reference's cost too
+            host = np.zeros(shape, dtype=dtype) if fill == 0 else np.full(shape, fill, dtype=dtype)
+            if used:
+                host[index_host] = written[name]
+            return host
+        return build
+
+    starts = np.zeros(n_recorded + 1, dtype=np.int64)
+    np.cumsum(data["counts"], out=starts[1:])
+    return LazyLogColumns(data, {name: dense(name, dtype, width) for name, dtype, width in native.EVENT_LOG_COLUMNS},
+                          starts, written)
 
 
 # Scenes recently resident on a GPU, kept for the next `simulate` call on the same scene: flattening is 0.1 ms, but
@@ -597,9 +676,20 @@ def merge_shards(results):
         for r in results[1:]:
             total += r.data[key]
         data[key] = total
-    for key in first.data:
-        if key not in data:
-            data[key] = np.concatenate([r.data[key] for r in results])
+    if all(isinstance(r.data, LazyLogColumns) for r in results):
+        # the shards' dense columns stay unbuilt: the merged ones are built (shard by shard, then joined) on demand
+        data["counts"] = np.concatenate([r.data["counts"] for r in results])
+        starts = np.zeros(len(data["counts"]) + 1, dtype=np.int64)
+        np.cumsum(data["counts"], out=starts[1:])
+        packed_rows = {name: np.concatenate([r.data.packed_rows[name] for r in results])
+                       for name in first.data.packed_rows}
+        builders = {name: (lambda name=name: np.concatenate([r.data[name] for r in results]))
+                    for name, _, _ in native.EVENT_LOG_COLUMNS}
+        data = LazyLogColumns(data, builders, starts, packed_rows)
+    else:
+        for key in first.data:
+            if key not in data:
+                data[key] = np.concatenate([r.data[key] for r in results])
     from pvtrace_amd.engine.emit import ChainedSources
 
     sources = ChainedSources([r.sources for r in results])

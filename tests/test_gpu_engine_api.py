@@ -525,3 +525,31 @@ def test_resident_scenes_are_reused_and_an_edited_scene_is_a_new_one():
     assert len(api._RESIDENT) <= api._RESIDENT_MAX
     engine.release_resident_scenes()
     assert api._RESIDENT == []
+
+
+@pytest.mark.gpu
+def test_dense_log_columns_are_built_on_demand_and_equal_the_packed_rows():
+    from pvtrace_amd.engine.api import EngineResult, LazyLogColumns
+    from pvtrace_amd.engine.native import EVENT_LOG_COLUMNS
+
+    scene = scenes.lsc_equivalent()
+    result = engine.simulate(scene, 3000, seed=3, emit_seed=8)
+    assert isinstance(result.data, LazyLogColumns) and len(result.data._builders) == len(EVENT_LOG_COLUMNS)
+    counts, histories = result.event_counts(), list(result.histories())
+    assert len(result.data._builders) == len(EVENT_LOG_COLUMNS)          # neither needed a dense column
+    position = result.data["position"]
+    assert position.shape == (3000 * result.max_events, 3) and len(result.data._builders) == len(EVENT_LOG_COLUMNS) - 1
+    dense = EngineResult(result.compiled, dict(result.data), result.sources, result.max_events, result.record_every,
+                         result.elapsed)
+    assert type(dense.data) is dict and dense.event_counts() == counts
+    assert [[(repr(r), e, m) for r, e, m in h] for h in dense.histories()] == \
+           [[(repr(r), e, m) for r, e, m in h] for h in histories]
+    packed = engine.simulate(scene, 3000, seed=3, emit_seed=8, packed_log=True)
+    for name, _, _ in EVENT_LOG_COLUMNS:
+        assert np.array_equal(packed.data[name], result.data.packed_rows[name])
+    assert np.array_equal(packed.data["row_start"], result.data.row_start)
+    # the dense columns are the reference's: pre-filled, the written rows at j * max_events + k
+    j = int(np.argmax(result.data["counts"]))
+    rows = result.rows_of(j)
+    assert np.array_equal(dense.data["kind"][rows], packed.data["kind"][packed.rows_of(j)])
+    assert dense.data["hit"][rows.stop] == -1 or rows.stop % result.max_events == 0

@@ -446,3 +446,36 @@ def test_chained_sources_behave_like_the_concatenated_list():
         assert list(chained[lo:hi]) == flat[lo:hi]
     assert chained[::3] == flat[::3]
     assert isinstance(chained[2:6], RoundRobinSources)      # a slice inside one part is that part's own slice
+
+
+def test_lazy_log_columns_behave_like_the_dict_they_stand_for():
+    import pickle
+
+    from pvtrace_amd.engine.api import LazyLogColumns
+
+    built = []
+
+    def column(name):
+        def build():
+            built.append(name)
+            return np.arange(3) + len(name)
+        return build
+
+    def fresh():
+        return LazyLogColumns({"counts": np.array([1, 2])}, {"kind": column("kind"), "hit": column("hit")},
+                              np.array([0, 1, 3]), {"kind": np.array([1, 2, 3]), "hit": np.array([0, 0, 1])})
+
+    d = fresh()
+    assert list(d) == ["counts", "kind", "hit"] and "kind" in d and len(d) == 3 and built == []
+    assert d["kind"].tolist() == [4, 5, 6] and built == ["kind"]
+    d["kind"]
+    assert built == ["kind"]                                   # built once
+    plain = dict(d)
+    assert type(plain) is dict and built == ["kind", "hit"] and plain["hit"].tolist() == [3, 4, 5]
+    assert {**fresh()}["kind"] is not None and fresh().get("hit").tolist() == [3, 4, 5] and fresh().get("nope", 5) == 5
+    assert all(v is not None for v in fresh().values()) and dict(fresh().items())["hit"].tolist() == [3, 4, 5]
+    thawed = pickle.loads(pickle.dumps(fresh()))
+    assert type(thawed) is dict and thawed["kind"].tolist() == [4, 5, 6]
+    e = fresh()
+    e["kind"] = 7
+    assert e["kind"] == 7 and e.pop("hit").tolist() == [3, 4, 5] and "hit" not in e

@@ -11,7 +11,7 @@ for n in (100_000, 1_000_000):
     r = engine.simulate(scene, n, seed=1)
     wall = time.perf_counter() - tic
     print(f"n={n}: trace elapsed {r.elapsed*1e3:.1f} ms ({n/r.elapsed/1e6:.1f} M rays/s, reference convention: trace only), "
-          f"kernel+memsets {r.kernel_ms:.1f} ms, end-to-end incl. emission/alloc/15GB download {wall:.2f} s ({n/wall/1e6:.2f} M rays/s); "
+          f"kernel+memsets {r.kernel_ms:.1f} ms, end-to-end incl. emission and the download of the written rows (dense columns built on demand) {wall:.2f} s ({n/wall/1e6:.2f} M rays/s); "
           f"events {int(r.data['counts'].sum())}", flush=True)
     del r
 
