@@ -355,6 +355,7 @@ def main():
                     self.step(2_000_000 + k, True, tail=k >= 1)
                 self.pipe.reduce_totals()
                 self.pipe.synchronize()
+                self.pipe.reset_totals()   # (totals reduced over the ranks are final: the pipeline refuses more bundles)
             t_spin, k_spin = time.perf_counter(), 0
             while time.perf_counter() - t_spin < seconds:
                 for _ in range(20):
