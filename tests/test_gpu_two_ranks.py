@@ -156,3 +156,27 @@ def test_bench_refuses_two_rccl_ranks_on_one_gpu_with_a_readable_line():
     assert done.returncode != 0
     lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
     assert lines and "one GPU per rank" in json.loads(lines[-1])["error"]
+
+
+@pytest.mark.timeout(1800)
+def test_bench_script_over_rccl_with_one_rank():
+    """The collectives of an N-GPU run on the real backend (RCCL), as far as a one-GPU box can take them: the
+    bench with its process group forced on for a single rank -- communicator with `device_id`, the counting
+    all-reduce, the spin-up's reduction, barriers, the MAX over ranks, the tallies' all-reduce of every window."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, PVT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1")
+    env.pop("PVT_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+           "--photons", "50000", "--repeats", "2", "--sustained-s", "1.0", "--total-photons", "400001",
+           "--ray-buffers", "2", "--spinup-s", "0.05", "--no-cpu-baseline", "--config-photons", "100000",
+           "--config-sustained-s", "0.2"]
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert done.returncode == 0, done.stderr[-2000:]
+    out = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["rccl_ranks"] == 1 and out["n_gpus"] == 1 and out["value"] > 0
+    assert out["strong_scaling"]["photons_tallied"] == 400001
+    assert abs(out["tallies"]["entering"] + out["tallies"]["reflected"] - 1.0) < 1e-12
+    assert out["configs"]["cfg4"]["sustained"]["value"] > 0 and out["configs"]["cfg5"]["value"] > 0
