@@ -1,3 +1,5 @@
+#!/bin/bash
+# Developer tool (GPU box): SQ counters of single launches of the headline scene at several sizes (tools/gpu_perf.py lsc): the bulk of a launch against its tail
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# Developer tool (GPU box): carry tests, then per-launch timelines (tools/gpu_timeline2.sh) of the bench with and without carried photons
 timeout 600 python -m pytest tests/test_gpu_carry.py tests/test_gpu_engine_api.py tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -5
 bash tools/gpu_timeline2.sh 2>&1 | grep -v "^+" | awk '/=== /{c=0} {c++; if (c<=9) print}'
 F="--no-cpu-baseline --repeats 2 --sustained-s 1.0 --total-photons 0 --extra-configs none"
