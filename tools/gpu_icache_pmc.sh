@@ -1,3 +1,5 @@
+#!/bin/bash
+# Developer tool (GPU box): instruction-cache counters of single launches of the headline scene (tools/gpu_perf.py lsc)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp

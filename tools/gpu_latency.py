@@ -1,3 +1,4 @@
+"""Developer tool (GPU box): kernel time of one launch of the headline scene from 64 to 10^6 photons (launch floor and ramp)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np

@@ -1,3 +1,4 @@
+"""Developer tool (GPU box): 2000 create/close cycles of a device scene, then streams of launches: free device memory must not drift."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,3 +1,4 @@
+"""Developer tool (GPU box): kernel time against photons per launch (4 096 ... 4 10^6) of the headline scene, tally mode."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np

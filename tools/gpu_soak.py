@@ -1,3 +1,4 @@
+"""Developer tool (GPU box): 400 engine.simulate() calls alternating tally and sampled-history modes: results stay put, memory does not grow."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch

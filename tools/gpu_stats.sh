@@ -1,4 +1,5 @@
 #!/bin/bash
+# Developer tool (GPU box): the -DPVT_STATS=1 build's counters (wave-iterations, live lanes, lanes per class, section clocks of a lone wave) for one 10^6-photon launch of cfg2
 export PVT_LIB=$GRAFT_REPO_ROOT/build/dev/stats.so
 python - <<'PY' 2>&1 | grep "pvt stats" | tail -6
 import os, sys
