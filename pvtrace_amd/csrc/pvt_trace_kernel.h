@@ -673,7 +673,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     const unsigned long long tl_c0 = __builtin_readcyclecounter();   // shader clock (s_memtime); wall_clock64 is the constant 100 MHz one
 #endif
     const Lay L = A.lay;
-    const bool coated = A.n_coat > 0;  // wave-uniform
+    // Launch constants that the loop only asks yes/no questions of, in ONE scalar register.  Kept as separate
+    // conditions each becomes a 64-bit lane mask that the allocator holds (spills) for the whole loop; `uf(bit)`
+    // re-derives the answer from the word where it is asked (the empty asm keeps the compiler from hoisting it).
+    enum { UF_COATED = 0, UF_FUSE_EXIT, UF_CRIT, UF_HAS_REC, UF_TQ_POS, UF_BINS_LDS, UF_EMIT_FULL, UF_EMIT_KT, UF_LAZY1, UF_LAZY2 };
+    const unsigned int uflags =
+        (A.n_coat > 0 ? 1u << UF_COATED : 0u) | (A.fuse_exit != 0 ? 1u << UF_FUSE_EXIT : 0u) | (L.crit_d >= 0 ? 1u << UF_CRIT : 0u) |
+        (A.n_rec > 0 ? 1u << UF_HAS_REC : 0u) | (A.tq_pos ? 1u << UF_TQ_POS : 0u) | (A.bins_in_lds ? 1u << UF_BINS_LDS : 0u) |
+        (A.emit_method == PVT_EMIT_FULL ? 1u << UF_EMIT_FULL : 0u) | (A.emit_method == PVT_EMIT_KT ? 1u << UF_EMIT_KT : 0u) |
+        (A.lazy_root == 1 ? 1u << UF_LAZY1 : 0u) | (A.lazy_root == 2 ? 1u << UF_LAZY2 : 0u);
+    auto uf = [&](int bit) -> bool {
+        unsigned int f = uflags;
+        asm volatile("" : "+s"(f));
+        return ((f >> bit) & 1u) != 0u;
+    };
 
     // ---- stage tables + zero accumulators --------------------------------
     double* lds_d = smem;
@@ -809,7 +822,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (ib < 0 || ib >= nb) continue;
                     slot = T.iv(hi_ + HI_OFF) + ia * nb + ib;
                 }
-                if (A.bins_in_lds) atomicAdd(&acc_bins[slot], 1u);
+                if (uf(UF_BINS_LDS)) atomicAdd(&acc_bins[slot], 1u);
                 else atomicAdd(reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i + slot, 1ull);
             }
         }
@@ -1133,7 +1146,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 // compare the crossings they have with a cheap lower bound of the root's distance -- the
                 // distance to the root's nearest face -- and only the lanes it cannot decide for pay for the
                 // root's intersection; in a typical scene (a 5 cm slab in a 5 m world) none ever does.
-                const int lazy_root = (MESH || RECORD) ? 0 : A.lazy_root;   // wave-uniform (tally launches only)
+                const int lazy_root = (MESH || RECORD) ? 0 : (uf(UF_LAZY1) ? 1 : (uf(UF_LAZY2) ? 2 : 0));   // wave-uniform (tally launches only)
                 for (int k = 0; k < A.n_nodes; k++) {
                     const int node = !lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1));
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
@@ -1517,11 +1530,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         const int eh = T.iv(ci + CI_EMS_HIST);
                         const double ew = T.dv(cd + CD_EMS_W);
                         double p1;
-                        if (A.emit_method == PVT_EMIT_FULL) {
+                        if (uf(UF_EMIT_FULL)) {
                             p1 = 0.0;
                         } else {
                             double e_nm = wl;
-                            if (A.emit_method == PVT_EMIT_KT) {
+                            if (uf(UF_EMIT_KT)) {
                                 const double kb_ev = 1.380649e-23 / 1.60217662e-19;
                                 double e_ev = div_normal(1240.0, e_nm) + 1.5 * kb_ev * 300.0;
                                 e_nm = div_normal(1240.0, e_ev);
@@ -1655,9 +1668,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 bool tir;
                 // (the reference compares acos(c1) with the critical angle; the host has turned that into a
                 // comparison of c1 itself wherever it could prove the two agree for every double)
-                const double cc = L.crit_d >= 0 ? T.dv(L.ccrit_d + container * A.n_nodes + adjacent) : __builtin_nan("");
+                const bool crit_tab = uf(UF_CRIT);
+                const double cc = crit_tab ? T.dv(L.ccrit_d + container * A.n_nodes + adjacent) : __builtin_nan("");
                 if (cc == cc) tir = c1 < cc;
-                else if (L.crit_d >= 0) tir = pvt_acos(c1) > T.dv(L.crit_d + container * A.n_nodes + adjacent);
+                else if (crit_tab) tir = pvt_acos(c1) > T.dv(L.crit_d + container * A.n_nodes + adjacent);
                 else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(container * ND + ND_RN)));
                 if (tir) {
                     r = 1.0;
@@ -1674,7 +1688,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 }
             }
             int coat = -1;
-            if (coated && fres) {
+            if (uf(UF_COATED) && fres) {
                 const int cs = T.iv(hit * NI + NI_KSTART), ce = cs + T.iv(hit * NI + NI_KCOUNT);
                 const V3 lpos = local_point(), nloc = local_normal(lpos);
                 const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
@@ -1751,7 +1765,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             // g / dn -- below kEps, hence ignored (_kernel.pyx:271-276), whenever g <= kEps/2 * dn; g is formed
             // with the very operations the next step would use (o = pos + t, h = 0.5 * size).  A photon that
             // cannot be cleared this way (grazing departures) simply takes its next step.
-            if (!RECORD && !MESH && A.fuse_exit != 0 && !terminal && count < A.maxsteps &&
+            if (!RECORD && !MESH && uf(UF_FUSE_EXIT) && !terminal && count < A.maxsteps &&
                 (ev_kind == PVT_EV_REFLECT ? container == A.root : adjacent == A.root)) {
                 const V3 lp = local_point();
                 const int gp = hit * ND + ND_PARAMS;
@@ -1774,7 +1788,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // serialises same-address lanes; no wave-uniform recorder loop, no scalar-load
         // chains, no software scan).  Recorder order per lane is ascending, as in the
         // reference's loop (_kernel.pyx:517-556).
-        if (A.n_rec > 0) {
+        if (uf(UF_HAS_REC)) {
             // Facet recorders whose facets have distinct dominant axes (the usual "one recorder
             // per box face") are found in O(1): the host files each under the bin (dominant axis,
             // sign) of its facet, the lane looks up the bin of ITS normal and verifies that one
@@ -1847,7 +1861,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (push) {
                         tq_r[at] = push_r;
                         tq_d[at] = wl; tq_d[kTallyQ + at] = t_cos; tq_d[2 * kTallyQ + at] = duration; tq_d[3 * kTallyQ + at] = travelled;
-                        if (A.tq_pos) {
+                        if (uf(UF_TQ_POS)) {
                             const V3 lpos = local_point();   // position in the recorder node's frame
                             tq_d[4 * kTallyQ + at] = lpos.x; tq_d[5 * kTallyQ + at] = lpos.y; tq_d[6 * kTallyQ + at] = lpos.z;
                         }
