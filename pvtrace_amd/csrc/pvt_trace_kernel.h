@@ -752,9 +752,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #if PVT_STATS
     unsigned long long st_iters = 0, st_lane_steps = 0, st_drain_iters = 0, st_drain_lane_steps = 0;
     unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_mark = 0;
-#define PVT_MARK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); if (solo) st_t[k] += now_ - st_mark; st_mark = now_; } while (0)
+#define PVT_MARK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); if (ws & WS_SOLO) st_t[k] += now_ - st_mark; st_mark = now_; } while (0)
     unsigned long long st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bulk-phase lane counts per section
-#define PVT_COUNT(k, pred) do { unsigned long long b_ = __ballot(pred); if (!exhausted) st_c[k] += __popcll(b_); } while (0)
+#define PVT_COUNT(k, pred) do { unsigned long long b_ = __ballot(pred); if (!(ws & WS_EXHAUSTED)) st_c[k] += __popcll(b_); } while (0)
 #else
 #define PVT_MARK(k) do {} while (0)
 #define PVT_COUNT(k, pred) do {} while (0)
@@ -770,17 +770,18 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     unsigned int w_next = w_first, w_end = w_first, w_base = 0;
     unsigned int w_claim_end = w_first < n_local ? (n_local - w_first < (unsigned int)kClaim ? n_local : w_first + kClaim) : w_first;
     unsigned int c_next = 0, c_end = 0;   // window of parked photons
-    bool c_first = true;
-    bool exhausted = false;
-    bool carry_in_live = !RECORD && (A.carry_flags & 1) != 0;   // (wave-uniform) parked photons may still be waiting
+    // The wave's own yes/no state, one bit each in ONE scalar register (as separate flags each is a 64-bit lane mask
+    // held -- or spilled -- across the whole loop): the ray cursor is dry; that has been counted in the workgroup;
+    // in the drain rendezvous; last wave standing; parked photons may still be waiting; first claim of them
+    enum { WS_EXHAUSTED = 1, WS_COUNTED = 2, WS_REGIME = 4, WS_SOLO = 8, WS_CARRY_IN = 16, WS_C_FIRST = 32 };
+    unsigned int ws = WS_C_FIRST | ((!RECORD && (A.carry_flags & 1) != 0) ? WS_CARRY_IN : 0u);
     // Per-wave pool of ready-made RNG states for the claimed chunk (4 x 64 u64 = 2 KB).  It lives
     // in the photon-exchange buffer: that buffer is first used when ALL waves of the workgroup
     // have run the cursor dry, i.e. after every pool has been consumed.
     const bool seed_pool = A.xslots * (14 + SEENW) >= kWaves * 4 * 64;
     const int pool_at = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 4 * 64;   // wave-uniform
     // drain-phase consolidation state (all wave-uniform)
-    const int wave = threadIdx.x >> 6;
-    bool counted = false, in_regime = false, solo = false;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int members = 0, parity = 0;
 
     // Statistics of the parked first crossings, one lane per record: the recorder's distinct count, the
@@ -838,28 +839,28 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             // beyond is claimed through the claim cursor, one atomic per 64.  (A claim per refill, for just the lanes
             // that died in the last step, put a queue of ~10^5 same-address atomics in front of every step: measured
             // 21 us per iteration instead of 11.)
-            if (PVT_CARRY_IN && carry_in_live && need != 0ull) {
+            if (PVT_CARRY_IN && (ws & WS_CARRY_IN) && need != 0ull) {
                 const __attribute__((address_space(4))) KArgs* ak =
                     (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(ak));
                 const unsigned int have = *ak->carry_in_count;
                 if (c_next >= c_end) {
                     unsigned int b = ~0u;
-                    if (c_first) {
-                        c_first = false;
+                    if (ws & WS_C_FIRST) {
+                        ws &= ~(unsigned int)WS_C_FIRST;
                         b = wave_in_set * 64u;
                     } else if (have > waves_in_set * 64u) {
                         if (lane == 0) b = atomicAdd(cursor + 1, 64u);
                         b = __builtin_amdgcn_readfirstlane(b) + waves_in_set * 64u;
                     }
                     if (b >= have) {
-                        carry_in_live = false;
+                        ws &= ~(unsigned int)WS_CARRY_IN;
                     } else {
                         c_next = b;
                         c_end = have - b < 64u ? have : b + 64u;
                     }
                 }
-                if (carry_in_live) {
+                if (ws & WS_CARRY_IN) {
                     const unsigned int want = __popcll(need), got = c_end - c_next < want ? c_end - c_next : want;
                     const unsigned int rank = rank_in(need);
                     if (!alive && rank < got) {
@@ -884,7 +885,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
         for (int pass = 0; pass < 2 && need != 0ull; pass++) {
             if (w_next >= w_end) {
-                if (exhausted) break;
+                if (ws & WS_EXHAUSTED) break;
                 unsigned int b = w_end;          // next chunk of the rays this wave has claimed ...
                 if (b >= w_claim_end) {          // ... or a new claim (the first one is the wave's own index: no atomic;
                                                  // 4096 waves starting together on ONE word cost the launch ~50 us)
@@ -898,7 +899,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     unsigned int c = 0;
                     if (lane == 0) c = atomicAdd(cursor, claim);
                     c = __builtin_amdgcn_readfirstlane(c) + waves_in_set * (unsigned int)kClaim;
-                    if (c >= n_local) { exhausted = true; break; }
+                    if (c >= n_local) { ws |= WS_EXHAUSTED; break; }
                     b = c;
                     w_claim_end = (n_local - c < claim) ? n_local : c + claim;
                 }
@@ -978,7 +979,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // emptied waves retire.  Which lane carries a photon never affects its history (RNG
         // stream, seen-mask and log rows travel with it), so results stay bit-identical.
         if constexpr (!RECORD) {
-            if (PVT_CARRY_OUT && exhausted && (A.carry_flags & 2)) {
+            if (PVT_CARRY_OUT && (ws & WS_EXHAUSTED) && (A.carry_flags & 2)) {
                 // no rays left for this wave: its live photons are parked for the next launch on the stream
                 const unsigned long long live_mask = __ballot(alive);
                 if (live_mask != 0ull) {
@@ -1003,22 +1004,24 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 }
             }
         }
-        if (exhausted && !counted) {
-            counted = true;
+        if ((ws & (WS_EXHAUSTED | WS_COUNTED)) == WS_EXHAUSTED) {
+            ws |= WS_COUNTED;
             if (lane == 0) atomicAdd(&ctl[CTL_EXHAUSTED], 1);
         }
-        if (!in_regime) {
+        if (!(ws & WS_REGIME)) {
             if (__ballot(alive) == 0ull) break;  // wave drained and cursor exhausted
-            if (A.xslots > 0 && exhausted && !solo &&
-                __hip_atomic_load(&ctl[CTL_EXHAUSTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kWaves) {
-                in_regime = true;
+            // (values read back from LDS are made scalars explicitly -- readfirstlane -- so that the state they
+            // decide stays in scalar registers)
+            if (A.xslots > 0 && (ws & (WS_EXHAUSTED | WS_SOLO)) == WS_EXHAUSTED &&
+                __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_EXHAUSTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kWaves) {
+                ws |= WS_REGIME;
                 if (lane == 0) ctl[CTL_IN + wave] = 1;
                 __syncthreads();  // R0: everybody still running is now in lock-step
-                members = (ctl[CTL_IN] ? 1 : 0) | (ctl[CTL_IN + 1] ? 2 : 0) | (ctl[CTL_IN + 2] ? 4 : 0) |
-                          (ctl[CTL_IN + 3] ? 8 : 0);
+                members = __builtin_amdgcn_readfirstlane((ctl[CTL_IN] ? 1 : 0) | (ctl[CTL_IN + 1] ? 2 : 0) | (ctl[CTL_IN + 2] ? 4 : 0) |
+                                                         (ctl[CTL_IN + 3] ? 8 : 0));
             }
         }
-        if (in_regime) {
+        if (ws & WS_REGIME) {
             const unsigned long long live_mask = __ballot(alive);
             const int live = __popcll(live_mask);
             int* live_tab = ctl + CTL_LIVE + parity * kWaves;  // double-buffered by iteration parity
@@ -1028,7 +1031,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             int l[kWaves], total = 0, nw = 0, before = 0, pos_in_set = 0;
 #pragma unroll
             for (int w = 0; w < kWaves; w++) {
-                l[w] = ((members >> w) & 1) ? live_tab[w] : 0;
+                l[w] = ((members >> w) & 1) ? __builtin_amdgcn_readfirstlane(live_tab[w]) : 0;
                 if (l[w] == 0) members &= ~(1 << w);  // that wave retires now (it sees its own 0)
                 else {
                     if (w < wave) { before += l[w]; pos_in_set += 1; }
@@ -1038,8 +1041,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             }
             if (live == 0) break;
             if (nw == 1) {
-                in_regime = false;
-                solo = true;  // last wave standing: no more rendezvous
+                ws = (ws & ~(unsigned int)WS_REGIME) | WS_SOLO;  // last wave standing: no more rendezvous
             } else if (total <= 64 * (nw - 1) && total <= A.xslots) {
                 constexpr int X = kXSlots;   // (A.xslots is 0 or kXSlots: constant offsets in the LDS instructions)
                 if (alive) {
@@ -1082,20 +1084,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 for (int w = 0; w < kWaves; w++)
                     if (((members >> w) & 1) && kept < keep) { m2 |= 1 << w; kept += 1; }
                 members = m2;
-                if (keep == 1) { in_regime = false; solo = true; }
+                if (keep == 1) ws = (ws & ~(unsigned int)WS_REGIME) | WS_SOLO;
             }
         }
 #if PVT_STATS
         {
             unsigned long long live = __popcll(__ballot(alive));
             st_iters += 1; st_lane_steps += live;
-            if (exhausted) { st_drain_iters += 1; st_drain_lane_steps += live; }
+            if (ws & WS_EXHAUSTED) { st_drain_iters += 1; st_drain_lane_steps += live; }
         }
 #endif
 
 #if PVT_TIMELINE
         if (tl_iters == 0) tl_t[2] = wall_clock64();
-        if (exhausted && tl_t[3] == 0) tl_t[3] = wall_clock64();
+        if ((ws & WS_EXHAUSTED) && tl_t[3] == 0) tl_t[3] = wall_clock64();
         tl_iters += 1;
 #endif
         PVT_MARK(0);  // refill + drain bookkeeping
@@ -1887,7 +1889,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         atomicAdd(c + 2, st_drain_iters); atomicAdd(c + 3, st_drain_lane_steps);
         atomicAdd(c + 4, 1ull);
         for (int k = 0; k < 7; k++) atomicAdd(c + 8 + k, st_t[k]);
-        atomicAdd(c + 15, solo ? 1ull : 0ull);
+        atomicAdd(c + 15, (ws & WS_SOLO) ? 1ull : 0ull);
         for (int k = 0; k < 8; k++) atomicAdd(c + 16 + k, st_c[k]);
     }
 #endif
