@@ -672,17 +672,17 @@ hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const
 #if PVT_DEV_VARIANTS
     if (emit || mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
     if constexpr (TAB_LDS && SEENW == 1) {
-        if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_rec3<true, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
+        if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, true, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((trace_kernel_w4<false, true, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
     }
 #else
     if (emit) {
         if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, true>), dim3(grid), dim3(kBlock), lds, st, a);
-        else if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_rec3<TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
+        else if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((trace_kernel_w4<false, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
     } else {
         if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
-        else if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_rec3<TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
+        else if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((trace_kernel_w4<false, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
     }
 #endif

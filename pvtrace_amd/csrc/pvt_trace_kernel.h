@@ -1931,10 +1931,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
 }
 
-// Entry points.  Tally launches of scenes of analytic shapes run four waves per SIMD (128 registers, none spilled);
-// their history-keeping variants three (see trace_kernel_rec3).  Mesh variants (BVH walk,
-// 180-200 registers unforced: two waves per SIMD) are held to three waves (168 registers, 5-28 spilled):
-// 25 % faster on large meshes in tally mode, no slower with histories.
+// Entry points.  Scenes of analytic shapes run four waves per SIMD, tally launches and history-keeping ones alike
+// (108-118 registers, none spilled: the build switches machine-level loop-invariant code motion off, which had kept
+// every constant of the loop in a register of its own -- with it the history variants needed 144 registers and ran
+// three waves; at four they are 3-10 % faster).  Mesh variants (BVH walk, 144-154 registers, none spilled) run three.
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) trace_kernel(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, MESH>(A);
@@ -1942,13 +1942,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_w4(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, false>(A);
-}
-// History variants of analytic scenes: three waves per SIMD (144 registers, none spilled).  Held to four waves they
-// spill 11 registers -- scratch traffic that showed up as a fifth of the launch's HBM writes -- and are no faster
-// (10^6 LSC rays with full histories 0.863 ms either way, hello_world 0.270 against 0.285 ms).
-template <bool TAB_LDS, int SEENW, bool EMIT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) trace_kernel_rec3(KArgs A) {
-    trace_body<true, TAB_LDS, SEENW, EMIT, false>(A);
 }
 
 }  // namespace
