@@ -4,4 +4,4 @@
 name=$1; shift
 mkdir -p /root/repo/build/dev
 cd /root/repo/pvtrace_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -mllvm -disable-machine-licm -fPIC -shared -DPVT_DEV_VARIANTS=1 "$@" pvt_trace.hip -o /root/repo/build/dev/$name.so
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -mllvm -disable-machine-licm -fno-unroll-loops -fPIC -shared -DPVT_DEV_VARIANTS=1 "$@" pvt_trace.hip -o /root/repo/build/dev/$name.so

@@ -2,7 +2,7 @@
 # Developer tool: register / spill metadata and SGPR-spill traffic (v_readlane/v_writelane) of the dev variants.
 # usage: tools/isa_meta.sh [extra hipcc flags]   (writes /tmp/isa_meta.s)
 cd /root/repo/pvtrace_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -mllvm -disable-machine-licm -DPVT_DEV_VARIANTS=1 "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -mllvm -disable-machine-licm -fno-unroll-loops -DPVT_DEV_VARIANTS=1 "$@" \
     --cuda-device-only -S pvt_trace.hip -o /tmp/isa_meta.s 2>/dev/null
 python3 - <<'PY'
 import re

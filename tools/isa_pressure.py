@@ -7,7 +7,7 @@ floor = int(sys.argv[2]) if len(sys.argv) > 2 else 112
 tmp = tempfile.mkdtemp(prefix="isap_")
 src = os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace.hip")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-g", "-std=c++17", "-ffp-contract=off",
-                       "-fno-fast-math", "-munsafe-fp-atomics", "-mllvm", "-disable-machine-licm", "--cuda-device-only", "-S", src, "-o", os.path.join(tmp, "k.s")],
+                       "-fno-fast-math", "-munsafe-fp-atomics", "-mllvm", "-disable-machine-licm", "-fno-unroll-loops", "--cuda-device-only", "-S", src, "-o", os.path.join(tmp, "k.s")],
                       stderr=subprocess.DEVNULL)
 s = open(os.path.join(tmp, "k.s")).read()
 files = dict(re.findall(r'\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', s)) or dict(re.findall(r'\.file\s+(\d+)\s+"([^"]+)"', s))

@@ -7,7 +7,7 @@ variant = "trace_kernel_w4ILb0ELb1ELi1ELb0E"
 tmp = tempfile.mkdtemp(prefix="isas_")
 src = os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace.hip")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-g", "-std=c++17", "-ffp-contract=off",
-                       "-fno-fast-math", "-munsafe-fp-atomics", "-mllvm", "-disable-machine-licm", "-DPVT_DEV_VARIANTS=1", "--cuda-device-only", "-S", src, "-o", os.path.join(tmp, "k.s")],
+                       "-fno-fast-math", "-munsafe-fp-atomics", "-mllvm", "-disable-machine-licm", "-fno-unroll-loops", "-DPVT_DEV_VARIANTS=1", "--cuda-device-only", "-S", src, "-o", os.path.join(tmp, "k.s")],
                       stderr=subprocess.DEVNULL)
 s = open(os.path.join(tmp, "k.s")).read()
 files = dict(re.findall(r'\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', s)) or dict(re.findall(r'\.file\s+(\d+)\s+"([^"]+)"', s))

@@ -6,7 +6,7 @@ variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernel_w4ILb0ELb1ELi1ELb0
 tmp = tempfile.mkdtemp(prefix="isa_")
 src = os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace.hip")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                       "-fno-fast-math", "-munsafe-fp-atomics", "-mllvm", "-disable-machine-licm", "--cuda-device-only", "-S", src, "-o",
+                       "-fno-fast-math", "-munsafe-fp-atomics", "-mllvm", "-disable-machine-licm", "-fno-unroll-loops", "--cuda-device-only", "-S", src, "-o",
                        os.path.join(tmp, "k.s")])
 s = open(os.path.join(tmp, "k.s")).read()
 for f in re.split(r"\n\s*\.globl\s+", s)[1:]:
