@@ -199,8 +199,8 @@ def load_pmc(name, value_per_gpu, cus):
             # VALU busy WHILE THE LAUNCHES OVERLAP: the instruction count per photon is a property of the work (PMC,
             # the same whether dispatches are serialised or not), the photon rate is measured here, and the shader
             # clock was measured inside overlapping launches (s_memtime against s_memrealtime in every wave,
-            # tools/gpu_clock_overlap.sh -> profiles/r03_c_clock_overlap.json) instead of assumed
-            clock = os.path.join(ROOT, "profiles", "r03_c_clock_overlap.json")
+            # tools/gpu_clock_overlap.sh -> profiles/r03_j_clock_overlap.json) instead of assumed
+            clock = os.path.join(ROOT, "profiles", "r03_j_clock_overlap.json")
             if os.path.exists(clock):
                 c = json.load(open(clock))
                 side["valu_busy_under_overlap"] = rate * 4.0 / (cus * 4 * c["shader_clock_mhz"] * 1e6)
