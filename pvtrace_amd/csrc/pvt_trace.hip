@@ -579,6 +579,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMemset(s->d_cursor, 0, 64 * kCursorSlots + 256));
     HIP_TRY(hipMalloc(&s->d_set_cursor, (size_t)kCursorSlots * kMaxSets * 4));
     if (!bvh_nodes.empty()) {
+        bvh_nodes.push_back(pvt::BvhNode{});   // sentinel: the walk fetches one record ahead of the one it tests
         HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
         HIP_TRY(hipMalloc(&s->d_tris, bvh_tris.size() * sizeof(pvt::MeshTri)));
         HIP_TRY(hipMemcpy(s->d_bvh, bvh_nodes.data(), bvh_nodes.size() * sizeof(pvt::BvhNode), hipMemcpyHostToDevice));

@@ -1246,8 +1246,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
                     int i = T.iu(node * NI + NI_MESH);
                     const int end = A.bvh[i].skip;
+                    pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
                     while (i < end) {
-                        const pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
+                        // the successor after a HIT is the next record (depth-first order): fetched while this box is
+                        // tested (one record past the array's end exists: the host appends a sentinel)
+                        const pvt::BvhNode nxt = A.bvh[i + 1];
                         double tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
                         for (int a = 0; a < 3; a++) {
@@ -1255,7 +1258,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
                             tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
                         }
-                        if (tmax < tmin || tmax < 0.0) { i = b.skip; continue; }
+                        if (tmax < tmin || tmax < 0.0) { i = b.skip; if (i < end) b = A.bvh[i]; continue; }
                         const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
                         const pvt::MeshTri* tr = A.tris + tri_start;
                         for (int k = 0; k < tn; k++, tr++) {
@@ -1292,6 +1295,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             nhits += 1;
                         }
                         i += 1;
+                        b = nxt;
                     }
                 } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
                 double tmin = -INFINITY, tmax = INFINITY;
