@@ -1935,12 +1935,15 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
 }
 
-// Entry points.  Scenes of analytic shapes run four waves per SIMD, tally launches and history-keeping ones alike
-// (108-118 registers, none spilled: the build switches machine-level loop-invariant code motion off, which had kept
-// every constant of the loop in a register of its own -- with it the history variants needed 144 registers and ran
-// three waves; at four they are 3-10 % faster).  Mesh variants (BVH walk, 144-154 registers, none spilled) run three.
+// Entry points.  Every variant runs four waves per SIMD.  Scenes of analytic shapes, tally launches and
+// history-keeping ones alike, need 108-118 registers, none spilled (the build switches machine-level loop-invariant
+// code motion off, which had kept every constant of the loop in a register of its own -- with it the history variants
+// needed 144 registers and ran three waves; at four they are 3-10 % faster).  Mesh variants would take 144-154
+// registers: held to 128 they park about sixty values in scratch around the BVH walk (photon state the walk does not
+// touch), and the fourth wave is worth more than that costs -- the walk is a chain of dependent loads: +8 ... +19 % in
+// the pipelined stream, 3.1 -> 2.7 ms for a single 10^6-photon launch on the 327 680-face ball (five waves: worse).
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) trace_kernel(KArgs A) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, MESH>(A);
 }
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
