@@ -11,8 +11,11 @@ run() { name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/mesh_pmc_${scene}_$name -o pmc -- \
       python $R/tools/gpu_mesh_stream.py $scene > $R/gpurun_out/mesh_pmc_${scene}_$name.log 2>&1
 }
+# (the TA_* / TCP_* counter sets did not come back within ten minutes on this pool: run only on request)
+if [ "$2" = with-ta ]; then
 run ta TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum
+fi
 run sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY
 run tcc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 cd $R
