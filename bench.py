@@ -134,7 +134,7 @@ def parse_args():
     ap.add_argument("--reduce", choices=("end", "bundle"), default="end",
                     help="multi-GPU: all-reduce the tallies once per job, inside the timed region "
                          "(default), or after every bundle")
-    ap.add_argument("--config", choices=("cfg2", "cfg4", "cfg5"), default="cfg2",
+    ap.add_argument("--config", default="cfg2",
                     help="scene of the main loop (developer flag for profiles; the contract's metric is cfg2). "
                          "cfg4/cfg5 use device-side emission")
     ap.add_argument("--extra-configs", default="cfg4,cfg5",

@@ -8,15 +8,20 @@
   its parent, in a 10 cm air sphere; 30-degree cone from z = -1).
 * cfg5: reference examples/006 Coatings.ipynb cell 5 (10x10x1 cm slab, perfect mirror on the x>0, y>0 quadrant of
   the top face, 5x5 rectangular source above it) plus an isotropic 1 cm^-1 scatterer (qy 1) in the slab.
+* tiles<k>: the scene-size family: a k x k array of cfg2's slab (5x5x1 cm, Lumogen F Red 305 +
+  background, plain Fresnel surfaces, so the reference kernel runs it too) on a 5.5 cm pitch in cfg2's world,
+  lit from above by one rectangular source that covers the array, 20-degree cone, 555 nm: k*k + 1 nodes.  The
+  reference intersects every node in every step (pvtrace/engine/_kernel.pyx:666-680).
 """
 import functools
 
 import numpy as np
 
 from pvtrace_amd import (
-    LSC, Box, Coating, CoatedSurfaceDelegate, Cylinder, Light, Material, Node, Scatterer, Scene, Sphere,
-    Surface, cone, rectangular_mask,
+    LSC, Absorber, Box, Coating, CoatedSurfaceDelegate, Cylinder, Light, Luminophore, Material, Node, Scatterer,
+    Scene, Sphere, Surface, cone, rectangular_mask,
 )
+from pvtrace_amd.data import lumogen_f_red_305
 from pvtrace_amd.engine import Heatmap, Histogram, Recorder
 from pvtrace_amd.engine.instrument import face_recorders
 
@@ -65,6 +70,50 @@ def cfg5_coated_slab(scatter=1.0):
     return Scene(world)
 
 
+TILE_PITCH = 5.5
+
+
+def tiles_lsc(k, recorders="centre"):
+    """k x k slabs of the headline LSC in one world (k*k + 1 nodes).  `recorders`: "centre" = the headline's ten
+    face recorders on the middle tile; "all" = additionally `escaping` and `lost` on every tile (2 k^2 + 10)."""
+    x = np.arange(400, 800)
+    world = Node(name="World", geometry=Box((500.0, 500.0, 100.0), material=Material(refractive_index=1.0)))
+    middle = (k // 2) * k + k // 2
+    for i in range(k * k):
+        row, col = divmod(i, k)
+        tile = Node(
+            name=f"tile-{row}-{col}", parent=world,
+            geometry=Box((5.0, 5.0, 1.0), material=Material(
+                refractive_index=1.5,
+                components=[
+                    Luminophore(coefficient=np.column_stack((x, lumogen_f_red_305.absorption(x) * 10.0)),
+                                emission=np.column_stack((x, lumogen_f_red_305.emission(x))),
+                                quantum_yield=1.0, name=f"Lumogen F Red 305 ({row},{col})"),
+                    Absorber(0.1, name=f"Background ({row},{col})"),
+                ])))
+        tile.location = ((col - 0.5 * (k - 1)) * TILE_PITCH, (row - 0.5 * (k - 1)) * TILE_PITCH, 0.0)
+        recs = face_recorders() if i == middle else []
+        if recorders == "all":
+            recs = recs + [Recorder(f"escaping-{row}-{col}", event="escaping"), Recorder(f"lost-{row}-{col}", event="lost")]
+        tile.recorders = recs
+    half = 0.5 * k * TILE_PITCH
+    light = Node(name="Light", parent=world,
+                 light=Light(position=functools.partial(rectangular_mask, half, half),
+                             direction=functools.partial(cone, np.radians(20)), name="Light"))
+    light.location = (0.0, 0.0, 5.0)
+    light.rotate(np.radians(180), (1, 0, 0))
+    return Scene(world)
+
+
+def _tiles_config(k):
+    return dict(build=functools.partial(tiles_lsc, k), emit_method="kT",
+                workload=f"scene-size family: {k}x{k} array of cfg2's slab on a 5.5 cm pitch ({k * k + 1} nodes), "
+                         f"rectangular source over the array, 20-degree cone @555 nm, 10 recorders on the middle "
+                         f"tile, record_every=0")
+
+
+TILE_SIZES = (1, 2, 3, 4, 6, 8, 11)
+
 CONFIGS = {
     "cfg2": dict(build=cfg2_lsc, emit_method="kT",
                  workload="BASELINE configs[1]: 5x5x1 cm LSC((5,5,1)), Lumogen F Red 305 (10 cm^-1 peak, qy 1) + "
@@ -77,3 +126,4 @@ CONFIGS = {
                  workload="BASELINE configs[4]: 10x10x1 cm slab, mirror coating on a quadrant of the top face + "
                           "1 cm^-1 isotropic scatterer, 5x5 cm rectangular source, 11 recorders, record_every=0"),
 }
+CONFIGS.update({f"tiles{k}": _tiles_config(k) for k in TILE_SIZES})

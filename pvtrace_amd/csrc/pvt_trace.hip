@@ -192,14 +192,51 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             if (t->mesh_faces[k] < 0 || t->mesh_faces[k] >= t->n_mesh_vertices)
                 return fail(PVT_ERR_INVALID, "mesh face indexes a missing vertex");
     }
-    // fixed-stride records, then the pooled spectra (see the enums next to struct Lay)
-    Lay lay{};
-    lay.comp_d = N * ND;
-    lay.rec_d = lay.comp_d + C * CD;
-    lay.hist_d = lay.rec_d + R * RD;
-    lay.coat_d = lay.hist_d + H * HD;
-    const int spec_d = lay.coat_d + K * KD;
-    // Spectra, packed per component.  RN(1/spacing) when EVERY interval of the abscissae has the same bits and
+    // ---- classes: what many nodes have in common is stored once (see the enums next to struct Lay) ----
+    // unrotated: the 3x3 blocks of both matrices of a node are the identity, bit for bit (+0.0 off the diagonal)
+    auto unrotated = [&](int n) {
+        const double one = 1.0, zero = 0.0;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                const double* want = r == c ? &one : &zero;
+                if (std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], want, 8) != 0) return false;
+                if (std::memcmp(&t->local_to_world[n * 16 + r * 4 + c], want, 8) != 0) return false;
+            }
+        return true;
+    };
+    // rotation classes: nodes whose two 3x3 blocks have the same bits share a record (and, in the wave-uniform
+    // node loop, the local direction and its reciprocals)
+    std::vector<int> rot_class(N), rot_first;
+    for (int n = 0; n < N; n++) {
+        int cls = -1;
+        for (size_t e = 0; e < rot_first.size() && cls < 0; e++) {
+            bool same = true;
+            for (int r = 0; r < 3 && same; r++)
+                for (int c = 0; c < 3 && same; c++)
+                    same = std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], &t->world_to_local[rot_first[e] * 16 + r * 4 + c], 8) == 0 &&
+                           std::memcmp(&t->local_to_world[n * 16 + r * 4 + c], &t->local_to_world[rot_first[e] * 16 + r * 4 + c], 8) == 0;
+            if (same) cls = (int)e;
+        }
+        if (cls < 0) { cls = (int)rot_first.size(); rot_first.push_back(n); }
+        rot_class[n] = cls;
+    }
+    const int Q = (int)rot_first.size();
+    // refractive-index classes (bit-identical indices)
+    bool index_ok = true;   // refractive indices the known-divisor division is proven for
+    std::vector<int> idx_class(N), idx_first;
+    for (int n = 0; n < N; n++) {
+        const double v = t->refractive_index[n];
+        if (!(std::isfinite(v) && v > 1e-100 && v < 1e100)) index_ok = false;
+        int cls = -1;
+        for (size_t e = 0; e < idx_first.size() && cls < 0; e++)
+            if (std::memcmp(&t->refractive_index[idx_first[e]], &v, 8) == 0) cls = (int)e;
+        if (cls < 0) { cls = (int)idx_first.size(); idx_first.push_back(n); }
+        idx_class[n] = cls;
+    }
+    if (!index_ok) return fail(PVT_ERR_INVALID, "refractive indices must be finite and positive");
+    const int M = (int)idx_first.size();
+
+    // Spectra, packed per DISTINCT table.  RN(1/spacing) when EVERY interval of the abscissae has the same bits and
     // the ordinates keep the quotient inside div_known's domain (no -0.0, no extreme magnitudes):
     auto even_rcp = [](const double* xs, const double* ys, int n) -> double {
         if (n < 2) return NAN;
@@ -243,6 +280,77 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         }
         return w;
     };
+    // The reference keeps one set of tables per component of every node (compiler.py:160-215); a scene of many nodes
+    // made of the same material repeats them.  Here a table that has the bits of an earlier one (abscissae, ordinates,
+    // sampling mode) is that earlier one: the 121 tiles of an LSC array share ONE absorption and ONE emission table.
+    auto abs_hist = [&](int c) { return t->comp_abs_hist && t->comp_abs_hist[c] ? 1 : 0; };
+    auto ems_hist = [&](int c) { return t->comp_ems_hist && t->comp_ems_hist[c] ? 1 : 0; };
+    auto same_abs = [&](int c, int e) {
+        const int n = t->comp_abs_n[c];
+        return n == t->comp_abs_n[e] && abs_hist(c) == abs_hist(e) &&
+               std::memcmp(t->abs_x + t->comp_abs_start[c], t->abs_x + t->comp_abs_start[e], (size_t)n * 8) == 0 &&
+               std::memcmp(t->abs_y + t->comp_abs_start[c], t->abs_y + t->comp_abs_start[e], (size_t)n * 8) == 0;
+    };
+    auto same_ems = [&](int c, int e) {
+        const int n = t->comp_ems_n[c];
+        return n == t->comp_ems_n[e] && ems_hist(c) == ems_hist(e) &&
+               std::memcmp(t->ems_x + t->comp_ems_start[c], t->ems_x + t->comp_ems_start[e], (size_t)n * 8) == 0 &&
+               std::memcmp(t->ems_cdf + t->comp_ems_start[c], t->ems_cdf + t->comp_ems_start[e], (size_t)n * 8) == 0;
+    };
+    std::vector<int> abs_of(C), ems_of(C);   // the component whose tables component c uses (itself: it owns them)
+    {
+        std::vector<int> abs_owners, ems_owners;
+        for (int c = 0; c < C; c++) {
+            abs_of[c] = ems_of[c] = c;
+            for (int e : abs_owners) if (same_abs(c, e)) { abs_of[c] = e; break; }
+            for (int e : ems_owners) if (same_ems(c, e)) { ems_of[c] = e; break; }
+            if (abs_of[c] == c) abs_owners.push_back(c);
+            if (ems_of[c] == c) ems_owners.push_back(c);
+        }
+    }
+    // component RECORDS: the components of a node are a run of records; a node whose run has the contents of an
+    // earlier node's run shares it (NI_CREC).  Component IDS (events, `source`, recorder filters) stay the reference's.
+    auto same_component = [&](int c, int e) {
+        return t->comp_type[c] == t->comp_type[e] && t->comp_phase_type[c] == t->comp_phase_type[e] &&
+               std::memcmp(&t->comp_qy[c], &t->comp_qy[e], 8) == 0 && std::memcmp(&t->comp_tau_rad[c], &t->comp_tau_rad[e], 8) == 0 &&
+               std::memcmp(&t->comp_tau_nr[c], &t->comp_tau_nr[e], 8) == 0 &&
+               std::memcmp(&t->comp_phase_param[c], &t->comp_phase_param[e], 8) == 0 &&
+               abs_of[c] == abs_of[e] && ems_of[c] == ems_of[e];
+    };
+    std::vector<int> node_crec(N, 0), rec_comp;   // rec_comp[r] = the component id whose fields record r holds
+    for (int n = 0; n < N; n++) {
+        const int c0 = t->comp_start[n], cc = t->comp_count[n];
+        if (cc < 0 || c0 < 0 || c0 + cc > C) return fail(PVT_ERR_INVALID, "component range of a node out of bounds");
+        int found = -1;
+        for (int e = 0; e < n && found < 0; e++) {
+            if (t->comp_count[e] != cc) continue;
+            bool same = true;
+            for (int k = 0; k < cc && same; k++) same = same_component(c0 + k, t->comp_start[e] + k);
+            if (same) found = node_crec[e];
+        }
+        if (found < 0) {
+            found = (int)rec_comp.size();
+            for (int k = 0; k < cc; k++) rec_comp.push_back(c0 + k);
+        }
+        node_crec[n] = found;
+    }
+    const int CR = (int)rec_comp.size();
+    // recorder candidate blocks: only for the nodes somebody listens to
+    std::vector<int> node_cand(N, -1);
+    int n_cand = 0;
+    for (int r = 0; r < R; r++) {
+        const int n = t->rec_node[r];
+        if (n < 0 || n >= N) return fail(PVT_ERR_INVALID, "recorder on a missing node");
+        if (node_cand[n] < 0) node_cand[n] = n_cand++;
+    }
+
+    // fixed-stride records, then the pooled spectra
+    Lay lay{};
+    lay.comp_d = N * ND;
+    lay.rec_d = lay.comp_d + CR * CD;
+    lay.hist_d = lay.rec_d + R * RD;
+    lay.coat_d = lay.hist_d + H * HD;
+    const int spec_d = lay.coat_d + K * KD;
     std::vector<double> c_abs_rcp(C), c_abs_w(C), c_ems_rcp_x(C), c_ems_rcp_c(C), c_ems_w(C);
     std::vector<int> c_abs_x(C), c_abs_y(C), c_ems_x(C), c_ems_c(C), c_abs_g(C), c_ems_gx(C), c_ems_gc(C);
     int spec_len = 0, guide_len = 0;
@@ -252,48 +360,67 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         const double* ex = t->ems_x + t->comp_ems_start[c];
         const double* ec = t->ems_cdf + t->comp_ems_start[c];
         const int an = t->comp_abs_n[c], en = t->comp_ems_n[c];
-        c_abs_rcp[c] = even_rcp(ax, ay, an);
-        c_ems_rcp_x[c] = even_rcp(ex, ec, en);
-        c_ems_rcp_c[c] = even_rcp(ec, ex, en);
-        const bool abs_hist = t->comp_abs_hist && t->comp_abs_hist[c], ems_hist = t->comp_ems_hist && t->comp_ems_hist[c];
-        c_abs_w[c] = abs_hist ? NAN : even_w(ax, an, c_abs_rcp[c]);
-        c_ems_w[c] = ems_hist ? NAN : even_w(ex, en, c_ems_rcp_x[c]);
-        const bool abs_compact = c_abs_w[c] == c_abs_w[c], ems_compact = c_ems_w[c] == c_ems_w[c];
-        c_abs_x[c] = spec_d + spec_len; spec_len += abs_compact ? (an > 0 ? 1 : 0) : an;
-        c_abs_y[c] = spec_d + spec_len; spec_len += an;
-        c_ems_x[c] = spec_d + spec_len; spec_len += ems_compact ? (en > 0 ? 1 : 0) : en;
-        c_ems_c[c] = spec_d + spec_len; spec_len += en;
-        c_abs_g[c] = abs_compact ? -1 : guide_len; guide_len += abs_compact ? 0 : an;
-        c_ems_gx[c] = ems_compact ? -1 : guide_len; guide_len += ems_compact ? 0 : en;
-        c_ems_gc[c] = guide_len; guide_len += en;
+        if (abs_of[c] != c) {
+            const int e = abs_of[c];
+            c_abs_rcp[c] = c_abs_rcp[e]; c_abs_w[c] = c_abs_w[e]; c_abs_x[c] = c_abs_x[e]; c_abs_y[c] = c_abs_y[e]; c_abs_g[c] = c_abs_g[e];
+        } else {
+            c_abs_rcp[c] = even_rcp(ax, ay, an);
+            c_abs_w[c] = abs_hist(c) ? NAN : even_w(ax, an, c_abs_rcp[c]);
+            const bool abs_compact = c_abs_w[c] == c_abs_w[c];
+            c_abs_x[c] = spec_d + spec_len; spec_len += abs_compact ? (an > 0 ? 1 : 0) : an;
+            c_abs_y[c] = spec_d + spec_len; spec_len += an;
+            c_abs_g[c] = abs_compact ? -1 : guide_len; guide_len += abs_compact ? 0 : an;
+        }
+        if (ems_of[c] != c) {
+            const int e = ems_of[c];
+            c_ems_rcp_x[c] = c_ems_rcp_x[e]; c_ems_rcp_c[c] = c_ems_rcp_c[e]; c_ems_w[c] = c_ems_w[e];
+            c_ems_x[c] = c_ems_x[e]; c_ems_c[c] = c_ems_c[e]; c_ems_gx[c] = c_ems_gx[e]; c_ems_gc[c] = c_ems_gc[e];
+        } else {
+            c_ems_rcp_x[c] = even_rcp(ex, ec, en);
+            c_ems_rcp_c[c] = even_rcp(ec, ex, en);
+            c_ems_w[c] = ems_hist(c) ? NAN : even_w(ex, en, c_ems_rcp_x[c]);
+            const bool ems_compact = c_ems_w[c] == c_ems_w[c];
+            c_ems_x[c] = spec_d + spec_len; spec_len += ems_compact ? (en > 0 ? 1 : 0) : en;
+            c_ems_c[c] = spec_d + spec_len; spec_len += en;
+            c_ems_gx[c] = ems_compact ? -1 : guide_len; guide_len += ems_compact ? 0 : en;
+            c_ems_gc[c] = guide_len; guide_len += en;
+        }
     }
     const int spec_end = spec_d + spec_len;
-    bool index_ok = true;   // refractive indices the known-divisor division is proven for
-    for (int n = 0; n < N; n++) {
-        const double v = t->refractive_index[n];
-        if (!(std::isfinite(v) && v > 1e-100 && v < 1e100)) index_ok = false;
-    }
-    if (!index_ok) return fail(PVT_ERR_INVALID, "refractive indices must be finite and positive");
-    constexpr int kCritNodes = 16;
-    lay.crit_d = N <= kCritNodes ? spec_end : -1;
-    lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + N * N : -1;
-    // after everything else: one 64-byte record per node with what the intersection loop reads of it (see Lay::hot_d)
-    lay.hot_d = (int)(((size_t)spec_end + (lay.crit_d >= 0 ? (size_t)2 * N * N : 0) + 1 + 7) / 8 * 8);
-    std::vector<double> gd((size_t)lay.hot_d + (size_t)N * HOT, 0.0);
+    constexpr int kCritClasses = 16;
+    lay.n_cls = M;
+    lay.crit_d = M <= kCritClasses ? spec_end : -1;
+    lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + M * M : -1;
+    lay.rot_d = spec_end + (lay.crit_d >= 0 ? 2 * M * M : 0);
+    lay.ncls_d = lay.rot_d + Q * RT;
+    std::vector<double> gd((size_t)lay.ncls_d + (size_t)M * 2 + 1, 0.0);
     if (lay.crit_d >= 0)
-        for (int c = 0; c < N; c++)
-            for (int a = 0; a < N; a++) {
-                const double n1 = t->refractive_index[c], n2 = t->refractive_index[a];
+        for (int c = 0; c < M; c++)
+            for (int a = 0; a < M; a++) {
+                const double n1 = t->refractive_index[idx_first[c]], n2 = t->refractive_index[idx_first[a]];
                 const double crit = n2 < n1 ? pvt_asin(n2 / n1) : INFINITY;   // same pvt_asin as the device
-                gd[lay.crit_d + c * N + a] = crit;
-                gd[lay.ccrit_d + c * N + a] = cosine_threshold(crit);
+                gd[lay.crit_d + c * M + a] = crit;
+                gd[lay.ccrit_d + c * M + a] = cosine_threshold(crit);
             }
+    for (int q = 0; q < Q; q++) {
+        double* d = gd.data() + lay.rot_d + q * RT;
+        const int n = rot_first[q];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                d[RT_W2L + r * 3 + c] = t->world_to_local[n * 16 + r * 4 + c];
+                d[RT_L2W + r * 3 + c] = t->local_to_world[n * 16 + r * 4 + c];
+            }
+    }
+    for (int m = 0; m < M; m++) {
+        gd[lay.ncls_d + m * 2] = t->refractive_index[idx_first[m]];
+        gd[lay.ncls_d + m * 2 + 1] = 1.0 / t->refractive_index[idx_first[m]];
+    }
     lay.comp_i = N * NI;
-    lay.rec_i = lay.comp_i + C * CI;
+    lay.rec_i = lay.comp_i + CR * CI;
     lay.hist_i = lay.rec_i + R * RI;
     lay.coat_i = lay.hist_i + H * HI;
     lay.cand_i = lay.coat_i + K * KI;
-    lay.cand_list = lay.cand_i + N * 7 * 8;
+    lay.cand_list = lay.cand_i + n_cand * 7 * 8;
     const int guide0 = lay.cand_list + R;  // guide tables: one entry per table point, per searched array
     std::vector<int> gi((size_t)guide0 + (size_t)guide_len + 1, 0);
     // guide[b] = largest i <= n-2 with xs[i] <= xs[0] + b*(xs[n-1]-xs[0])/(n-1), b = 0..n-1
@@ -309,23 +436,15 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             gi[at + b] = i;
         }
     };
-    // unrotated: the 3x3 blocks of both matrices of a node are the identity, bit for bit (+0.0 off the diagonal)
-    auto unrotated = [&](int n) {
-        const double one = 1.0, zero = 0.0;
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) {
-                const double* want = r == c ? &one : &zero;
-                if (std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], want, 8) != 0) return false;
-                if (std::memcmp(&t->local_to_world[n * 16 + r * 4 + c], want, 8) != 0) return false;
-            }
-        return true;
-    };
     {   // recorders grouped by the (node, selector) they listen to.  A facet recorder whose facet
         // has a clearly dominant component, alone in its (axis, sign) bin, goes to the bin table;
         // the rest (no facet, oblique facets, bin collisions) to the walked list, ascending id.
         int at = 0;
-        for (int key = 0; key < N * 7; key++) {
-            int* rec = gi.data() + lay.cand_i + key * 8;
+        for (int node_of_key = 0; node_of_key < N; node_of_key++) {
+          if (node_cand[node_of_key] < 0) continue;
+          for (int sel = 0; sel < 7; sel++) {
+            const int key = node_of_key * 7 + sel;
+            int* rec = gi.data() + lay.cand_i + (node_cand[node_of_key] * 7 + sel) * 8;
             rec[0] = at;
             int owner[6] = {-1, -1, -1, -1, -1, -1};
             bool clash[6] = {false, false, false, false, false, false};
@@ -347,7 +466,6 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             // kRecPlain on an entry: the lane need not read the recorder's row at all -- no source filter, and either no
             // facet, or a facet that IS the bin's axis (exactly +-1 on it, zeros elsewhere) on an unrotated box, whose
             // world normals are exactly such unit vectors: |facet - normal| is exactly 0 for every normal of the bin
-            const int node_of_key = key / 7;
             const bool exact_normals = t->geom_type[node_of_key] == PVT_GEOM_BOX && unrotated(node_of_key);
             auto unfiltered = [&](int r) { return !t->rec_source_mode || t->rec_source_mode[r] == 0; };
             auto axis_facet = [&](int r, int b) {
@@ -367,57 +485,41 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
                 gi[lay.cand_list + at++] = r | ((unfiltered(r) && !t->rec_has_facet[r]) ? kRecPlain : 0);
             }
             rec[1] = at - rec[0];
+          }
         }
     }
     for (int n = 0; n < N; n++) {
         double* d = gd.data() + n * ND;
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 4; c++) d[ND_W2L + r * 4 + c] = t->world_to_local[n * 16 + r * 4 + c];
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) d[ND_L2W + r * 3 + c] = t->local_to_world[n * 16 + r * 4 + c];
-        for (int c = 0; c < 4; c++) d[ND_PARAMS + c] = t->geom_params[n * 4 + c];
+        for (int r = 0; r < 3; r++) d[ND_T + r] = t->world_to_local[n * 16 + r * 4 + 3];
+        for (int c = 0; c < 3; c++) d[ND_PARAMS + c] = t->geom_params[n * 4 + c];
+        const unsigned long long bits = (unsigned long long)(unsigned int)((unrotated(n) ? 1 : 0) | (t->geom_type[n] << 8)) |
+                                        ((unsigned long long)(unsigned int)rot_class[n] << 32);
+        std::memcpy(&d[ND_BITS], &bits, 8);
         d[ND_N] = t->refractive_index[n];
-        d[ND_RN] = 1.0 / t->refractive_index[n];
         int* q = gi.data() + n * NI;
-        q[NI_GEOM] = t->geom_type[n];
         q[NI_SURF] = t->surface_type[n];
         q[NI_CSTART] = t->comp_start[n];
         q[NI_CCOUNT] = t->comp_count[n];
+        q[NI_CREC] = node_crec[n];
         q[NI_KSTART] = K > 0 ? t->coat_start[n] : 0;
         q[NI_KCOUNT] = K > 0 ? t->coat_count[n] : 0;
         q[NI_MESH] = -1;
-        q[NI_IDENT] = unrotated(n) ? 1 : 0;
-        q[NI_ROT] = n;   // first node whose world->local rotation (the 3x3 block) has the same bits
-        for (int e = 0; e < n; e++) {
-            bool same = true;
-            for (int r = 0; r < 3 && same; r++)
-                for (int c = 0; c < 3 && same; c++)
-                    same = std::memcmp(&t->world_to_local[n * 16 + r * 4 + c], &t->world_to_local[e * 16 + r * 4 + c], 8) == 0;
-            if (same) { q[NI_ROT] = e; break; }
-        }
-        {
-            double* h = gd.data() + lay.hot_d + n * HOT;
-            for (int r = 0; r < 3; r++) h[HOT_T + r] = t->world_to_local[n * 16 + r * 4 + 3];
-            for (int r = 0; r < 3; r++)
-                for (int c = 0; c < 3; c++) h[HOT_ROT + r * 3 + c] = t->world_to_local[n * 16 + r * 4 + c];
-            for (int c = 0; c < 3; c++) h[HOT_PARAMS + c] = t->geom_params[n * 4 + c];
-            const unsigned long long bits = (unsigned long long)(unsigned int)((q[NI_IDENT] ? 1 : 0) | (q[NI_GEOM] << 8)) |
-                                            ((unsigned long long)(unsigned int)q[NI_ROT] << 32);
-            std::memcpy(&h[HOT_BITS], &bits, 8);
-        }
+        q[NI_CAND] = node_cand[n];
+        q[NI_NCLS] = idx_class[n];
         if (t->geom_type[n] == PVT_GEOM_MESH) {
             const int f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
             q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris)
                              .add_mesh(f0, fc);
         }
     }
-    for (int c = 0; c < C; c++) {
-        double* d = gd.data() + lay.comp_d + c * CD;
+    for (int rc = 0; rc < CR; rc++) {
+        const int c = rec_comp[rc];
+        double* d = gd.data() + lay.comp_d + rc * CD;
         d[CD_QY] = t->comp_qy[c];
         d[CD_TAU_RAD] = t->comp_tau_rad[c];
         d[CD_TAU_NR] = t->comp_tau_nr[c];
         d[CD_PHASE] = t->comp_phase_param[c];
-        int* q = gi.data() + lay.comp_i + c * CI;
+        int* q = gi.data() + lay.comp_i + rc * CI;
         q[CI_TYPE] = t->comp_type[c];
         q[CI_PHASE] = t->comp_phase_type[c];
         q[CI_ABS_X] = c_abs_x[c];   // absolute offsets into the double blob
@@ -426,30 +528,52 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[CI_EMS_X] = c_ems_x[c];
         q[CI_EMS_CDF] = c_ems_c[c];
         q[CI_EMS_N] = t->comp_ems_n[c];
-        q[CI_ABS_HIST] = t->comp_abs_hist ? t->comp_abs_hist[c] : 0;
-        q[CI_EMS_HIST] = t->comp_ems_hist ? t->comp_ems_hist[c] : 0;
+        q[CI_ABS_HIST] = abs_hist(c);
+        q[CI_EMS_HIST] = ems_hist(c);
         // guide tables only for the arrays that are searched (see even_w); -1 is never dereferenced
         q[CI_ABS_G] = c_abs_g[c] < 0 ? -1 : guide0 + c_abs_g[c];
         q[CI_EMS_GX] = c_ems_gx[c] < 0 ? -1 : guide0 + c_ems_gx[c];
         q[CI_EMS_GC] = guide0 + c_ems_gc[c];
-        const double* ax = t->abs_x + t->comp_abs_start[c];
-        const double* ex = t->ems_x + t->comp_ems_start[c];
-        const double* ec = t->ems_cdf + t->comp_ems_start[c];
-        const int an = t->comp_abs_n[c], en = t->comp_ems_n[c];
-        if (c_abs_g[c] >= 0) build_guide(ax, an, q[CI_ABS_G], &d[CD_ABS_SCALE]);
-        if (c_ems_gx[c] >= 0) build_guide(ex, en, q[CI_EMS_GX], &d[CD_EMS_SCALE_X]);
-        build_guide(ec, en, q[CI_EMS_GC], &d[CD_EMS_SCALE_C]);
         d[CD_ABS_RCP] = c_abs_rcp[c];
         d[CD_EMS_RCP_X] = c_ems_rcp_x[c];
         d[CD_EMS_RCP_C] = c_ems_rcp_c[c];
         d[CD_ABS_W] = c_abs_w[c];
         d[CD_EMS_W] = c_ems_w[c];
-        // the tables themselves: a compact table keeps its first abscissa only
-        const bool abs_compact = c_abs_g[c] < 0, ems_compact = c_ems_gx[c] < 0;
-        for (int i = 0; i < (abs_compact ? (an > 0 ? 1 : 0) : an); i++) gd[c_abs_x[c] + i] = ax[i];
-        for (int i = 0; i < an; i++) gd[c_abs_y[c] + i] = t->abs_y[t->comp_abs_start[c] + i];
-        for (int i = 0; i < (ems_compact ? (en > 0 ? 1 : 0) : en); i++) gd[c_ems_x[c] + i] = ex[i];
-        for (int i = 0; i < en; i++) gd[c_ems_c[c] + i] = ec[i];
+        // the guide scales are functions of the tables alone: computed (and the tables written) by whoever owns them,
+        // which is always a component with a record of its own or an earlier one -- fill in from the owner below
+    }
+    // the tables themselves, once per owner (a compact table keeps its first abscissa only), and their guide tables
+    std::vector<double> abs_scale(C, 0.0), ems_scale_x(C, 0.0), ems_scale_c(C, 0.0);
+    for (int c = 0; c < C; c++) {
+        const double* ax = t->abs_x + t->comp_abs_start[c];
+        const double* ex = t->ems_x + t->comp_ems_start[c];
+        const double* ec = t->ems_cdf + t->comp_ems_start[c];
+        const int an = t->comp_abs_n[c], en = t->comp_ems_n[c];
+        if (abs_of[c] == c) {
+            const bool abs_compact = c_abs_g[c] < 0;
+            if (!abs_compact) build_guide(ax, an, guide0 + c_abs_g[c], &abs_scale[c]);
+            for (int i = 0; i < (abs_compact ? (an > 0 ? 1 : 0) : an); i++) gd[c_abs_x[c] + i] = ax[i];
+            for (int i = 0; i < an; i++) gd[c_abs_y[c] + i] = t->abs_y[t->comp_abs_start[c] + i];
+        } else {
+            abs_scale[c] = abs_scale[abs_of[c]];
+        }
+        if (ems_of[c] == c) {
+            const bool ems_compact = c_ems_gx[c] < 0;
+            if (!ems_compact) build_guide(ex, en, guide0 + c_ems_gx[c], &ems_scale_x[c]);
+            build_guide(ec, en, guide0 + c_ems_gc[c], &ems_scale_c[c]);
+            for (int i = 0; i < (ems_compact ? (en > 0 ? 1 : 0) : en); i++) gd[c_ems_x[c] + i] = ex[i];
+            for (int i = 0; i < en; i++) gd[c_ems_c[c] + i] = ec[i];
+        } else {
+            ems_scale_x[c] = ems_scale_x[ems_of[c]];
+            ems_scale_c[c] = ems_scale_c[ems_of[c]];
+        }
+    }
+    for (int rc = 0; rc < CR; rc++) {
+        const int c = rec_comp[rc];
+        double* d = gd.data() + lay.comp_d + rc * CD;
+        d[CD_ABS_SCALE] = abs_scale[c];
+        d[CD_EMS_SCALE_X] = ems_scale_x[c];
+        d[CD_EMS_SCALE_C] = ems_scale_c[c];
     }
     for (int r = 0; r < R; r++) {
         double* d = gd.data() + lay.rec_d + r * RD;
@@ -538,7 +662,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     bool fuse_exit = false;
     if (lazy_root && N == 2 && !getenv("PVT_NO_FUSED_EXIT")) {
         const int child = 1 - t->root_id;
-        bool ok = t->geom_type[child] == PVT_GEOM_BOX && gi[child * NI + NI_IDENT] != 0 && t->comp_count[t->root_id] == 0;
+        bool ok = t->geom_type[child] == PVT_GEOM_BOX && unrotated(child) && t->comp_count[t->root_id] == 0;
         for (int r = 0; r < R; r++)
             if (t->rec_node[r] == t->root_id) ok = false;
         fuse_exit = ok;

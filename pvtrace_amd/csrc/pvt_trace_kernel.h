@@ -62,11 +62,21 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // Scene blobs are arrays of fixed-stride RECORDS (one double blob, one int32 blob), so a
 // table element is addressed as base + index*stride + field with compile-time strides
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
-enum { ND_W2L = 0, ND_L2W = 12, ND_PARAMS = 21, ND_N = 25, ND_RN = 26, ND = 27 };  // node doubles (RN: RN(1/n))
-enum { NI_GEOM = 0, NI_SURF, NI_CSTART, NI_CCOUNT, NI_KSTART, NI_KCOUNT, NI_MESH, NI_ROT, NI_IDENT, NI };  // node ints (NI_MESH: BVH root, -1 = none;
-                                                                                          // NI_ROT: first node whose world->local rotation has the same bits;
-                                                                                          // NI_IDENT: that rotation is the identity matrix, bit for bit)
-enum { HOT_T = 0, HOT_PARAMS = 3, HOT_BITS = 6, HOT_ROT = 7, HOT = 16 };   // Lay::hot_d records (HOT doubles apart; three shape parameters: no shape has four)
+// Node records are what a photon reads of the node it is in / hits / tests, and what the intersection loop reads of
+// EVERY node: 64 bytes (one scalar load in the wave-uniform loop, four 16-byte LDS reads per lane in the grid walk).
+// Rotations, refractive-index reciprocals and critical angles live in small side tables indexed by CLASS (nodes with
+// bit-identical rotations / refractive indices share an entry), so a scene of 120 tiles costs 12 KB of LDS, not 56.
+enum { ND_T = 0, ND_PARAMS = 3, ND_BITS = 6, ND_N = 7, ND = 8 };  // node doubles: translation of world->local, three shape
+                                                                 // parameters (no shape has four), one word of {bit 0: the
+                                                                 // rotation is the identity, bit for bit; bits 8-15: geometry
+                                                                 // type; high half: rotation class}, refractive index
+enum { NI_SURF = 0, NI_CSTART, NI_CCOUNT, NI_CREC, NI_KSTART, NI_KCOUNT, NI_MESH, NI_CAND, NI_NCLS, NI };  // node ints (NI_CSTART: id of the
+                                                                 // node's first component, what events and recorders name;
+                                                                 // NI_CREC: its first component RECORD -- identical components
+                                                                 // share records; NI_MESH: BVH root, -1 = none; NI_CAND: block of
+                                                                 // the recorder candidate tables, -1 = nobody listens to the node;
+                                                                 // NI_NCLS: refractive-index class)
+enum { RT_W2L = 0, RT_L2W = 9, RT = 18 };                         // Lay::rot_d records: the 3x3 blocks of world->local and local->world
 enum { CD_QY = 0, CD_TAU_RAD, CD_TAU_NR, CD_PHASE, CD_ABS_SCALE, CD_EMS_SCALE_X, CD_EMS_SCALE_C,
        CD_ABS_RCP, CD_EMS_RCP_X, CD_EMS_RCP_C, CD_ABS_W, CD_EMS_W, CD };   // component doubles (*_RCP: RN(1/spacing) of an evenly spaced table, else NaN;
                                                             // *_W: the spacing w when additionally xs[i] == xs[0] + i*w bit for bit, else NaN)
@@ -83,18 +93,19 @@ struct Lay {  // record bases (elements) inside the blobs; spectra follow the re
               // addressed by absolute offsets stored in the component records
     int comp_d, rec_d, hist_d, coat_d;
     int comp_i, rec_i, hist_i, coat_i;
-    int cand_i;     // (n_nodes*7) x {start, count, bin[6]}: recorders that can fire for a
-                    // (node, selector): a list to walk + facet recorders found by normal bin
+    int cand_i;     // per node that carries recorders (NI_CAND) 7 x {start, count, bin[6]}: recorders that can fire
+                    // for a (node, selector): a list to walk + facet recorders found by normal bin
     int cand_list;  // recorder ids, ascending within each (node, selector)
-    int crit_d;     // (n_nodes x n_nodes) critical angles asin(n[a]/n[c]) (+inf where n[a] >= n[c]),
-                    // or -1 when the scene has too many nodes for the table
-    int hot_d;      // n_nodes x HOT doubles, 64-byte aligned: what the intersection loop reads of a node -- translation of
-                    // world->local (HOT_T), shape parameters (HOT_PARAMS), and one word of {identity rotation, geometry
-                    // type, rotation class} (HOT_BITS) -- so that a wave fetches a node with ONE scalar load and one wait
-                    // instead of six dependent ones (a lone wave spent a third of its step waiting for those); the nine
-                    // rotation entries of world->local follow (HOT_ROT, row-major), read for rotated nodes only
+    int crit_d;     // (n_cls x n_cls) critical angles asin(n[a]/n[c]) (+inf where n[a] >= n[c]) by refractive-index
+                    // class, or -1 when the scene has too many distinct indices for the table
     int ccrit_d;    // same shape: the cosine below which pvt_acos(cosine) exceeds that angle (host-proven
                     // threshold, NaN where it could not be proven, -inf where there is no critical angle)
+    int grid_d;     // the node grid of scenes with many nodes (-1 = none; GRID variants): {lo[3], hi[3], cell[3], 1/cell[3],
+                    // guard, one word of {nx | ny << 8 | nz << 16 | 64-bit words per cell << 24 | odd << 28}}, then per
+                    // cell the bit mask of the nodes filed under it (x fastest)
+    int rot_d;      // rotation classes x RT doubles (every node has one; the identity's is only read by the Lambertian branch)
+    int ncls_d;     // refractive-index classes x {n, RN(1/n)}
+    int n_cls;
 };
 
 struct EmitOff {  // emitter blobs (global only; read once per photon)
@@ -664,7 +675,8 @@ struct Seen {
 // --------------------------------------------------------------- kernel
 // MESH: the scene has triangle-mesh nodes.  The BVH walk costs ~35 VGPRs, so scenes made of
 // analytic shapes run the variant compiled without it (one more wave per SIMD).
-template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
+// GRID: scenes of many nodes -- every lane finds the nodes its ray can cross through a uniform grid (see the node loop).
+template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH, bool GRID = false>
 __device__ __forceinline__ void trace_body(const KArgs& A) {
     extern __shared__ double smem[];
 #if PVT_TIMELINE
@@ -725,6 +737,89 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #endif
 
     Tables<TAB_LDS> T{(CDoubles)A.gd, (CInts)A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi, A.gd, A.gi};
+
+    // a node's flag word, read by the lane (see ND_BITS)
+    auto node_bits = [&](int node) -> unsigned long long { return pvt_d2u(T.dv(node * ND + ND_BITS)); };
+    auto node_ident = [](unsigned long long bits) -> bool { return (bits & 1ull) != 0; };
+    auto node_geom = [](unsigned long long bits) -> int { return (int)(((unsigned int)bits >> 8) & 0xffu); };
+    auto node_rot = [&](unsigned long long bits) -> int { return L.rot_d + (int)(unsigned int)(bits >> 32) * RT; };
+
+    // Forward crossings (t > kEps) of one analytic shape by the ray (o, d) in the shape's own frame, each handed to
+    // `fold` in the reference's order (_kernel.pyx:245-345).  `inv`: 1/d per axis (boxes only).  The shape parameters
+    // are scalars in the wave-uniform node loop and per-lane values in the grid walk: same operations either way.
+    auto shape_hits = [](int gt, double g0, double g1, double g2, const V3& o, const V3& d, const double (&inv)[3], auto&& fold) {
+        if (gt == PVT_GEOM_BOX) {  // slab test (:245-276)
+            double tmin = -INFINITY, tmax = INFINITY;
+            bool miss = false;
+            const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, gpar[3] = {g0, g1, g2};
+            // a ray parallel to a pair of faces (a direction component below 1e-300) takes the reference's
+            // inside/outside test for that axis; the wave only runs the general form when a lane holds one
+            if (__ballot(pvt_fabs(dd[0]) < 1e-300 || pvt_fabs(dd[1]) < 1e-300 || pvt_fabs(dd[2]) < 1e-300) == 0ull) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const double sz = gpar[a];
+                    const double ta = (-0.5 * sz - oo[a]) * inv[a], tb = (0.5 * sz - oo[a]) * inv[a];
+                    tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                    tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                }
+            } else
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                double sz = gpar[a];
+                double lo = -0.5 * sz, hi = 0.5 * sz;
+                if (pvt_fabs(dd[a]) < 1e-300) {
+                    if (oo[a] < lo || oo[a] > hi) miss = true;
+                } else {
+                    // (the reference swaps ta, tb into order and keeps the largest entry / smallest exit
+                    // distance: min and max of finite numbers, which is what these are)
+                    const double ta = (lo - oo[a]) * inv[a], tb = (hi - oo[a]) * inv[a];
+                    tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                    tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                }
+            }
+            if (!miss && !(tmax < tmin)) {
+                if (tmin > kEps) fold(tmin);
+                if (tmax > kEps) fold(tmax);
+            }
+        } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
+            double radius = g0;
+            double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
+            double disc = b * b - 4.0 * a * c;
+            if (!(disc < 0.0)) {
+                double sq = pvt_sqrt(disc);
+                double t = (-b - sq) / (2.0 * a);
+                if (t > kEps) fold(t);
+                t = (-b + sq) / (2.0 * a);
+                if (t > kEps) fold(t);
+            }
+        } else {  // capped z cylinder (:301-345)
+            double half = 0.5 * g0, radius = g1;
+            double a = d.x * d.x + d.y * d.y;
+            if (a > 1e-300) {
+                double b = 2.0 * (o.x * d.x + o.y * d.y);
+                double c = o.x * o.x + o.y * o.y - radius * radius;
+                double disc = b * b - 4.0 * a * c;
+                if (disc >= 0.0) {
+                    double sq = pvt_sqrt(disc);
+                    double t = (-b - sq) / (2.0 * a);
+                    double z = o.z + t * d.z;
+                    if (z > -half && z < half && t > kEps) fold(t);
+                    t = (-b + sq) / (2.0 * a);
+                    z = o.z + t * d.z;
+                    if (z > -half && z < half && t > kEps) fold(t);
+                }
+            }
+            if (pvt_fabs(d.z) > 1e-300) {
+                double t = (-half - o.z) / d.z;
+                double x = o.x + t * d.x, y = o.y + t * d.y;
+                if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                t = (half - o.z) / d.z;
+                x = o.x + t * d.x;
+                y = o.y + t * d.y;
+                if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+            }
+        }
+    };
 
     const int lane = threadIdx.x & 63;
     // rank of this lane among the set bits of a wave mask: the bits below it, counted by the mbcnt pair
@@ -1149,34 +1244,170 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 // distance to the root's nearest face -- and only the lanes it cannot decide for pay for the
                 // root's intersection; in a typical scene (a 5 cm slab in a 5 m world) none ever does.
                 const int lazy_root = (MESH || RECORD) ? 0 : (uf(UF_LAZY1) ? 1 : (uf(UF_LAZY2) ? 2 : 0));   // wave-uniform (tally launches only)
-                for (int k = 0; k < A.n_nodes; k++) {
-                    const int node = !lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1));
+                if constexpr (GRID) {
+                    // ---- scenes of many nodes: every lane looks up ITS candidates in a uniform grid over the nodes -----
+                    // The reference intersects every node in every step (_kernel.pyx:666-680).  A node the ray does not
+                    // cross contributes nothing to that loop, and all the step needs of the others is the nearest and
+                    // the second-nearest crossing and the nearest node crossed exactly once.  The host files every
+                    // node but the root under the cells of a grid that its bounding box (grown by a margin far above
+                    // rounding) touches; a lane walks the cells its ray passes, front to back (3-D DDA), and runs the
+                    // reference's own intersection arithmetic on the nodes it finds there, each once.  Crossings are
+                    // folded by (t, node) -- the order the reference's first-minimum scans imply -- so the visiting
+                    // order cannot matter.  The walk ends where the ray leaves the grid, or earlier: once two
+                    // crossings lie nearer than the end of the cells visited (by `guard`, the margin again), every
+                    // node not yet seen has all its crossings beyond them -- it cannot be the nearest or the second
+                    // -- and lies clear of the photon, so a convex box or sphere is crossed twice or not at all and
+                    // cannot hold the ray either.  (A cylinder grazed at the rim of a cap may come out with ONE
+                    // crossing in the reference's arithmetic, _kernel.pyx:301-345: scenes with cylinders -- `odd` --
+                    // additionally walk on until the cells visited reach past the container found so far.)
+                    const int gb = L.grid_d;
+                    const unsigned long long gbits = pvt_d2u(T.du(gb + 13));   // nx | ny << 8 | nz << 16 | words << 24 | odd << 28
+                    const double guard = T.du(gb + 12);
+                    const double invw[3] = {rcp_normal(dir.x), rcp_normal(dir.y), rcp_normal(dir.z)};
+                    const double pw[3] = {pos.x, pos.y, pos.z}, dw[3] = {dir.x, dir.y, dir.z};
+                    // the ray against the grid's box (a direction component this small moves the photon by less than
+                    // rounding over the whole scene: treated as parallel)
+                    double t_in = 0.0, t_out = INFINITY;
+                    bool walk = true;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const double lo = T.du(gb + a), hi = T.du(gb + 3 + a);
+                        if (pvt_fabs(dw[a]) < 1e-20) {
+                            if (pw[a] < lo || pw[a] > hi) walk = false;
+                        } else {
+                            const double ta = (lo - pw[a]) * invw[a], tb = (hi - pw[a]) * invw[a];
+                            t_in = __builtin_fmax(t_in, __builtin_fmin(ta, tb));
+                            t_out = __builtin_fmin(t_out, __builtin_fmax(ta, tb));
+                        }
+                    }
+                    if (!(t_in <= t_out)) walk = false;
+                    // first cell, the distance at which the ray leaves it along each axis, steps left along each axis
+                    double tm[3];
+                    unsigned int remv = 0;   // steps left: x | y << 8 | z << 16; bits 24-26: the ray runs towards lower indices
+                    int ci = 0;
+                    {
+                        int stride = 1;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const int na = (int)((unsigned int)(gbits >> (8 * a)) & 0xffu);
+                            const double lo = T.du(gb + a), cell = T.du(gb + 6 + a), rcell = T.du(gb + 9 + a);
+                            const double at = pw[a] + dw[a] * t_in;
+                            int c = (int)((at - lo) * rcell);
+                            c = c < 0 ? 0 : (c > na - 1 ? na - 1 : c);
+                            const bool par = pvt_fabs(dw[a]) < 1e-20, neg = dw[a] < 0.0;
+                            tm[a] = par ? INFINITY : ((lo + (double)(c + (neg ? 0 : 1)) * cell) - pw[a]) * invw[a];
+                            remv |= (unsigned int)(neg ? c : na - 1 - c) << (8 * a);
+                            if (neg) remv |= 1u << (24 + a);
+                            ci += c * stride;
+                            stride *= na;
+                        }
+                    }
+                    const int words = (int)((unsigned int)(gbits >> 24) & 0xfu);
+                    const bool odd = ((gbits >> 28) & 1ull) != 0;
+                    unsigned long long seen_lo = 0ull, seen_hi = 0ull, pend_lo = 0ull, pend_hi = 0ull;
+                    auto load_cell = [&]() {
+                        const int at = gb + 14 + ci * words;
+                        const unsigned long long m_lo = pvt_d2u(T.dv(at)), m_hi = words > 1 ? pvt_d2u(T.dv(at + 1)) : 0ull;
+                        pend_lo = m_lo & ~seen_lo; pend_hi = m_hi & ~seen_hi;
+                        seen_lo |= m_lo; seen_hi |= m_hi;
+                    };
+                    if (walk) load_cell();
+                    // one node, tested by this lane alone (the records come from LDS with per-lane addresses)
+                    auto visit = [&](int node) {
+                        const int hn = node * ND;
+                        const double tx = T.dv(hn + ND_T), ty = T.dv(hn + ND_T + 1), tz = T.dv(hn + ND_T + 2);
+                        const double g0 = T.dv(hn + ND_PARAMS), g1 = T.dv(hn + ND_PARAMS + 1), g2 = T.dv(hn + ND_PARAMS + 2);
+                        const unsigned long long hb = pvt_d2u(T.dv(hn + ND_BITS));
+                        const int gt = (int)(((unsigned int)hb >> 8) & 0xffu);
+                        V3 o, dl;
+                        double il[3];
+                        if ((hb & 1ull) != 0) {
+                            o.x = pos.x + tx; o.y = pos.y + ty; o.z = pos.z + tz;
+                            dl = dir;
+                            il[0] = invw[0]; il[1] = invw[1]; il[2] = invw[2];
+                        } else {
+                            const int rm = L.rot_d + (int)(unsigned int)(hb >> 32) * RT + RT_W2L;
+                            o.x = T.dv(rm + 0) * pos.x + T.dv(rm + 1) * pos.y + T.dv(rm + 2) * pos.z + tx;
+                            o.y = T.dv(rm + 3) * pos.x + T.dv(rm + 4) * pos.y + T.dv(rm + 5) * pos.z + ty;
+                            o.z = T.dv(rm + 6) * pos.x + T.dv(rm + 7) * pos.y + T.dv(rm + 8) * pos.z + tz;
+                            dl.x = T.dv(rm + 0) * dir.x + T.dv(rm + 1) * dir.y + T.dv(rm + 2) * dir.z;
+                            dl.y = T.dv(rm + 3) * dir.x + T.dv(rm + 4) * dir.y + T.dv(rm + 5) * dir.z;
+                            dl.z = T.dv(rm + 6) * dir.x + T.dv(rm + 7) * dir.y + T.dv(rm + 8) * dir.z;
+                            il[0] = rcp_normal(dl.x); il[1] = rcp_normal(dl.y); il[2] = rcp_normal(dl.z);
+                        }
+                        int nl = 0;
+                        double tfirst = 0.0;
+                        auto fold = [&](double t) {
+                            if (nl == 0) tfirst = t;
+                            nl += 1;
+                            if (nhits == 0) { t1 = t; n1 = node; }
+                            else if (t < t1 || (t == t1 && node < n1)) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
+                            else if (n2 < 0 || t < t2 || (t == t2 && node < n2)) { t2 = t; n2 = node; }
+                            nhits += 1;
+                        };
+                        shape_hits(gt, g0, g1, g2, o, dl, il, fold);
+                        if (nl == 1 && (tfirst < cbest || (tfirst == cbest && node < cnode))) { cbest = tfirst; cnode = node; }
+                    };
+                    for (;;) {
+                        // the nodes filed under the current cell that this lane has not tested yet
+                        while (__ballot((pend_lo | pend_hi) != 0ull) != 0ull) {
+                            if ((pend_lo | pend_hi) != 0ull) {
+                                int node;
+                                if (pend_lo != 0ull) { node = __builtin_ctzll(pend_lo); pend_lo &= pend_lo - 1ull; }
+                                else { node = 64 + __builtin_ctzll(pend_hi); pend_hi &= pend_hi - 1ull; }
+                                visit(node);
+                            }
+                        }
+                        if (__ballot(walk) == 0ull) break;
+                        if (walk) {
+                            const double t_cell = __builtin_fmin(tm[0], __builtin_fmin(tm[1], tm[2]));   // the ray leaves the cell here
+                            const bool enough = nhits >= 2 && t2 + guard < t_cell && (!odd || (cnode >= 0 && cbest + guard < t_cell));
+                            const int ax = (tm[0] <= tm[1] && tm[0] <= tm[2]) ? 0 : (tm[1] <= tm[2] ? 1 : 2);
+                            const unsigned int left = (remv >> (8 * ax)) & 0xffu;
+                            if (enough || left == 0u || !(t_cell < INFINITY)) {
+                                walk = false;
+                            } else {
+                                remv -= 1u << (8 * ax);
+                                const int nx = (int)((unsigned int)gbits & 0xffu), ny = (int)((unsigned int)(gbits >> 8) & 0xffu);
+                                const int stride = ax == 0 ? 1 : (ax == 1 ? nx : nx * ny);
+                                ci += ((remv >> (24 + ax)) & 1u) ? -stride : stride;
+                                if (ax == 0) tm[0] = __builtin_fma(pvt_fabs(invw[0]), T.du(gb + 6), tm[0]);
+                                else if (ax == 1) tm[1] = __builtin_fma(pvt_fabs(invw[1]), T.du(gb + 7), tm[1]);
+                                else tm[2] = __builtin_fma(pvt_fabs(invw[2]), T.du(gb + 8), tm[2]);
+                                load_cell();
+                            }
+                        }
+                    }
+                }
+                // (grid scenes: only the root is left, and it folds by (t, node) like the walk)
+                for (int k = GRID ? A.n_nodes - 1 : 0; k < A.n_nodes; k++) {
+                    const int node = GRID ? A.root : (!lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1)));
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
                     // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,
                     // quotient or stored value below can see.
                     // the node's 64-byte record: one scalar load, all of it in SGPRs
-                    const int hn = L.hot_d + node * HOT;
-                    const double tx = T.du(hn + HOT_T), ty = T.du(hn + HOT_T + 1), tz = T.du(hn + HOT_T + 2);
-                    const double gpar[3] = {T.du(hn + HOT_PARAMS), T.du(hn + HOT_PARAMS + 1), T.du(hn + HOT_PARAMS + 2)};
-                    const unsigned long long hbits = pvt_d2u(T.du(hn + HOT_BITS));
+                    const int hn = node * ND;
+                    const double tx = T.du(hn + ND_T), ty = T.du(hn + ND_T + 1), tz = T.du(hn + ND_T + 2);
+                    const double gpar[3] = {T.du(hn + ND_PARAMS), T.du(hn + ND_PARAMS + 1), T.du(hn + ND_PARAMS + 2)};
+                    const unsigned long long hbits = pvt_d2u(T.du(hn + ND_BITS));
                     const bool ident = (hbits & 1ull) != 0;   // wave-uniform
+                    const int rc = (int)(unsigned int)(hbits >> 32);   // rotation class
                     V3 o;
                     if (ident) {
                         o.x = pos.x + tx; o.y = pos.y + ty; o.z = pos.z + tz;
                     } else {
-                        const int rm = hn + HOT_ROT;
+                        const int rm = L.rot_d + rc * RT + RT_W2L;
                         o.x = T.du(rm + 0) * pos.x + T.du(rm + 1) * pos.y + T.du(rm + 2) * pos.z + tx;
                         o.y = T.du(rm + 3) * pos.x + T.du(rm + 4) * pos.y + T.du(rm + 5) * pos.z + ty;
                         o.z = T.du(rm + 6) * pos.x + T.du(rm + 7) * pos.y + T.du(rm + 8) * pos.z + tz;
                     }
                     // Nodes whose world->local rotations are bit-identical (the host files them under the
                     // first such node) see the same local direction: it and its reciprocals are reused.
-                    const int rc = (int)(unsigned int)(hbits >> 32);
                     if (rc != rot) {
                         if (ident) {
                             d = dir;
                         } else {
-                            const int rm = hn + HOT_ROT;
+                            const int rm = L.rot_d + rc * RT + RT_W2L;
                             d.x = T.du(rm + 0) * dir.x + T.du(rm + 1) * dir.y + T.du(rm + 2) * dir.z;
                             d.y = T.du(rm + 3) * dir.x + T.du(rm + 4) * dir.y + T.du(rm + 5) * dir.z;
                             d.z = T.du(rm + 6) * dir.x + T.du(rm + 7) * dir.y + T.du(rm + 8) * dir.z;
@@ -1184,7 +1415,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         rot = rc;
                         inv_ok = false;
                     }
-                const int gt = (int)((unsigned int)hbits >> 8);
+                const int gt = (int)(((unsigned int)hbits >> 8) & 0xffu);
                 // Hits are folded as they are found, in the reference's (node, k)
                 // order, so no per-ray hit list exists; the tie-breaks equal the
                 // reference's argmin scans over its hit arrays (:684-714).
@@ -1216,8 +1447,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (nl == 0) tfirst = t;
                     nl += 1;
                     if (nhits == 0) { t1 = t; n1 = node; }
-                    else if (t < t1) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
-                    else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
+                    else if (t < t1 || (GRID && t == t1 && node < n1)) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
+                    else if (n2 < 0 || t < t2 || (GRID && t == t2 && node < n2)) { t2 = t; n2 = node; }
                     nhits += 1;
                 };
                 if (root_known) {
@@ -1297,81 +1528,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         i += 1;
                         b = nxt;
                     }
-                } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
-                double tmin = -INFINITY, tmax = INFINITY;
-                bool miss = false;
-                const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-                if (!inv_ok) {   // 1/d per axis, shared by consecutive nodes whose rotations have the same bits
-#pragma unroll
-                    for (int a = 0; a < 3; a++) inv[a] = rcp_normal(dd[a]);   // 1/d (garbage below 1e-300: never used)
-                    inv_ok = true;
-                }
-                // a ray parallel to a pair of faces (a direction component below 1e-300) takes the reference's
-                // inside/outside test for that axis; the wave only runs the general form when a lane holds one
-                if (__ballot(pvt_fabs(dd[0]) < 1e-300 || pvt_fabs(dd[1]) < 1e-300 || pvt_fabs(dd[2]) < 1e-300) == 0ull) {
-#pragma unroll
-                    for (int a = 0; a < 3; a++) {
-                        const double sz = gpar[a];
-                        const double ta = (-0.5 * sz - oo[a]) * inv[a], tb = (0.5 * sz - oo[a]) * inv[a];
-                        tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
-                        tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                } else {
+                    if (gt == PVT_GEOM_BOX && !inv_ok) {   // 1/d per axis, shared by consecutive nodes whose rotations have the same bits
+                        inv[0] = rcp_normal(d.x); inv[1] = rcp_normal(d.y); inv[2] = rcp_normal(d.z);   // (garbage below 1e-300: never used)
+                        inv_ok = true;
                     }
-                } else
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    double sz = gpar[a];
-                    double lo = -0.5 * sz, hi = 0.5 * sz;
-                    if (pvt_fabs(dd[a]) < 1e-300) {
-                        if (oo[a] < lo || oo[a] > hi) miss = true;
-                    } else {
-                        // (the reference swaps ta, tb into order and keeps the largest entry / smallest exit
-                        // distance: min and max of finite numbers, which is what these are)
-                        const double ta = (lo - oo[a]) * inv[a], tb = (hi - oo[a]) * inv[a];
-                        tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
-                        tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
-                    }
-                }
-                if (!miss && !(tmax < tmin)) {
-                    if (tmin > kEps) fold(tmin);
-                    if (tmax > kEps) fold(tmax);
-                }
-            } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
-                    double radius = gpar[0];
-                    double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
-                    double disc = b * b - 4.0 * a * c;
-                    if (!(disc < 0.0)) {
-                        double sq = pvt_sqrt(disc);
-                        double t = (-b - sq) / (2.0 * a);
-                        if (t > kEps) fold(t);
-                        t = (-b + sq) / (2.0 * a);
-                        if (t > kEps) fold(t);
-                    }
-                } else {  // capped z cylinder (:301-345)
-                    double half = 0.5 * gpar[0], radius = gpar[1];
-                    double a = d.x * d.x + d.y * d.y;
-                    if (a > 1e-300) {
-                        double b = 2.0 * (o.x * d.x + o.y * d.y);
-                        double c = o.x * o.x + o.y * o.y - radius * radius;
-                        double disc = b * b - 4.0 * a * c;
-                        if (disc >= 0.0) {
-                            double sq = pvt_sqrt(disc);
-                            double t = (-b - sq) / (2.0 * a);
-                            double z = o.z + t * d.z;
-                            if (z > -half && z < half && t > kEps) fold(t);
-                            t = (-b + sq) / (2.0 * a);
-                            z = o.z + t * d.z;
-                            if (z > -half && z < half && t > kEps) fold(t);
-                        }
-                    }
-                    if (pvt_fabs(d.z) > 1e-300) {
-                        double t = (-half - o.z) / d.z;
-                        double x = o.x + t * d.x, y = o.y + t * d.y;
-                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
-                        t = (half - o.z) / d.z;
-                        x = o.x + t * d.x;
-                        y = o.y + t * d.y;
-                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
-                    }
+                    shape_hits(gt, gpar[0], gpar[1], gpar[2], o, d, inv, fold);
                 }
                     // The container is the nearest node the ray starts inside of: crossed exactly once for the
                     // reference's convex shapes (:696-706); a triangle mesh may be non-convex, so it holds the
@@ -1379,7 +1541,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // pvtrace/geometry/mesh.py:29-32)
                     const bool holds = (MESH && gt == PVT_GEOM_MESH) ? (nl & 1) != 0 : nl == 1;
                     if (holds && !root_known) {
-                        if (tfirst < cbest) {
+                        if (tfirst < cbest || (GRID && tfirst == cbest && node < cnode)) {
                             if constexpr (MESH) { c2best = cbest; c2node = cnode; }
                             cbest = tfirst; cnode = node;
                         } else if (MESH && tfirst < c2best) { c2best = tfirst; c2node = node; }
@@ -1399,7 +1561,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         if constexpr (MESH) {
                             // leaving a mesh: the second-nearest crossing may be the same (non-convex) mesh
                             // again; what lies beyond the surface is the next node that holds the ray
-                            if (container == hit && c2node >= 0 && T.iv(hit * NI + NI_GEOM) == PVT_GEOM_MESH) adjacent = c2node;
+                            if (container == hit && c2node >= 0 && node_geom(node_bits(hit)) == PVT_GEOM_MESH) adjacent = c2node;
                         }
                     }
                     ev_container = container;
@@ -1419,13 +1581,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // thresholds the reference recomputes when it picks the absorbing component (:768-781): the first
         // one is kept (it decides for containers of two components; more are re-walked when a lane needs it)
         double alpha = 0.0, pre0 = 0.0, n_container = 1.0;
-        int cbase = 0, ccount = 0;
+        int cbase = 0, ccount = 0, crec = 0;   // first component id, count, first component record (identical components share records)
         if (pend) {
             n_container = T.dv(container * ND + ND_N);
             cbase = T.iv(container * NI + NI_CSTART); ccount = T.iv(container * NI + NI_CCOUNT);
+            crec = T.iv(container * NI + NI_CREC);
             if (hit != A.root) {
                 for (int k = 0; k < ccount; k++) {
-                    const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
+                    const int ci = L.comp_i + (crec + k) * CI, cd = L.comp_d + (crec + k) * CD;
                     alpha += interp_clamped<TAB_LDS>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
                                                             T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
                                                             T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
@@ -1461,7 +1624,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     } else {
                         double running = 0.0;
                         for (int k = 0; k < ccount; k++) {
-                            const int ci = L.comp_i + (cbase + k) * CI, cd = L.comp_d + (cbase + k) * CD;
+                            const int ci = L.comp_i + (crec + k) * CI, cd = L.comp_d + (crec + k) * CD;
                             running += interp_clamped<TAB_LDS>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
                                                                       T.iv(ci + CI_ABS_G), T.dv(cd + CD_ABS_SCALE), T.iv(ci + CI_ABS_HIST),
                                                                       T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
@@ -1489,9 +1652,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // ---- the absorbing component decides (:783-832): one pass per distinct component of the wave,
         // its record in SGPRs
         {
-            const int cu = comp;
+            const int cu = comp;                       // the component's id (what the event and `source` name) ...
             const bool mine = cls == CLS_ABS;
-            const int ci = L.comp_i + cu * CI, cd = L.comp_d + cu * CD;
+            const int cr = mine ? crec + (comp - cbase) : 0;   // ... and its record
+            const int ci = L.comp_i + cr * CI, cd = L.comp_d + cr * CD;
             const int ctype = T.iv(ci + CI_TYPE);
             if (mine) {
                 bool radiative = false;
@@ -1581,16 +1745,18 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         // x,y,z histogram axes RECOMPUTE them where needed (same arithmetic, same bits) instead of
         // keeping 12 VGPRs alive across the transcendental sites, the register-pressure peak.
         auto local_point = [&]() -> V3 {
-            const int m = t_node * ND + ND_W2L;
-            if (T.iv(t_node * NI + NI_IDENT) != 0)   // unrotated node: translate only
-                return V3{pos.x + T.dv(m + 3), pos.y + T.dv(m + 7), pos.z + T.dv(m + 11)};
-            return V3{T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(m + 3),
-                      T.dv(m + 4) * pos.x + T.dv(m + 5) * pos.y + T.dv(m + 6) * pos.z + T.dv(m + 7),
-                      T.dv(m + 8) * pos.x + T.dv(m + 9) * pos.y + T.dv(m + 10) * pos.z + T.dv(m + 11)};
+            const int tr = t_node * ND + ND_T;
+            const unsigned long long tb = node_bits(t_node);
+            if (node_ident(tb))   // unrotated node: translate only
+                return V3{pos.x + T.dv(tr), pos.y + T.dv(tr + 1), pos.z + T.dv(tr + 2)};
+            const int m = node_rot(tb) + RT_W2L;
+            return V3{T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + T.dv(tr),
+                      T.dv(m + 3) * pos.x + T.dv(m + 4) * pos.y + T.dv(m + 5) * pos.z + T.dv(tr + 1),
+                      T.dv(m + 6) * pos.x + T.dv(m + 7) * pos.y + T.dv(m + 8) * pos.z + T.dv(tr + 2)};
         };
         auto local_normal = [&](const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
             const int gp = t_node * ND + ND_PARAMS;
-            const int gt = T.iv(t_node * NI + NI_GEOM);
+            const int gt = node_geom(node_bits(t_node));
             if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
                 const pvt::MeshTri* tr = A.tris + tri1;
                 return V3{tr->n[0], tr->n[1], tr->n[2]};
@@ -1624,10 +1790,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         };
         if (alive && t_normal) {
             const V3 nloc = local_normal(local_point());
-            if (T.iv(t_node * NI + NI_IDENT) != 0) {
+            const unsigned long long tb = node_bits(t_node);
+            if (node_ident(tb)) {
                 nrm = nloc;
             } else {
-                const int q = t_node * ND + ND_L2W;
+                const int q = node_rot(tb) + RT_L2W;
                 nrm.x = T.dv(q + 0) * nloc.x + T.dv(q + 1) * nloc.y + T.dv(q + 2) * nloc.z;
                 nrm.y = T.dv(q + 3) * nloc.x + T.dv(q + 4) * nloc.y + T.dv(q + 5) * nloc.z;
                 nrm.z = T.dv(q + 6) * nloc.x + T.dv(q + 7) * nloc.y + T.dv(q + 8) * nloc.z;
@@ -1668,17 +1835,19 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             if (fres) {  // unpolarised Fresnel, 1.0 beyond the critical angle (:406-419)
                 n1 = T.dv(container * ND + ND_N);
                 n2 = T.dv(adjacent * ND + ND_N);
-                rn2 = T.dv(adjacent * ND + ND_RN);
+                // what depends on the refractive indices alone is tabulated per pair of index CLASSES
+                const int kc = T.iv(container * NI + NI_NCLS), ka = T.iv(adjacent * NI + NI_NCLS);
+                rn2 = T.dv(L.ncls_d + ka * 2 + 1);
                 // critical angle asin(n2/n1): a function of the node pair, tabulated by the host
                 // with the same pvt_asin (small scenes), else computed here
                 bool tir;
                 // (the reference compares acos(c1) with the critical angle; the host has turned that into a
                 // comparison of c1 itself wherever it could prove the two agree for every double)
                 const bool crit_tab = uf(UF_CRIT);
-                const double cc = crit_tab ? T.dv(L.ccrit_d + container * A.n_nodes + adjacent) : __builtin_nan("");
+                const double cc = crit_tab ? T.dv(L.ccrit_d + kc * L.n_cls + ka) : __builtin_nan("");
                 if (cc == cc) tir = c1 < cc;
-                else if (crit_tab) tir = pvt_acos(c1) > T.dv(L.crit_d + container * A.n_nodes + adjacent);
-                else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(container * ND + ND_RN)));
+                else if (crit_tab) tir = pvt_acos(c1) > T.dv(L.crit_d + kc * L.n_cls + ka);
+                else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(L.ncls_d + kc * 2 + 1)));
                 if (tir) {
                     r = 1.0;
                 } else {
@@ -1734,7 +1903,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     V3 t2v{b, sign + mm.y * mm.y * a, -mm.y};
                     V3 dl{sd.x * t1v.x + sd.y * t2v.x + sd.z * mm.x, sd.x * t1v.y + sd.y * t2v.y + sd.z * mm.y,
                           sd.x * t1v.z + sd.y * t2v.z + sd.z * mm.z};
-                    const int q = hit * ND + ND_L2W;
+                    const int q = node_rot(node_bits(hit)) + RT_L2W;
                     dir.x = T.dv(q + 0) * dl.x + T.dv(q + 1) * dl.y + T.dv(q + 2) * dl.z;
                     dir.y = T.dv(q + 3) * dl.x + T.dv(q + 4) * dl.y + T.dv(q + 5) * dl.z;
                     dir.z = T.dv(q + 6) * dl.x + T.dv(q + 7) * dl.y + T.dv(q + 8) * dl.z;
@@ -1801,10 +1970,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             // recorder with the full tolerance test (its first trip).  Everything else is walked.
             int cs = 0, cn = 0, rbin = -1;
             if (alive && t_sel >= 0) {
-                const int key = L.cand_i + (t_node * 7 + t_sel) * 8;
-                cs = T.iv(key);
-                cn = T.iv(key + 1);
-                if (t_normal) {
+                const int cb = T.iv(t_node * NI + NI_CAND);   // -1: nobody listens to this node
+                const int key = L.cand_i + ((cb < 0 ? 0 : cb) * 7 + t_sel) * 8;
+                if (cb >= 0) {
+                    cs = T.iv(key);
+                    cn = T.iv(key + 1);
+                }
+                if (cb >= 0 && t_normal) {
                     const double ax = pvt_fabs(nrm.x), ay = pvt_fabs(nrm.y), az = pvt_fabs(nrm.z);
                     int b = (ax >= ay && ax >= az) ? (nrm.x > 0.0 ? 1 : 0)
                           : (ay >= az)             ? (nrm.y > 0.0 ? 3 : 2)
@@ -1949,6 +2121,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_w4(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, false>(A);
+}
+template <bool RECORD, int SEENW, bool EMIT>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_grid(KArgs A) {
+    trace_body<RECORD, true, SEENW, EMIT, false, true>(A);
 }
 
 }  // namespace
