@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 9
+#define PVT_ABI_VERSION 10
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -353,6 +353,17 @@ int pvt_scene_launch_info(PvtScene* scene, int32_t* grid, int32_t* block, int32_
  * node / leaf counts and the tree depth, or PVT_ERR_INVALID with pvt_last_error(). */
 int pvt_mesh_bvh_check(const PvtSceneTables* tables, int32_t node, int32_t* n_bvh_nodes,
                        int32_t* n_leaves, int32_t* depth);
+
+/* Host-only view of the NODE GRID the library builds for scenes of many nodes (no GPU needed).  The reference
+ * intersects every node in every step (_kernel.pyx:666-680); for such scenes the trace kernel instead files every
+ * node but the root under the cells of a uniform grid touched by its bounding box grown by a margin, and each
+ * photon tests only the nodes filed under the cells its ray passes (results unchanged bit for bit).
+ * dims[3] = cells per axis, all 0 when the scene gets no grid (few nodes, meshes, non-rigid poses; the plain node loop
+ * then serves it); lo[3] / cell[3] = the grid's corner and cell edges, `guard` = the margin, `odd` = a cylinder is
+ * filed (the walk's early exit is then more cautious).  `masks` (nullable) receives, per cell (x fastest), two 64-bit
+ * words whose bit n says node n is filed there, up to `masks_cap` words. */
+int pvt_node_grid_plan(const PvtSceneTables* tables, int32_t* dims, double* lo, double* cell, double* guard,
+                       int32_t* odd, uint64_t* masks, int64_t masks_cap);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,8 @@ struct PvtScene {
     int lazy_root = 0;              // 1 box / 2 sphere root that strictly contains every other node (see the kernel's node loop)
     double lazy_k = 0.0;            // sphere root: 1 / (2 radius)
     bool exit_observed = false;     // a recorder listens to (root, exit)
+    bool grid = false;              // the scene has a node grid (many nodes; see plan_node_grid)
+    int grid_dims[3] = {0, 0, 0};
     bool fuse_exit = false;         // see scene_create: photons leaving the only child's surface outwards are done
     bool hist_reads_position = false;   // a histogram axis is x, y or z
     bool consolidate = true;        // developer switches (environment), read once at scene creation
@@ -166,6 +168,130 @@ static double cosine_threshold(double crit) {
         if (hi + k <= bits(1.0) && beyond(from(hi + k))) return NAN;
     }
     return from(hi);   // the smallest cosine that is NOT beyond the critical angle
+}
+
+// The node grid of scenes with many nodes (kernel: GRID variants, the walk in the node loop).  Every node but the root
+// is filed under the cells that its world-space bounding box, grown by 2m, touches; m = 1e-6 of the scene's extent, many
+// orders of magnitude above the rounding of any distance the intersection arithmetic forms (1e-16 of it per
+// operation).  What the kernel's early exit relies on, with that margin:
+//   * a crossing the reference's arithmetic reports for a node lies inside that node's box grown by m, so some cell the
+//     walk has visited by then (the walk's own rounding: 1e-13 of the extent) holds the node;
+//   * a node filed under none of the cells visited so far stands clear of the photon by more than m, so a box or a
+//     sphere (radius >= 1e-5 of the extent, checked here) is crossed twice or not at all -- never once.
+// Returns false (no grid: the plain node loop serves the scene) for scenes it cannot vouch for: few nodes, meshes,
+// non-rigid or inconsistent poses, degenerate shapes.
+struct NodeGrid {
+    int n[3] = {1, 1, 1};
+    double lo[3], hi[3], cell[3], guard = 0.0;
+    int words = 1;
+    bool odd = false, any_rotated = false;
+    std::vector<unsigned long long> masks;
+};
+static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
+    const int N = t->n_nodes, root = t->root_id;
+    int min_nodes = 8;
+    if (const char* env = getenv("PVT_GRID_MIN_NODES")) min_nodes = atoi(env);
+    if (getenv("PVT_NO_GRID") || N < min_nodes || N < 3) return false;
+    std::vector<double> blo((size_t)N * 3), bhi((size_t)N * 3);
+    double extent = 0.0;
+    for (int n = 0; n < N; n++) {
+        if (t->geom_type[n] == PVT_GEOM_MESH) return false;
+        const double* w = t->world_to_local + n * 16;
+        const double* l = t->local_to_world + n * 16;
+        const double* gp = t->geom_params + n * 4;
+        double h[3];
+        switch (t->geom_type[n]) {
+            case PVT_GEOM_BOX: h[0] = 0.5 * gp[0]; h[1] = 0.5 * gp[1]; h[2] = 0.5 * gp[2]; break;
+            case PVT_GEOM_SPHERE: h[0] = h[1] = h[2] = gp[0]; break;
+            default: h[0] = h[1] = gp[1]; h[2] = 0.5 * gp[0]; break;   // cylinder about z
+        }
+        for (int a = 0; a < 3; a++)
+            if (!(std::isfinite(h[a]) && h[a] > 0.0)) return false;
+        // rigid and consistent: world->local is a rotation plus a translation, local->world its inverse
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                double rr = 0.0, wl = 0.0;
+                for (int k = 0; k < 3; k++) { rr += w[r * 4 + k] * w[c * 4 + k]; wl += w[r * 4 + k] * l[k * 4 + c]; }
+                if (!(std::fabs(rr - (r == c ? 1.0 : 0.0)) < 1e-9) || !(std::fabs(wl - (r == c ? 1.0 : 0.0)) < 1e-9)) return false;
+            }
+        double back = 0.0;   // world->local of the node's own origin must be the zero vector
+        for (int r = 0; r < 3; r++) {
+            const double v = w[r * 4] * l[3] + w[r * 4 + 1] * l[7] + w[r * 4 + 2] * l[11] + w[r * 4 + 3];
+            back = std::fmax(back, std::fabs(v));
+        }
+        for (int a = 0; a < 3; a++) {
+            const double c = l[a * 4 + 3];
+            double hw = t->geom_type[n] == PVT_GEOM_SPHERE ? h[0]
+                                                           : std::fabs(l[a * 4]) * h[0] + std::fabs(l[a * 4 + 1]) * h[1] + std::fabs(l[a * 4 + 2]) * h[2];
+            hw *= 1.0 + 1e-9;
+            if (!std::isfinite(c) || !std::isfinite(hw)) return false;
+            blo[(size_t)n * 3 + a] = c - hw; bhi[(size_t)n * 3 + a] = c + hw;
+            extent = std::fmax(extent, std::fabs(c) + hw);
+        }
+        if (!(back <= 1e-9 * (1.0 + extent))) return false;
+        if (n != root) {   // rotated: the 3x3 block of world->local is not the identity, bit for bit
+            const double one = 1.0, zero = 0.0;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++)
+                    if (std::memcmp(&w[r * 4 + c], r == c ? &one : &zero, 8) != 0 || std::memcmp(&l[r * 4 + c], r == c ? &one : &zero, 8) != 0)
+                        g->any_rotated = true;
+        }
+    }
+    if (!(extent > 0.0) || !std::isfinite(extent)) return false;
+    const double m = 1e-6 * extent;
+    for (int n = 0; n < N; n++) {
+        if (n == root || t->geom_type[n] == PVT_GEOM_BOX) continue;
+        const double radius = t->geom_type[n] == PVT_GEOM_SPHERE ? t->geom_params[n * 4] : t->geom_params[n * 4 + 1];
+        if (!(radius >= 1e-5 * extent)) return false;
+        if (t->geom_type[n] == PVT_GEOM_CYLINDER) g->odd = true;
+    }
+    // (negative controls of tests/test_gpu_grid.py: file the boxes a centimetre too small / leave the walk as soon as
+    // any two crossings are known -- results must then differ from the referee's)
+    const double grow = getenv("PVT_GRID_DEV_SHRINK") ? -1.0 : 2.0 * m;
+    for (int a = 0; a < 3; a++) { g->lo[a] = INFINITY; g->hi[a] = -INFINITY; }
+    for (int n = 0; n < N; n++) {
+        if (n == root) continue;
+        for (int a = 0; a < 3; a++) {
+            blo[(size_t)n * 3 + a] -= grow; bhi[(size_t)n * 3 + a] += grow;
+            g->lo[a] = std::fmin(g->lo[a], blo[(size_t)n * 3 + a] - m);
+            g->hi[a] = std::fmax(g->hi[a], bhi[(size_t)n * 3 + a] + m);
+        }
+    }
+    // resolution: about one cell per node (measured on the tile arrays: 121 / 242 / 484 / 961 cells for 121 tiles give
+    // 2.03 / 2.06 / 2.59 / 2.08 ms per 2 10^6 photons), at most 512 (8 KB of masks in LDS), cells as cubic as the extent allows
+    double target = std::fmin(512.0, std::fmax(8.0, 1.0 * (N - 1)));
+    if (const char* env = getenv("PVT_GRID_CELLS")) target = std::fmin(4096.0, std::fmax(1.0, atof(env)));
+    double ext[3], vol = 1.0;
+    for (int a = 0; a < 3; a++) { ext[a] = g->hi[a] - g->lo[a]; vol *= ext[a]; }
+    double side = std::cbrt(vol / target);
+    for (int pass = 0; pass < 200; pass++) {
+        long long cells = 1;
+        for (int a = 0; a < 3; a++) {
+            g->n[a] = (int)std::fmin(64.0, std::fmax(1.0, std::floor(ext[a] / side + 0.5)));
+            cells *= g->n[a];
+        }
+        if ((double)cells <= target * 1.25) break;
+        side *= 1.05;
+    }
+    g->words = N > 64 ? 2 : 1;
+    g->guard = getenv("PVT_GRID_DEV_GUARD") ? -1e30 : m;
+    for (int a = 0; a < 3; a++) g->cell[a] = ext[a] / g->n[a];
+    g->masks.assign((size_t)g->n[0] * g->n[1] * g->n[2] * g->words, 0ull);
+    for (int n = 0; n < N; n++) {
+        if (n == root) continue;
+        int c0[3], c1[3];
+        for (int a = 0; a < 3; a++) {   // cells touched, one cell more on either side when a face lies within m of a cell wall
+            c0[a] = (int)std::floor((blo[(size_t)n * 3 + a] - m - g->lo[a]) / g->cell[a]);
+            c1[a] = (int)std::floor((bhi[(size_t)n * 3 + a] + m - g->lo[a]) / g->cell[a]);
+            c0[a] = c0[a] < 0 ? 0 : c0[a];
+            c1[a] = c1[a] > g->n[a] - 1 ? g->n[a] - 1 : c1[a];
+        }
+        for (int z = c0[2]; z <= c1[2]; z++)
+            for (int y = c0[1]; y <= c1[1]; y++)
+                for (int x = c0[0]; x <= c1[0]; x++)
+                    g->masks[(((size_t)z * g->n[1] + y) * g->n[0] + x) * g->words + (n >> 6)] |= 1ull << (n & 63);
+    }
+    return true;
 }
 
 int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
@@ -393,7 +519,20 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + M * M : -1;
     lay.rot_d = spec_end + (lay.crit_d >= 0 ? 2 * M * M : 0);
     lay.ncls_d = lay.rot_d + Q * RT;
-    std::vector<double> gd((size_t)lay.ncls_d + (size_t)M * 2 + 1, 0.0);
+    NodeGrid grid;
+    const bool has_grid = plan_node_grid(t, &grid);
+    lay.grid_d = has_grid ? lay.ncls_d + M * 2 : -1;
+    std::vector<double> gd((size_t)lay.ncls_d + (size_t)M * 2 + (has_grid ? 14 + grid.masks.size() : 0) + 1, 0.0);
+    if (has_grid) {
+        double* d = gd.data() + lay.grid_d;
+        for (int a = 0; a < 3; a++) { d[a] = grid.lo[a]; d[3 + a] = grid.hi[a]; d[6 + a] = grid.cell[a]; d[9 + a] = 1.0 / grid.cell[a]; }
+        d[12] = grid.guard;
+        const unsigned long long bits = (unsigned long long)grid.n[0] | ((unsigned long long)grid.n[1] << 8) | ((unsigned long long)grid.n[2] << 16) |
+                                        ((unsigned long long)grid.words << 24) | ((unsigned long long)(grid.odd ? 1 : 0) << 28) |
+                                        ((unsigned long long)(grid.any_rotated ? 1 : 0) << 29);
+        std::memcpy(&d[13], &bits, 8);
+        std::memcpy(&d[14], grid.masks.data(), grid.masks.size() * 8);
+    }
     if (lay.crit_d >= 0)
         for (int c = 0; c < M; c++)
             for (int a = 0; a < M; a++) {
@@ -688,6 +827,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->lazy_k = lazy_k;
     s->exit_observed = exit_observed;
     s->fuse_exit = fuse_exit;
+    s->grid = has_grid;
+    for (int a = 0; a < 3; a++) s->grid_dims[a] = has_grid ? grid.n[a] : 0;
     for (int h = 0; h < H; h++)
         if (t->hist_prop_a[h] >= 4 || t->hist_prop_b[h] >= 4) s->hist_reads_position = true;
     hipDeviceProp_t prop;
@@ -794,6 +935,13 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
 template <bool RECORD, bool TAB_LDS, int SEENW>
 hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
     const bool mesh = a.bvh != nullptr;
+    if constexpr (TAB_LDS && (!PVT_DEV_VARIANTS || SEENW == 1)) {
+        if (a.lay.grid_d >= 0 && !mesh && (!PVT_DEV_VARIANTS || !emit)) {   // many nodes: per-lane walk of the node grid
+            if (emit && !PVT_DEV_VARIANTS) hipLaunchKernelGGL((trace_kernel_grid<RECORD, SEENW, !PVT_DEV_VARIANTS>), dim3(grid), dim3(kBlock), lds, st, a);
+            else hipLaunchKernelGGL((trace_kernel_grid<RECORD, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
+            return hipGetLastError();
+        }
+    }
 #if PVT_DEV_VARIANTS
     if (emit || mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
     if constexpr (TAB_LDS && SEENW == 1) {
@@ -1016,6 +1164,9 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
         fprintf(stderr, "[pvt stats] solo-wave cycles: refill %llu nodes %llu absorb %llu frame %llu trig %llu surface %llu tally %llu (solo waves %llu)\n",
                 c[9], c[10], c[11], c[12], c[13], c[14], c[15], c[16]);
         const double bi = (double)(c[1] - c[3]) + 1e-9;
+        if (a.lay.grid_d >= 0)
+            fprintf(stderr, "[pvt stats] grid walk per wave-iteration: cell rounds %.2f  node-test trips %.2f  (lanes per trip %.1f, lanes per cell round %.1f)\n",
+                    (double)c[25] / c[1], (double)c[26] / c[1], (double)c[27] / (c[26] + 1e-9), (double)c[28] / (c[25] + 1e-9));
         fprintf(stderr, "[pvt stats] bulk lanes/iteration: live %.1f absorbed %.1f re-emitted %.1f surface %.1f exit %.1f terminal-selector %.1f terminal %.1f\n",
                 c[17] / bi, c[18] / bi, c[19] / bi, c[20] / bi, c[21] / bi, c[22] / bi, c[23] / bi);
     }
@@ -1609,5 +1760,26 @@ int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables*
 }
 
 int pvt_last_multi_reduce(void) { return g_last_multi_reduce; }
+
+int pvt_node_grid_plan(const PvtSceneTables* t, int32_t* dims, double* lo, double* cell, double* guard, int32_t* odd,
+                       uint64_t* masks, int64_t masks_cap) {
+    if (!t || !dims || t->n_nodes <= 0 || t->n_nodes > PVT_MAX_NODES) return fail(PVT_ERR_INVALID, "bad argument");
+    NodeGrid g;
+    const bool on = plan_node_grid(t, &g);
+    for (int a = 0; a < 3; a++) {
+        dims[a] = on ? g.n[a] : 0;
+        if (lo) lo[a] = on ? g.lo[a] : 0.0;
+        if (cell) cell[a] = on ? g.cell[a] : 0.0;
+    }
+    if (guard) *guard = on ? g.guard : 0.0;
+    if (odd) *odd = on && g.odd ? 1 : 0;
+    if (on && masks) {
+        const size_t cells = (size_t)g.n[0] * g.n[1] * g.n[2];
+        for (size_t c = 0; c < cells; c++)
+            for (int w = 0; w < 2; w++)
+                if ((int64_t)(c * 2 + w) < masks_cap) masks[c * 2 + w] = w < g.words ? g.masks[c * g.words + w] : 0ull;
+    }
+    return PVT_OK;
+}
 
 }  // extern "C"

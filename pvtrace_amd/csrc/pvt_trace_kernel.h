@@ -63,10 +63,11 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // table element is addressed as base + index*stride + field with compile-time strides
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
 // Node records are what a photon reads of the node it is in / hits / tests, and what the intersection loop reads of
-// EVERY node: 64 bytes (one scalar load in the wave-uniform loop, four 16-byte LDS reads per lane in the grid walk).
+// EVERY node: 64 bytes of payload, 72 apart -- the lanes of the grid walk read the records of DIFFERENT nodes in one
+// LDS instruction, and with 64 bytes between records all of them would fall on two of the 32 banks.
 // Rotations, refractive-index reciprocals and critical angles live in small side tables indexed by CLASS (nodes with
 // bit-identical rotations / refractive indices share an entry), so a scene of 120 tiles costs 12 KB of LDS, not 56.
-enum { ND_T = 0, ND_PARAMS = 3, ND_BITS = 6, ND_N = 7, ND = 8 };  // node doubles: translation of world->local, three shape
+enum { ND_T = 0, ND_PARAMS = 3, ND_BITS = 6, ND_N = 7, ND = 9 };  // node doubles: translation of world->local, three shape
                                                                  // parameters (no shape has four), one word of {bit 0: the
                                                                  // rotation is the identity, bit for bit; bits 8-15: geometry
                                                                  // type; high half: rotation class}, refractive index
@@ -747,11 +748,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     // Forward crossings (t > kEps) of one analytic shape by the ray (o, d) in the shape's own frame, each handed to
     // `fold` in the reference's order (_kernel.pyx:245-345).  `inv`: 1/d per axis (boxes only).  The shape parameters
     // are scalars in the wave-uniform node loop and per-lane values in the grid walk: same operations either way.
-    auto shape_hits = [](int gt, double g0, double g1, double g2, const V3& o, const V3& d, const double (&inv)[3], auto&& fold) {
+    auto shape_hits = [](int gt, double g0, double g1, double g2, const V3& o, const V3& d, double inv0, double inv1, double inv2,
+                         auto&& fold) __attribute__((always_inline)) {
         if (gt == PVT_GEOM_BOX) {  // slab test (:245-276)
             double tmin = -INFINITY, tmax = INFINITY;
             bool miss = false;
-            const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, gpar[3] = {g0, g1, g2};
+            const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, gpar[3] = {g0, g1, g2}, inv[3] = {inv0, inv1, inv2};
             // a ray parallel to a pair of faces (a direction component below 1e-300) takes the reference's
             // inside/outside test for that axis; the wave only runs the general form when a lane holds one
             if (__ballot(pvt_fabs(dd[0]) < 1e-300 || pvt_fabs(dd[1]) < 1e-300 || pvt_fabs(dd[2]) < 1e-300) == 0ull) {
@@ -849,6 +851,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_mark = 0;
 #define PVT_MARK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); if (ws & WS_SOLO) st_t[k] += now_ - st_mark; st_mark = now_; } while (0)
     unsigned long long st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bulk-phase lane counts per section
+    unsigned long long st_g[4] = {0, 0, 0, 0};   // grid walk: cell rounds, node-test trips (per wave), node tests, cell steps (per lane)
 #define PVT_COUNT(k, pred) do { unsigned long long b_ = __ballot(pred); if (!(ws & WS_EXHAUSTED)) st_c[k] += __popcll(b_); } while (0)
 #else
 #define PVT_MARK(k) do {} while (0)
@@ -1244,6 +1247,28 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 // distance to the root's nearest face -- and only the lanes it cannot decide for pay for the
                 // root's intersection; in a typical scene (a 5 cm slab in a 5 m world) none ever does.
                 const int lazy_root = (MESH || RECORD) ? 0 : (uf(UF_LAZY1) ? 1 : (uf(UF_LAZY2) ? 2 : 0));   // wave-uniform (tally launches only)
+                // Grid scenes fold a crossing by the key (t, node): what the reference's first-minimum scans over its hit
+                // list (nodes ascending) come to, whatever the order the nodes are visited in.  Written as selects of
+                // VALUES: as branches that assign, the compiler merges the assignments into stores through a selected
+                // POINTER, and nearest / second-nearest then live in scratch memory.
+                // (Every captured variable is read ONCE, up front, and written once at the end: a lambda's body is optimised
+                // before it is inlined, while its captures are still pointers, and a choice between two of them read in
+                // different branches becomes a load through a chosen pointer -- which pins them to memory for good.)
+                auto fold_by_key = [&](double t, int node, int& nl, double& tfirst) __attribute__((always_inline)) {
+                    const double a1 = t1, a2 = t2, tf = tfirst;
+                    const int m1 = n1, m2 = n2, have = nhits, l = nl;
+                    const bool none = have == 0;
+                    const bool nearest = none || t < a1 || (t == a1 && node < m1);
+                    const bool second = !nearest && (m2 < 0 || t < a2 || (t == a2 && node < m2));
+                    const bool shift = nearest && !none;
+                    tfirst = l == 0 ? t : tf;
+                    nl = l + 1;
+                    t1 = nearest ? t : a1;
+                    n1 = nearest ? node : m1;
+                    t2 = shift ? a1 : (second ? t : a2);
+                    n2 = shift ? m1 : (second ? node : m2);
+                    nhits = have + 1;
+                };
                 if constexpr (GRID) {
                     // ---- scenes of many nodes: every lane looks up ITS candidates in a uniform grid over the nodes -----
                     // The reference intersects every node in every step (_kernel.pyx:666-680).  A node the ray does not
@@ -1263,7 +1288,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     const int gb = L.grid_d;
                     const unsigned long long gbits = pvt_d2u(T.du(gb + 13));   // nx | ny << 8 | nz << 16 | words << 24 | odd << 28
                     const double guard = T.du(gb + 12);
-                    const double invw[3] = {rcp_normal(dir.x), rcp_normal(dir.y), rcp_normal(dir.z)};
+                    // (everything the walk keeps is a named scalar: a local array that is selected from or passed by reference
+                    // ends up in scratch memory, and a scratch access is a trip to the memory system in the middle of the walk)
+                    const double invw0 = rcp_normal(dir.x), invw1 = rcp_normal(dir.y), invw2 = rcp_normal(dir.z);
+                    const double invw[3] = {invw0, invw1, invw2};   // (set-up only, fully unrolled)
                     const double pw[3] = {pos.x, pos.y, pos.z}, dw[3] = {dir.x, dir.y, dir.z};
                     // the ray against the grid's box (a direction component this small moves the photon by less than
                     // rounding over the whole scene: treated as parallel)
@@ -1282,7 +1310,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     }
                     if (!(t_in <= t_out)) walk = false;
                     // first cell, the distance at which the ray leaves it along each axis, steps left along each axis
-                    double tm[3];
+                    double tm0 = INFINITY, tm1 = INFINITY, tm2 = INFINITY;
                     unsigned int remv = 0;   // steps left: x | y << 8 | z << 16; bits 24-26: the ray runs towards lower indices
                     int ci = 0;
                     {
@@ -1295,7 +1323,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             int c = (int)((at - lo) * rcell);
                             c = c < 0 ? 0 : (c > na - 1 ? na - 1 : c);
                             const bool par = pvt_fabs(dw[a]) < 1e-20, neg = dw[a] < 0.0;
-                            tm[a] = par ? INFINITY : ((lo + (double)(c + (neg ? 0 : 1)) * cell) - pw[a]) * invw[a];
+                            const double tma = par ? INFINITY : ((lo + (double)(c + (neg ? 0 : 1)) * cell) - pw[a]) * invw[a];
+                            if (a == 0) tm0 = tma; else if (a == 1) tm1 = tma; else tm2 = tma;
                             remv |= (unsigned int)(neg ? c : na - 1 - c) << (8 * a);
                             if (neg) remv |= 1u << (24 + a);
                             ci += c * stride;
@@ -1304,27 +1333,25 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     }
                     const int words = (int)((unsigned int)(gbits >> 24) & 0xfu);
                     const bool odd = ((gbits >> 28) & 1ull) != 0;
-                    unsigned long long seen_lo = 0ull, seen_hi = 0ull, pend_lo = 0ull, pend_hi = 0ull;
-                    auto load_cell = [&]() {
-                        const int at = gb + 14 + ci * words;
-                        const unsigned long long m_lo = pvt_d2u(T.dv(at)), m_hi = words > 1 ? pvt_d2u(T.dv(at + 1)) : 0ull;
-                        pend_lo = m_lo & ~seen_lo; pend_hi = m_hi & ~seen_hi;
-                        seen_lo |= m_lo; seen_hi |= m_hi;
-                    };
-                    if (walk) load_cell();
+                    unsigned long long seen_lo = 0ull, seen_hi = 0ull;   // nodes this lane has tested in this step
+                    // (always_inline: a closure that is CALLED holds pointers to the variables it captured, which then live in
+                    // scratch memory)
                     // one node, tested by this lane alone (the records come from LDS with per-lane addresses)
-                    auto visit = [&](int node) {
+                    // One node, tested by this lane alone (records from LDS with per-lane addresses).  The root comes last
+                    // and goes through here too -- with the lazy shortcut of the plain node loop below, when the launch
+                    // has it -- so the intersection code exists once in the kernel's text.
+                    auto visit = [&](int node) __attribute__((always_inline)) {
                         const int hn = node * ND;
                         const double tx = T.dv(hn + ND_T), ty = T.dv(hn + ND_T + 1), tz = T.dv(hn + ND_T + 2);
                         const double g0 = T.dv(hn + ND_PARAMS), g1 = T.dv(hn + ND_PARAMS + 1), g2 = T.dv(hn + ND_PARAMS + 2);
                         const unsigned long long hb = pvt_d2u(T.dv(hn + ND_BITS));
-                        const int gt = (int)(((unsigned int)hb >> 8) & 0xffu);
+                        int gt = (int)(((unsigned int)hb >> 8) & 0xffu);
                         V3 o, dl;
-                        double il[3];
+                        double il0, il1, il2;
                         if ((hb & 1ull) != 0) {
                             o.x = pos.x + tx; o.y = pos.y + ty; o.z = pos.z + tz;
                             dl = dir;
-                            il[0] = invw[0]; il[1] = invw[1]; il[2] = invw[2];
+                            il0 = invw0; il1 = invw1; il2 = invw2;
                         } else {
                             const int rm = L.rot_d + (int)(unsigned int)(hb >> 32) * RT + RT_W2L;
                             o.x = T.dv(rm + 0) * pos.x + T.dv(rm + 1) * pos.y + T.dv(rm + 2) * pos.z + tx;
@@ -1333,55 +1360,86 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             dl.x = T.dv(rm + 0) * dir.x + T.dv(rm + 1) * dir.y + T.dv(rm + 2) * dir.z;
                             dl.y = T.dv(rm + 3) * dir.x + T.dv(rm + 4) * dir.y + T.dv(rm + 5) * dir.z;
                             dl.z = T.dv(rm + 6) * dir.x + T.dv(rm + 7) * dir.y + T.dv(rm + 8) * dir.z;
-                            il[0] = rcp_normal(dl.x); il[1] = rcp_normal(dl.y); il[2] = rcp_normal(dl.z);
+                            il0 = rcp_normal(dl.x); il1 = rcp_normal(dl.y); il2 = rcp_normal(dl.z);
+                        }
+                        bool root_known = false;
+                        if (lazy_root && node == A.root) {   // (see the plain node loop: same bound, same conditions)
+                            double bound;
+                            if (lazy_root == 1) {
+                                bound = __builtin_fmin(__builtin_fmin(0.5 * g0 - pvt_fabs(o.x), 0.5 * g1 - pvt_fabs(o.y)), 0.5 * g2 - pvt_fabs(o.z));
+                            } else {
+                                bound = (g0 * g0 - dot3(o, o)) * A.lazy_k;
+                            }
+                            const bool undecided = !(bound > 0.0) || (nhits > 0 && !(t1 < bound)) || (nhits >= 2 && !(t2 < bound)) ||
+                                                   (cnode >= 0 && !(cbest < bound));
+                            {   // one more crossing, behind all the others: nearest only if there is no other
+                                const double a1 = t1, a2 = t2;
+                                const int m1 = n1, m2 = n2, have = nhits, cn = cnode;
+                                const bool known = !undecided;
+                                t1 = known && have == 0 ? bound : a1; n1 = known && have == 0 ? node : m1;
+                                t2 = known && have == 1 ? INFINITY : a2; n2 = known && have == 1 ? node : m2;
+                                nhits = have + (known ? 1 : 0);
+                                cnode = known && cn < 0 ? node : cn;   // crossed once: it holds the ray unless a nearer node does
+                                root_known = known;
+                                gt = known ? -1 : gt;   // nothing to intersect
+                            }
                         }
                         int nl = 0;
                         double tfirst = 0.0;
-                        auto fold = [&](double t) {
-                            if (nl == 0) tfirst = t;
-                            nl += 1;
-                            if (nhits == 0) { t1 = t; n1 = node; }
-                            else if (t < t1 || (t == t1 && node < n1)) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
-                            else if (n2 < 0 || t < t2 || (t == t2 && node < n2)) { t2 = t; n2 = node; }
-                            nhits += 1;
-                        };
-                        shape_hits(gt, g0, g1, g2, o, dl, il, fold);
-                        if (nl == 1 && (tfirst < cbest || (tfirst == cbest && node < cnode))) { cbest = tfirst; cnode = node; }
+                        auto fold = [&](double t) __attribute__((always_inline)) { fold_by_key(t, node, nl, tfirst); };
+                        if (gt >= 0) shape_hits(gt, g0, g1, g2, o, dl, il0, il1, il2, fold);
+                        {
+                            const double cb = cbest;
+                            const int cn = cnode;
+                            const bool holds = nl == 1 && !root_known && (tfirst < cb || (tfirst == cb && node < cn));
+                            cbest = holds ? tfirst : cb;
+                            cnode = holds ? node : cn;
+                        }
                     };
+                    auto next_cell = [&]() __attribute__((always_inline)) {   // leave the current cell: done, or on to the next one
+                        const double t_cell = __builtin_fmin(tm0, __builtin_fmin(tm1, tm2));   // the ray leaves the cell here
+                        const bool enough = nhits >= 2 && t2 + guard < t_cell && (!odd || (cnode >= 0 && cbest + guard < t_cell));
+                        const int ax = (tm0 <= tm1 && tm0 <= tm2) ? 0 : (tm1 <= tm2 ? 1 : 2);
+                        const unsigned int left = (remv >> (8 * ax)) & 0xffu;
+                        if (enough || left == 0u || !(t_cell < INFINITY)) {
+                            walk = false;
+                        } else {
+                            remv -= 1u << (8 * ax);
+                            const int nx = (int)((unsigned int)gbits & 0xffu), ny = (int)((unsigned int)(gbits >> 8) & 0xffu);
+                            const int stride = ax == 0 ? 1 : (ax == 1 ? nx : nx * ny);
+                            ci += ((remv >> (24 + ax)) & 1u) ? -stride : stride;
+                            if (ax == 0) tm0 = __builtin_fma(pvt_fabs(invw0), T.du(gb + 6), tm0);
+                            else if (ax == 1) tm1 = __builtin_fma(pvt_fabs(invw1), T.du(gb + 7), tm1);
+                            else tm2 = __builtin_fma(pvt_fabs(invw2), T.du(gb + 8), tm2);
+                        }
+                    };
+                    // Every lane at its own pace: a trip tests ONE node filed under the lane's current cell that the lane has
+                    // not tested yet, or -- none left -- moves the lane on to its next cell; after the walk, the root.
+                    bool root_todo = true;
                     for (;;) {
-                        // the nodes filed under the current cell that this lane has not tested yet
-                        while (__ballot((pend_lo | pend_hi) != 0ull) != 0ull) {
-                            if ((pend_lo | pend_hi) != 0ull) {
-                                int node;
-                                if (pend_lo != 0ull) { node = __builtin_ctzll(pend_lo); pend_lo &= pend_lo - 1ull; }
-                                else { node = 64 + __builtin_ctzll(pend_hi); pend_hi &= pend_hi - 1ull; }
-                                visit(node);
-                            }
-                        }
-                        if (__ballot(walk) == 0ull) break;
+                        if (__ballot(walk || root_todo) == 0ull) break;
+                        bool test = false;
+                        int node = A.root;
                         if (walk) {
-                            const double t_cell = __builtin_fmin(tm[0], __builtin_fmin(tm[1], tm[2]));   // the ray leaves the cell here
-                            const bool enough = nhits >= 2 && t2 + guard < t_cell && (!odd || (cnode >= 0 && cbest + guard < t_cell));
-                            const int ax = (tm[0] <= tm[1] && tm[0] <= tm[2]) ? 0 : (tm[1] <= tm[2] ? 1 : 2);
-                            const unsigned int left = (remv >> (8 * ax)) & 0xffu;
-                            if (enough || left == 0u || !(t_cell < INFINITY)) {
-                                walk = false;
-                            } else {
-                                remv -= 1u << (8 * ax);
-                                const int nx = (int)((unsigned int)gbits & 0xffu), ny = (int)((unsigned int)(gbits >> 8) & 0xffu);
-                                const int stride = ax == 0 ? 1 : (ax == 1 ? nx : nx * ny);
-                                ci += ((remv >> (24 + ax)) & 1u) ? -stride : stride;
-                                if (ax == 0) tm[0] = __builtin_fma(pvt_fabs(invw[0]), T.du(gb + 6), tm[0]);
-                                else if (ax == 1) tm[1] = __builtin_fma(pvt_fabs(invw[1]), T.du(gb + 7), tm[1]);
-                                else tm[2] = __builtin_fma(pvt_fabs(invw[2]), T.du(gb + 8), tm[2]);
-                                load_cell();
-                            }
+                            const int at = gb + 14 + ci * words;
+                            const unsigned long long m_lo = pvt_d2u(T.dv(at)) & ~seen_lo;
+                            const unsigned long long m_hi = words > 1 ? pvt_d2u(T.dv(at + 1)) & ~seen_hi : 0ull;
+                            if (m_lo != 0ull) { node = __builtin_ctzll(m_lo); seen_lo |= m_lo & (0ull - m_lo); test = true; }
+                            else if (m_hi != 0ull) { node = 64 + __builtin_ctzll(m_hi); seen_hi |= m_hi & (0ull - m_hi); test = true; }
+                            else next_cell();
+                        } else if (root_todo) {
+                            root_todo = false;
+                            test = true;
                         }
+#if PVT_STATS
+                        st_g[0] += 1; st_g[1] += 1; st_g[2] += __popcll(__ballot(test)); st_g[3] += __popcll(__ballot(!test));
+#endif
+                        if (test) visit(node);
                     }
                 }
-                // (grid scenes: only the root is left, and it folds by (t, node) like the walk)
-                for (int k = GRID ? A.n_nodes - 1 : 0; k < A.n_nodes; k++) {
-                    const int node = GRID ? A.root : (!lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1)));
+                // (grid scenes have visited every node they need by now)
+                for (int k = 0; k < (GRID ? 0 : A.n_nodes); k++) {
+                    const int node = !lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1));
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
                     // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,
                     // quotient or stored value below can see.
@@ -1443,12 +1501,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         root_known = true;
                     }
                 }
-                auto fold = [&](double t) {
+                auto fold = [&](double t) __attribute__((always_inline)) {
                     if (nl == 0) tfirst = t;
                     nl += 1;
                     if (nhits == 0) { t1 = t; n1 = node; }
-                    else if (t < t1 || (GRID && t == t1 && node < n1)) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
-                    else if (n2 < 0 || t < t2 || (GRID && t == t2 && node < n2)) { t2 = t; n2 = node; }
+                    else if (t < t1) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
+                    else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
                     nhits += 1;
                 };
                 if (root_known) {
@@ -1533,7 +1591,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         inv[0] = rcp_normal(d.x); inv[1] = rcp_normal(d.y); inv[2] = rcp_normal(d.z);   // (garbage below 1e-300: never used)
                         inv_ok = true;
                     }
-                    shape_hits(gt, gpar[0], gpar[1], gpar[2], o, d, inv, fold);
+                    shape_hits(gt, gpar[0], gpar[1], gpar[2], o, d, inv[0], inv[1], inv[2], fold);
                 }
                     // The container is the nearest node the ray starts inside of: crossed exactly once for the
                     // reference's convex shapes (:696-706); a triangle mesh may be non-convex, so it holds the
@@ -1541,7 +1599,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // pvtrace/geometry/mesh.py:29-32)
                     const bool holds = (MESH && gt == PVT_GEOM_MESH) ? (nl & 1) != 0 : nl == 1;
                     if (holds && !root_known) {
-                        if (tfirst < cbest || (GRID && tfirst == cbest && node < cnode)) {
+                        if (tfirst < cbest) {
                             if constexpr (MESH) { c2best = cbest; c2node = cnode; }
                             cbest = tfirst; cnode = node;
                         } else if (MESH && tfirst < c2best) { c2best = tfirst; c2node = node; }
@@ -2067,6 +2125,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         for (int k = 0; k < 7; k++) atomicAdd(c + 8 + k, st_t[k]);
         atomicAdd(c + 15, (ws & WS_SOLO) ? 1ull : 0ull);
         for (int k = 0; k < 8; k++) atomicAdd(c + 16 + k, st_c[k]);
+        for (int k = 0; k < 4; k++) atomicAdd(c + 24 + k, st_g[k]);
     }
 #endif
 #if PVT_TIMELINE
@@ -2122,8 +2181,11 @@ template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_w4(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, false>(A);
 }
+#ifndef PVT_GRID_WAVES
+#define PVT_GRID_WAVES 4
+#endif
 template <bool RECORD, int SEENW, bool EMIT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_grid(KArgs A) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_GRID_WAVES, PVT_GRID_WAVES))) trace_kernel_grid(KArgs A) {
     trace_body<RECORD, true, SEENW, EMIT, false, true>(A);
 }
 

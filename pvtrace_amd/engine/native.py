@@ -251,6 +251,9 @@ def declare_signatures(lib, names):
              C.POINTER(C.c_int32)], C.c_int),
         "pvt_scene_launch_info": (
             [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
+        "pvt_node_grid_plan": (
+            [C.POINTER(PvtSceneTables), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+             C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_int64], C.c_int),
     }
     for name in names:
         argtypes, restype = sigs[name]
@@ -265,11 +268,11 @@ ABI_SYMBOLS = (
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
     "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
-    "pvt_scene_carry_pending", "pvt_last_multi_reduce",
+    "pvt_scene_carry_pending", "pvt_last_multi_reduce", "pvt_node_grid_plan",
 )
 
 _lib = None
-ABI_VERSION = 9   # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 10  # include/pvtrace_hip.h PVT_ABI_VERSION
 FLAG_NO_LOG_PREFILL = 1   # PvtTraceParams.flags
 FLAG_CARRY_OUT = 2        # park the photons still alive at the end of the launch for the next launch on the stream
 
@@ -379,6 +382,30 @@ def mesh_bvh_check(compiled, node):
     check(lib.pvt_mesh_bvh_check(C.byref(st), int(node), *(C.byref(v) for v in out)), "pvt_mesh_bvh_check")
     del keep
     return tuple(int(v.value) for v in out)
+
+
+def node_grid_plan(compiled):
+    """The node grid the library files the nodes of a many-node scene under (host only, no GPU needed;
+    include/pvtrace_hip.h: pvt_node_grid_plan) -> dict(dims, lo, cell, guard, odd, masks[cells, 2] uint64),
+    or None when the scene is served by the plain node loop."""
+    import numpy as np
+
+    lib = load_library()
+    st, keep = scene_tables_struct(compiled)
+    dims = (C.c_int32 * 3)()
+    lo, cell = (C.c_double * 3)(), (C.c_double * 3)()
+    guard, odd = C.c_double(0.0), C.c_int32(0)
+    check(lib.pvt_node_grid_plan(C.byref(st), dims, lo, cell, C.byref(guard), C.byref(odd), None, 0), "pvt_node_grid_plan")
+    if dims[0] == 0:
+        del keep
+        return None
+    cells = int(dims[0]) * int(dims[1]) * int(dims[2])
+    masks = np.zeros((cells, 2), dtype=np.uint64)
+    check(lib.pvt_node_grid_plan(C.byref(st), dims, lo, cell, C.byref(guard), C.byref(odd),
+                                 masks.ctypes.data_as(C.POINTER(C.c_uint64)), masks.size), "pvt_node_grid_plan")
+    del keep
+    return {"dims": tuple(int(v) for v in dims), "lo": np.array(list(lo)), "cell": np.array(list(cell)),
+            "guard": float(guard.value), "odd": bool(odd.value), "masks": masks}
 
 
 class DeviceScene:

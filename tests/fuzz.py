@@ -138,3 +138,75 @@ def random_scene(seed, extensions=False):
         light.translate(tuple(rng.uniform(-3.0, 3.0, 3)))
         light.look_at(tuple(-np.asarray(light.location) + rng.normal(scale=0.3, size=3)))
     return Scene(world)
+
+
+def random_many_scene(seed, n_nodes=None):
+    """Scenes of MANY nodes (8 ... 120; the kernel's node-grid path): small shapes from a pool of shared materials
+    scattered over a box region, a good part of them on a lattice whose pitch EQUALS their size (faces shared with
+    the neighbours: crossings of two nodes at the very same distance, which the reference orders by node index),
+    some rotated by one of a few shared rotations or a random one, some nested inside earlier ones, some overlapping.
+    The reference engine can express all of it (no extensions)."""
+    rng = np.random.default_rng(50_000 + seed)
+    n = int(n_nodes or rng.integers(8, 121))
+    world_material = Material(1.0, components=[Absorber(float(rng.uniform(0.001, 0.01)), name="haze")] if rng.random() < 0.2 else [])
+    world = Node(name="world", geometry=(Sphere(30.0, material=world_material) if rng.random() < 0.4
+                                         else Box((44.0, 40.0, 36.0), material=world_material)))
+    pool = []
+    for k in range(int(rng.integers(1, 5))):
+        comps = _components(rng, False)
+        for j, c in enumerate(comps):
+            c.name = f"m{k}c{j}"
+        surface = Surface(delegate=NullSurfaceDelegate()) if rng.random() < 0.1 else None
+        pool.append(Material(float(rng.choice([1.0, 1.33, 1.5, 1.5, 1.7, float(rng.uniform(1.0, 2.2))])), surface=surface, components=comps))
+    kinds = rng.choice(3, p=[[0.7, 0.2, 0.1], [0.34, 0.33, 0.33], [1.0, 0.0, 0.0]][int(rng.integers(0, 3))], size=n)
+    rotations = [(float(rng.uniform(0, np.pi)), tuple(rng.normal(size=3))) for _ in range(3)]
+    lattice = float(rng.choice([1.0, 1.5, 2.0]))
+    flat = rng.random() < 0.4          # a tile array: one layer
+    span = max(2, int(np.ceil(n ** (0.5 if flat else 1 / 3.0))) + 1)
+    nodes, used = [world], set()
+    for k in range(n):
+        material = pool[int(rng.integers(0, len(pool)))]
+        # (materials are shared objects: the flattener repeats their tables per node, the packer stores them once)
+        nested = k > 2 and rng.random() < 0.15
+        on_lattice = not nested and rng.random() < 0.6
+        if kinds[k] == 0:
+            size = (lattice,) * 3 if on_lattice else tuple(rng.uniform(0.3, 2.5, 3))
+            if nested:
+                size = tuple(rng.uniform(0.1, 0.4, 3))
+            geometry = Box(size, material=material)
+        elif kinds[k] == 1:
+            geometry = Sphere(float(0.5 * lattice if on_lattice else rng.uniform(0.1 if nested else 0.3, 0.35 if nested else 1.4)), material=material)
+        else:
+            geometry = Cylinder(float(lattice if on_lattice else rng.uniform(0.2 if nested else 0.5, 0.4 if nested else 2.5)),
+                                float(0.5 * lattice if on_lattice else rng.uniform(0.1, 0.3 if nested else 1.0)), material=material)
+        parent = nodes[int(rng.integers(1, len(nodes)))] if nested else world
+        node = Node(name=f"n{k}", parent=parent, geometry=geometry)
+        if nested:
+            node.translate(tuple(rng.uniform(-0.2, 0.2, 3)))
+        elif on_lattice:
+            for _ in range(50):
+                cell = (int(rng.integers(0, span)), int(rng.integers(0, span)), 0 if flat else int(rng.integers(0, span)))
+                if cell not in used:
+                    break
+            used.add(cell)
+            node.translate(tuple((np.array(cell) - 0.5 * span) * lattice))
+        else:
+            node.translate(tuple(rng.uniform(-0.6 * span * lattice, 0.6 * span * lattice, 3) * (1.0, 1.0, 0.2 if flat else 1.0)))
+        if not on_lattice and rng.random() < 0.35:
+            angle, axis = rotations[int(rng.integers(0, 3))] if rng.random() < 0.6 else (float(rng.uniform(0, np.pi)), tuple(rng.normal(size=3)))
+            node.rotate(angle, axis)
+        nodes.append(node)
+    for node in nodes:
+        if rng.random() < (1.0 if node is world else 12.0 / n):
+            node.recorders = _recorders(rng, node, node is world, [], False)
+    taken = set()
+    for node in nodes:
+        node.recorders = [r for r in (node.recorders or []) if not (r.name in taken or taken.add(r.name))]
+    for k in range(int(rng.integers(1, 3))):
+        pos = [None, RectangularMask(0.5 * span * lattice, 0.5 * span * lattice), CubeMask(1.0, 1.0, 1.0)][int(rng.integers(0, 3))]
+        direc = [isotropic, Cone(float(rng.uniform(0.2, 1.2))), lambertian, None][int(rng.integers(0, 4))]
+        light = Node(name=f"light{k}", parent=world, light=Light(wavelength=ConstantWavelengthMask(float(rng.uniform(420, 700))),
+                                                                 position=pos, direction=direc, name=f"light{k}"))
+        light.translate(tuple(rng.uniform(-1.0, 1.0, 3) * (1.0, 1.0, 0.0) + (0.0, 0.0, float(rng.choice([-1, 1])) * (0.8 if flat else 0.6 * span) * lattice + 0.3)))
+        light.look_at(tuple(-np.asarray(light.location) + rng.normal(scale=0.5, size=3)))
+    return Scene(world)
