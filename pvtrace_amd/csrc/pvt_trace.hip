@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <dlfcn.h>
@@ -257,40 +258,157 @@ static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
             g->hi[a] = std::fmax(g->hi[a], bhi[(size_t)n * 3 + a] + m);
         }
     }
-    // resolution: about one cell per node (measured on the tile arrays: 121 / 242 / 484 / 961 cells for 121 tiles give
-    // 2.03 / 2.06 / 2.59 / 2.08 ms per 2 10^6 photons), at most 512 (8 KB of masks in LDS), cells as cubic as the extent allows
-    double target = std::fmin(512.0, std::fmax(8.0, 1.0 * (N - 1)));
-    if (const char* env = getenv("PVT_GRID_CELLS")) target = std::fmin(4096.0, std::fmax(1.0, atof(env)));
+    // ---- resolution.  What a photon pays for is the nodes it tests and the cells it steps through, and both depend on
+    // how the cells fall on the nodes: on an array of 6 x 6 tiles a 6 x 6 grid (one tile per cell) traces 2.26e9
+    // photons/s, 8 x 8 and 15 x 15 grids 1.58e9, 11 x 11 1.93e9 (measured).  So the resolution is CHOSEN: starting from
+    // about one cubic cell per node, each axis in turn tries other counts, and a candidate is priced by walking a fixed
+    // set of sample rays through it -- the kernel's walk with the nodes' boxes standing in for the shapes: cells
+    // visited, nodes tested, exit once two crossings lie before the end of the cells visited.  A wave waits for its
+    // slowest lane, so the price is the mean over the dearest quarter of the rays.
+    const int W = N > 64 ? 2 : 1;
+    auto file_nodes = [&](const int (&dims)[3], double (&cell)[3], std::vector<unsigned long long>& masks) {
+        for (int a = 0; a < 3; a++) cell[a] = (g->hi[a] - g->lo[a]) / dims[a];
+        masks.assign((size_t)dims[0] * dims[1] * dims[2] * W, 0ull);
+        for (int n = 0; n < N; n++) {
+            if (n == root) continue;
+            int c0[3], c1[3];
+            for (int a = 0; a < 3; a++) {   // cells touched, one cell more on either side when a face lies within m of a cell wall
+                c0[a] = (int)std::floor((blo[(size_t)n * 3 + a] - m - g->lo[a]) / cell[a]);
+                c1[a] = (int)std::floor((bhi[(size_t)n * 3 + a] + m - g->lo[a]) / cell[a]);
+                c0[a] = c0[a] < 0 ? 0 : c0[a];
+                c1[a] = c1[a] > dims[a] - 1 ? dims[a] - 1 : c1[a];
+            }
+            for (int z = c0[2]; z <= c1[2]; z++)
+                for (int y = c0[1]; y <= c1[1]; y++)
+                    for (int x = c0[0]; x <= c1[0]; x++)
+                        masks[(((size_t)z * dims[1] + y) * dims[0] + x) * W + (n >> 6)] |= 1ull << (n & 63);
+        }
+    };
+    // sample rays (fixed pseudo-random sequence: the same scene always gets the same grid): from inside a node's box,
+    // from a face of one, from anywhere in the grid's box; directions isotropic
+    struct Ray { double o[3], d[3]; };
+    std::vector<Ray> rays;
+    {
+        unsigned long long st = 0x9E3779B97F4A7C15ull;
+        auto uni = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
+        std::vector<int> others;
+        for (int n = 0; n < N; n++) if (n != root) others.push_back(n);
+        for (int k = 0; k < 384; k++) {
+            Ray r;
+            const int n = others[(size_t)(uni() * others.size()) % others.size()];
+            for (int a = 0; a < 3; a++) {
+                const double lo = k % 4 == 3 ? g->lo[a] : blo[(size_t)n * 3 + a], hi = k % 4 == 3 ? g->hi[a] : bhi[(size_t)n * 3 + a];
+                r.o[a] = lo + uni() * (hi - lo);
+            }
+            if (k % 4 == 2) { const int a = (int)(uni() * 3) % 3; r.o[a] = uni() < 0.5 ? blo[(size_t)n * 3 + a] + grow : bhi[(size_t)n * 3 + a] - grow; }
+            double z = 2.0 * uni() - 1.0, ph = 6.283185307179586 * uni(), s = std::sqrt(1.0 - z * z);
+            r.d[0] = s * std::cos(ph); r.d[1] = s * std::sin(ph); r.d[2] = z;
+            rays.push_back(r);
+        }
+    }
+    auto price = [&](const int (&dims)[3]) -> double {
+        double cell[3];
+        std::vector<unsigned long long> masks;
+        file_nodes(dims, cell, masks);
+        std::vector<double> cost;
+        for (const Ray& r : rays) {
+            double t_in = 0.0, t_out = INFINITY;
+            bool walk = true;
+            for (int a = 0; a < 3; a++) {
+                if (std::fabs(r.d[a]) < 1e-20) { if (r.o[a] < g->lo[a] || r.o[a] > g->hi[a]) walk = false; continue; }
+                const double ta = (g->lo[a] - r.o[a]) / r.d[a], tb = (g->hi[a] - r.o[a]) / r.d[a];
+                t_in = std::fmax(t_in, std::fmin(ta, tb)); t_out = std::fmin(t_out, std::fmax(ta, tb));
+            }
+            if (!(t_in <= t_out)) walk = false;
+            int c[3] = {0, 0, 0};
+            double tm[3] = {INFINITY, INFINITY, INFINITY};
+            for (int a = 0; a < 3 && walk; a++) {
+                c[a] = (int)((r.o[a] + r.d[a] * t_in - g->lo[a]) / cell[a]);
+                c[a] = c[a] < 0 ? 0 : (c[a] > dims[a] - 1 ? dims[a] - 1 : c[a]);
+                if (std::fabs(r.d[a]) >= 1e-20) tm[a] = (g->lo[a] + (c[a] + (r.d[a] < 0 ? 0 : 1)) * cell[a] - r.o[a]) / r.d[a];
+            }
+            unsigned long long seen[2] = {0ull, 0ull};
+            int cells = 0, tests = 0, nh = 0;
+            double t1 = INFINITY, t2 = INFINITY;
+            while (walk) {
+                cells += 1;
+                const unsigned long long* mk = &masks[(((size_t)c[2] * dims[1] + c[1]) * dims[0] + c[0]) * W];
+                for (int w = 0; w < W; w++) {
+                    unsigned long long fresh = mk[w] & ~seen[w];
+                    seen[w] |= mk[w];
+                    while (fresh) {
+                        const int n = w * 64 + __builtin_ctzll(fresh);
+                        fresh &= fresh - 1;
+                        tests += 1;
+                        double te = -INFINITY, tx = INFINITY;   // the ray against the node's box
+                        bool miss = false;
+                        for (int a = 0; a < 3; a++) {
+                            const double lo = blo[(size_t)n * 3 + a], hi = bhi[(size_t)n * 3 + a];
+                            if (std::fabs(r.d[a]) < 1e-20) { if (r.o[a] < lo || r.o[a] > hi) miss = true; continue; }
+                            const double ta = (lo - r.o[a]) / r.d[a], tb = (hi - r.o[a]) / r.d[a];
+                            te = std::fmax(te, std::fmin(ta, tb)); tx = std::fmin(tx, std::fmax(ta, tb));
+                        }
+                        if (miss || tx < te || !(tx > 0.0)) continue;
+                        const double ts[2] = {te, tx};
+                        for (int q = te > 0.0 ? 0 : 1; q < 2; q++) {
+                            if (ts[q] < t1) { t2 = t1; t1 = ts[q]; } else if (ts[q] < t2) t2 = ts[q];
+                            nh += 1;
+                        }
+                    }
+                }
+                const double t_cell = std::fmin(tm[0], std::fmin(tm[1], tm[2]));
+                const int ax = (tm[0] <= tm[1] && tm[0] <= tm[2]) ? 0 : (tm[1] <= tm[2] ? 1 : 2);
+                const int nxt = c[ax] + (r.d[ax] < 0 ? -1 : 1);
+                if ((nh >= 2 && t2 + m < t_cell) || !(t_cell < INFINITY) || nxt < 0 || nxt >= dims[ax]) break;
+                c[ax] = nxt;
+                tm[ax] += cell[ax] / std::fabs(r.d[ax]);
+            }
+            // a trip of the kernel's walk moves a lane on by one cell AND tests one node
+            cost.push_back((double)(cells > tests ? cells : tests) + 0.25 * (cells + tests));
+        }
+        std::sort(cost.begin(), cost.end());
+        double sum = 0.0;
+        const size_t from = cost.size() - cost.size() / 4;
+        for (size_t i = from; i < cost.size(); i++) sum += cost[i];
+        return sum / (double)(cost.size() - from);
+    };
     double ext[3], vol = 1.0;
     for (int a = 0; a < 3; a++) { ext[a] = g->hi[a] - g->lo[a]; vol *= ext[a]; }
-    double side = std::cbrt(vol / target);
-    for (int pass = 0; pass < 200; pass++) {
-        long long cells = 1;
-        for (int a = 0; a < 3; a++) {
-            g->n[a] = (int)std::fmin(64.0, std::fmax(1.0, std::floor(ext[a] / side + 0.5)));
-            cells *= g->n[a];
+    constexpr int kMaxCells = 512;   // 8 KB of masks in LDS at two words per cell
+    {   // start: about one cell per node, as cubic as the extent allows
+        double target = std::fmin((double)kMaxCells, std::fmax(8.0, 1.0 * (N - 1)));
+        if (const char* env = getenv("PVT_GRID_CELLS")) target = std::fmin(4096.0, std::fmax(1.0, atof(env)));
+        double side = std::cbrt(vol / target);
+        for (int pass = 0; pass < 200; pass++) {
+            long long cells = 1;
+            for (int a = 0; a < 3; a++) {
+                g->n[a] = (int)std::fmin(64.0, std::fmax(1.0, std::floor(ext[a] / side + 0.5)));
+                cells *= g->n[a];
+            }
+            if ((double)cells <= target * 1.25) break;
+            side *= 1.05;
         }
-        if ((double)cells <= target * 1.25) break;
-        side *= 1.05;
     }
-    g->words = N > 64 ? 2 : 1;
+    if (!getenv("PVT_GRID_CELLS") && !getenv("PVT_GRID_NO_TUNING")) {
+        double best = price(g->n);
+        for (int sweep = 0; sweep < 2; sweep++)
+            for (int a = 0; a < 3; a++) {
+                const int n0 = g->n[a];
+                int pick = n0;
+                for (int v = std::max(1, n0 / 2); v <= std::min(64, 2 * n0 + 1); v++) {
+                    if (v == n0) continue;
+                    int dims[3] = {g->n[0], g->n[1], g->n[2]};
+                    dims[a] = v;
+                    if ((long long)dims[0] * dims[1] * dims[2] > kMaxCells) break;
+                    const double p = price(dims);
+                    if (p < best * 0.98) { best = p; pick = v; }   // (a clear gain only: ties keep the coarser grid)
+                }
+                g->n[a] = pick;
+            }
+    }
+    g->words = W;
     g->guard = getenv("PVT_GRID_DEV_GUARD") ? -1e30 : m;
-    for (int a = 0; a < 3; a++) g->cell[a] = ext[a] / g->n[a];
-    g->masks.assign((size_t)g->n[0] * g->n[1] * g->n[2] * g->words, 0ull);
-    for (int n = 0; n < N; n++) {
-        if (n == root) continue;
-        int c0[3], c1[3];
-        for (int a = 0; a < 3; a++) {   // cells touched, one cell more on either side when a face lies within m of a cell wall
-            c0[a] = (int)std::floor((blo[(size_t)n * 3 + a] - m - g->lo[a]) / g->cell[a]);
-            c1[a] = (int)std::floor((bhi[(size_t)n * 3 + a] + m - g->lo[a]) / g->cell[a]);
-            c0[a] = c0[a] < 0 ? 0 : c0[a];
-            c1[a] = c1[a] > g->n[a] - 1 ? g->n[a] - 1 : c1[a];
-        }
-        for (int z = c0[2]; z <= c1[2]; z++)
-            for (int y = c0[1]; y <= c1[1]; y++)
-                for (int x = c0[0]; x <= c1[0]; x++)
-                    g->masks[(((size_t)z * g->n[1] + y) * g->n[0] + x) * g->words + (n >> 6)] |= 1ull << (n & 63);
-    }
+    file_nodes(g->n, g->cell, g->masks);
     return true;
 }
 

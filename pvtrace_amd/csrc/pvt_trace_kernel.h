@@ -1413,24 +1413,30 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             else tm2 = __builtin_fma(pvt_fabs(invw2), T.du(gb + 8), tm2);
                         }
                     };
-                    // Every lane at its own pace: a trip tests ONE node filed under the lane's current cell that the lane has
-                    // not tested yet, or -- none left -- moves the lane on to its next cell; after the walk, the root.
+                    // Every lane at its own pace.  A trip: a lane whose current cell holds nothing it has not tested moves on to
+                    // its next cell (or out of the walk); then it tests ONE node -- of the cell it is in now or, the walk
+                    // over, the root.  (Both halves run in every trip of a wave anyway, its lanes being at different points.)
                     bool root_todo = true;
+                    auto untested = [&](unsigned long long& m_lo, unsigned long long& m_hi) __attribute__((always_inline)) {
+                        const int at = gb + 14 + ci * words;
+                        m_lo = pvt_d2u(T.dv(at)) & ~seen_lo;
+                        m_hi = words > 1 ? pvt_d2u(T.dv(at + 1)) & ~seen_hi : 0ull;
+                    };
                     for (;;) {
                         if (__ballot(walk || root_todo) == 0ull) break;
+                        unsigned long long m_lo = 0ull, m_hi = 0ull;
+                        if (walk) {
+                            untested(m_lo, m_hi);
+                            if ((m_lo | m_hi) == 0ull) {
+                                next_cell();
+                                if (walk) untested(m_lo, m_hi);
+                            }
+                        }
                         bool test = false;
                         int node = A.root;
-                        if (walk) {
-                            const int at = gb + 14 + ci * words;
-                            const unsigned long long m_lo = pvt_d2u(T.dv(at)) & ~seen_lo;
-                            const unsigned long long m_hi = words > 1 ? pvt_d2u(T.dv(at + 1)) & ~seen_hi : 0ull;
-                            if (m_lo != 0ull) { node = __builtin_ctzll(m_lo); seen_lo |= m_lo & (0ull - m_lo); test = true; }
-                            else if (m_hi != 0ull) { node = 64 + __builtin_ctzll(m_hi); seen_hi |= m_hi & (0ull - m_hi); test = true; }
-                            else next_cell();
-                        } else if (root_todo) {
-                            root_todo = false;
-                            test = true;
-                        }
+                        if (m_lo != 0ull) { node = __builtin_ctzll(m_lo); seen_lo |= m_lo & (0ull - m_lo); test = true; }
+                        else if (m_hi != 0ull) { node = 64 + __builtin_ctzll(m_hi); seen_hi |= m_hi & (0ull - m_hi); test = true; }
+                        else if (!walk && root_todo) { root_todo = false; test = true; }
 #if PVT_STATS
                         st_g[0] += 1; st_g[1] += 1; st_g[2] += __popcll(__ballot(test)); st_g[3] += __popcll(__ballot(!test));
 #endif
