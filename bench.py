@@ -300,7 +300,7 @@ def main():
             self.scene = spec["build"]()
             self.compiled = compile_scene(self.scene)
             self.method = EMIT_METHODS[spec["emit_method"]]
-            self.array_input = name == "cfg2"
+            self.array_input = name == "cfg2" or os.environ.get("PVT_BENCH_ARRAY_INPUT") == "1"   # (developer A/B)
             self.ray_sets, self.host_rays = [None], None
             if self.array_input:
                 # each rank's shard: global indices [rank*n, (rank+1)*n); emission seeded per shard and per

@@ -119,6 +119,9 @@ struct PvtScene {
         long long bound = 0;       // at most this many
     };
     std::vector<Carry> carry;
+    // device emission: per stream slot, [7][64] doubles per wave of the launch (KArgs::emit_pool), grown on demand
+    std::vector<double*> emit_pool;
+    std::vector<size_t> emit_pool_bytes;
     unsigned int carry_cap = 0;    // photons one buffer holds (a launch of more lanes than that does not park)
     int num_cu = 0;
     int last_grid = 0, last_lds = 0;
@@ -932,6 +935,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     } owner{new PvtScene()};
     PvtScene* s = owner.p;
     s->stage.reserve(kCursorSlots); s->stage_bytes.reserve(kCursorSlots); s->carry.reserve(kCursorSlots);   // (references stay valid)
+    s->emit_pool.reserve(kCursorSlots); s->emit_pool_bytes.reserve(kCursorSlots);
     s->device = device;
     s->lay = lay;
     s->nd = (int)gd.size();
@@ -1022,6 +1026,7 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_tris) (void)hipFree(s->d_tris);
     for (auto* b : s->stage) if (b) (void)hipFree(b);
     for (auto& c : s->carry) for (auto* b : c.buf) if (b) (void)hipFree(b);
+    for (auto* b : s->emit_pool) if (b) (void)hipFree(b);
     delete s;
 }
 
@@ -1105,6 +1110,8 @@ int slot_of_stream(PvtScene* s, hipStream_t st) {
         s->stage.push_back(nullptr);
         s->stage_bytes.push_back(0);
         s->carry.emplace_back();
+        s->emit_pool.push_back(nullptr);
+        s->emit_pool_bytes.push_back(0);
     }
     return (int)slot;
 }
@@ -1255,6 +1262,18 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     }
 #endif
     const bool emit = rays == nullptr && s->d_ed != nullptr;
+    if (emit) {
+        const size_t need = (size_t)grid * kWaves * 7 * 64 * sizeof(double);
+        if (s->emit_pool_bytes[(size_t)slot] < need) {
+            // (growth is rare -- the grid of a stream's launches is stable -- and the launch before this one on the stream may
+            // still be reading the old buffer)
+            if (s->emit_pool[(size_t)slot]) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(s->emit_pool[(size_t)slot]); s->emit_pool[(size_t)slot] = nullptr; s->emit_pool_bytes[(size_t)slot] = 0; }
+            const size_t bytes = need < ((size_t)s->num_cu * 4 * kWaves * 7 * 64 * sizeof(double)) ? (size_t)s->num_cu * 4 * kWaves * 7 * 64 * sizeof(double) : need;
+            HIP_TRY(hipMalloc(&s->emit_pool[(size_t)slot], bytes));
+            s->emit_pool_bytes[(size_t)slot] = bytes;
+        }
+        a.emit_pool = s->emit_pool[(size_t)slot];
+    }
     hipError_t e;
     if (record) {
         e = tab_lds ? launch_seen<true, true>(s->n_rec, emit, (int)grid, lds, st, a)

@@ -176,6 +176,10 @@ struct KArgs {
     unsigned int carry_cap;
     int carry_flags;   // 1: resume parked photons first   2: park at exhaustion
     unsigned long long* timeline;   // (PVT_TIMELINE builds) 8 words per wave
+    // Device emission (EMIT variants): a wave samples the 64 rays of a chunk when it CLAIMS the chunk -- every lane busy,
+    // and the sampler's code (a fifth of the kernel's text) out of the step loop -- and parks them in its own
+    // [7][64] doubles here (position, direction, wavelength; global memory, L2-resident); refilled lanes read theirs.
+    double* emit_pool;
 };
 constexpr int kCarryBase = 14;     // u64 words of a parked photon before its seen-mask
 constexpr int kCarryStride = 18;   // words per parked photon (room for the four-word mask of scenes with > 64 recorders)
@@ -1003,6 +1007,25 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 }
                 w_next = b;
                 w_end = (w_claim_end - b < (unsigned int)kChunk) ? w_claim_end : b + kChunk;
+                w_base = b;
+                if constexpr (EMIT) {
+                    // sample the whole chunk now (see KArgs::emit_pool); the stores are read back by lanes of this very
+                    // wave, later in program order
+                    const __attribute__((address_space(4))) KArgs* ak =
+                        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ak));
+                    unsigned int lane_here = (unsigned int)lane;
+                    asm volatile("" : "+v"(lane_here));
+                    if (b + lane_here < w_end) {
+                        V3 ep, ed;
+                        double ew;
+                        emit_one(A, A.ray_offset + (unsigned long long)ray_lo + (unsigned long long)b + (unsigned long long)lane_here, ep, ed, ew);
+                        double* pool = ak->emit_pool + ((unsigned long long)blockIdx.x * kWaves + (unsigned long long)wave) * (7 * 64) + lane_here;
+                        pool[0] = ep.x; pool[64] = ep.y; pool[128] = ep.z;
+                        pool[192] = ed.x; pool[256] = ed.y; pool[320] = ed.z;
+                        pool[384] = ew;
+                    }
+                }
                 if (seed_pool) {
                     // Seed the whole chunk NOW, with every lane busy, instead of inside each later
                     // refill with only the dead lanes active (8 64-bit multiplies per seed): lane l
@@ -1017,7 +1040,6 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         xbuf[pool_at + k * 64 + lane] = splitmix64(st);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    w_base = b;
                 }
             }
             unsigned int avail = w_end - w_next;
@@ -1027,7 +1049,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 const unsigned int il = w_next + rank;   // index within the set
                 const unsigned int i = ray_lo + il;      // index within the launch
                 if constexpr (EMIT) {
-                    emit_one(A, A.ray_offset + i, pos, dir, wl);
+                    const __attribute__((address_space(4))) KArgs* ak =
+                        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ak));
+                    const double* pool = ak->emit_pool + ((unsigned long long)blockIdx.x * kWaves + (unsigned long long)wave) * (7 * 64) + (il - w_base);
+                    pos = V3{pool[0], pool[64], pool[128]};
+                    dir = V3{pool[192], pool[256], pool[320]};
+                    wl = pool[384];
                 } else {
                     // The three ray pointers are read from the kernel-argument segment HERE, through a pointer
                     // the compiler cannot trace back to it: kept as loop invariants they would sit in six
