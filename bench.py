@@ -137,6 +137,9 @@ def parse_args():
     ap.add_argument("--config", default="cfg2",
                     help="scene of the main loop (developer flag for profiles; the contract's metric is cfg2). "
                          "cfg4/cfg5 use device-side emission")
+    ap.add_argument("--scene-sizes", default="1,3,6,11",
+                    help="tile-array sizes k of the scene-size leg (k x k slabs of the headline LSC in one world, k*k + 1 "
+                         "nodes; benchmarks/configs.py tiles<k>); 'none' = skip")
     ap.add_argument("--extra-configs", default="cfg4,cfg5",
                     help="comma list of further configs timed after the cfg2 legs ('none' = skip)")
     ap.add_argument("--config-photons", type=int, default=10_000_000,
@@ -177,6 +180,9 @@ def load_pmc(name, value_per_gpu, cus):
         summary = json.load(open(path))
         derived = summary.get("derived", {})
         side = {
+            # counters come from committed rocprofv3 passes of this same command (rocprofv3 serialises dispatches while
+            # it samples, so they cannot be taken in the timed run); only the photon rate they are scaled by is measured here
+            "measured_in_this_run": False,
             "source": os.path.relpath(path, ROOT) + " (" + str(summary.get("stage", "")) + ")",
             "valu_wave_instructions_per_photon": derived.get("valu_wave_instructions_per_photon"),
             "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
@@ -478,6 +484,32 @@ def main():
         }
         other.close()
 
+    # ------------------------------------------------------------------ scene size: photons/s against the node count
+    scaling = None
+    sizes = ([int(k) for k in args.scene_sizes.split(",") if k and k != "none"]
+             if args.config == "cfg2" and args.extra_configs != "none" else [])   # ('--extra-configs none': the main config only)
+    if sizes:
+        scaling = {"what": "k x k tile arrays of the headline slab in one world (benchmarks/configs.py: tiles_lsc), device "
+                           "emission, same pipeline as the other configs; the reference intersects every node in every step "
+                           "(_kernel.pyx:666-680), this engine walks a node grid from 8 nodes on (DESIGN.md)",
+                   "photons_per_gpu_per_window": n * 10, "sizes": {}}
+        for k in sizes:
+            name = f"tiles{k}"
+            other = Leg(name, n)
+            other.spin_up(min(args.spinup_s, 0.1), 2)
+            dts = sorted(other.window(100 + w * 10, 10) for w in range(3))
+            v = n * world * 10 / dts[1]
+            sus_steps = max(10, int(1.0 / (dts[1] / 10)))
+            dt = other.window(100_000, sus_steps)
+            _, side = load_pmc(name, v / world, cus)
+            scaling["sizes"][name] = {
+                "nodes": k * k + 1, "value": v, "sustained": n * world * sus_steps / dt, "unit": "photons/s",
+                "launch": other.dscene.launch_info(), "node_grid": native.node_grid_plan(other.compiled) is not None,
+                "valu_wave_instructions_per_photon": (side or {}).get("valu_wave_instructions_per_photon"),
+                "valu_lane_utilisation": (side or {}).get("valu_lane_utilisation"),
+            }
+            other.close()
+
     if rank == 0:
         achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9 if leg.array_input else 0.0
         traffic, instruction_side = load_pmc(args.config, value / world, cus)
@@ -537,6 +569,8 @@ def main():
             out["strong_scaling"] = strong
         if extra:
             out["configs"] = extra
+        if scaling:
+            out["scene_scaling"] = scaling
         if not args.no_cpu_baseline and world == 1 and leg.array_input:   # the CPU referee is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(leg.compiled, *leg.host_rays)
         print(json.dumps(out), flush=True)

@@ -209,7 +209,11 @@ enum {
      * every launch, where a few long histories keep a few lanes busy (a fifth of all wave-iterations of a 10^6-
      * photon launch of the headline scene).  A launch WITHOUT the flag finishes everything, what it resumed
      * included; with n_rays == 0 it is the closing flush of a job.  pvt_scene_carry_pending() tells whether
-     * photons are waiting.  (The reference has no counterpart: its bundles end when their slowest ray ends.) */
+     * photons are waiting.  The resuming launch must ask for the maxsteps / emit_method of the launch that parked
+     * them (PVT_ERR_INVALID otherwise: the photons would silently change rules) and is never narrower than it (the
+     * library widens its grid if need be); pvt_scene_carry_discard() drops parked photons of a job that was
+     * abandoned.  The host-buffer entries (pvt_trace_bundle, pvt_trace_bundle_multi) ignore the flag: their scene
+     * lives for one call.  (The reference has no counterpart: its bundles end when their slowest ray ends.) */
     PVT_FLAG_CARRY_OUT = 2
 };
 
@@ -283,6 +287,10 @@ void pvt_scene_destroy(PvtScene* scene);
  * Asynchronous: returns after enqueueing. */
 int pvt_trace_device(PvtScene* scene, const PvtRays* rays, const PvtTraceParams* params,
                      const PvtTallies* tallies, const PvtEventLog* log, void* stream);
+/* (With column arrays the kernel's 128-byte event records are staged in a buffer of the scene, one per stream that
+ * asked for it, at most 1 GiB -- larger logs are traced over consecutive ray ranges, same results -- kept until
+ * the scene is destroyed: device memory on top of the caller's 117 bytes per row.  pvt_trace_device_records has no
+ * such buffer.) */
 
 /* Same launch, the event log kept as RECORDS in caller-owned DEVICE memory (no staging, no unpack pass):
  * what a caller wants who reads only the rows that were written (the Python engine.simulate() does).
@@ -292,6 +300,9 @@ int pvt_trace_device_records(PvtScene* scene, const PvtRays* rays, const PvtTrac
 
 /* 1 when photons parked by the last launch on `stream` (PVT_FLAG_CARRY_OUT) wait to be resumed, else 0. */
 int pvt_scene_carry_pending(PvtScene* scene, void* stream);
+/* Forget the photons parked on `stream` (a job abandoned half-way: an exception between two bundles, a consumer that
+ * went away).  The next launch on the stream then starts from its own rays alone. */
+int pvt_scene_carry_discard(PvtScene* scene, void* stream);
 
 /* Records -> column arrays (all DEVICE pointers), one coalesced pass; `prefill` != 0 also writes the
  * reference's fill values (0 / -1) into the rows no event reached, else those rows are left alone.

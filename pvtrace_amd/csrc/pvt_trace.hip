@@ -108,7 +108,7 @@ struct PvtScene {
     // stream slot, grown on demand, at most `stage_limit` bytes: larger logs are traced in several launches)
     std::vector<unsigned long long*> stage;
     std::vector<size_t> stage_bytes;
-    size_t stage_limit = (size_t)8 << 30;
+    size_t stage_limit = (size_t)1 << 30;
     // photons carried from launch to launch of a stream (PVT_FLAG_CARRY_OUT; see KArgs::carry_in): per stream slot
     // two buffers (the launch that resumes one may park into the other) and which of them holds parked photons
     struct Carry {
@@ -117,6 +117,7 @@ struct PvtScene {
         int phase = 0;             // ... and uses cursor block `phase` of the slot's three (see trace_launch)
         bool pending = false;      // buf[parity ^ 1] holds photons parked by the previous launch
         long long bound = 0;       // at most this many
+        int maxsteps = 0, emit_method = 0;   // ... under these rules: the launch that resumes them must trace by the same
     };
     std::vector<Carry> carry;
     // device emission: per stream slot, [7][64] doubles per wave of the launch (KArgs::emit_pool), grown on demand
@@ -1141,6 +1142,12 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     if (carry_in && (p->record_every > 0 || p->tally_bundle > 0))
         return fail(PVT_ERR_INVALID, "photons parked by the previous launch on this stream (PVT_FLAG_CARRY_OUT) are waiting: "
                                      "finish them with a plain tally launch (n_rays may be 0) first");
+    if (carry_in && (p->maxsteps != carry.maxsteps || p->emit_method != carry.emit_method))
+        return fail(PVT_ERR_INVALID, "photons parked by the previous launch on this stream were traced with maxsteps " +
+                                     std::to_string(carry.maxsteps) + ", emit_method " + std::to_string(carry.emit_method) +
+                                     "; this launch asks for " + std::to_string(p->maxsteps) + ", " + std::to_string(p->emit_method) +
+                                     ": finish them under their own rules first (a launch with n_rays = 0 and the old values), or drop "
+                                     "them with pvt_scene_carry_discard");
     long long n_sets = 0;
     if (p->tally_bundle > 0) {
         n_sets = (p->n_rays + p->tally_bundle - 1) / p->tally_bundle;
@@ -1219,6 +1226,10 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     long long grid = (long long)((double)s->num_cu * per_cu);
     if (grid > blocks_for_rays) grid = blocks_for_rays;
     if (grid < 1) grid = 1;
+    // Every wave resumes the slice of the parked photons that its index names (64 per wave, the kernel's refill); the
+    // launch that parked them put at most 64 per wave of ITS grid: this launch must not be narrower, or slices beyond
+    // its last wave would depend on the claim cursor being asked often enough (workgroups_per_cu 4, then 1)
+    if (carry_in && grid * kBlock < carry.bound) grid = (carry.bound + kBlock - 1) / kBlock;
     if (n_sets) {   // a workgroup serves one set: the same total, split evenly over the sets
         long long per_set = grid / n_sets;
         const long long for_rays = (p->tally_bundle + kBlock - 1) / kBlock;
@@ -1287,6 +1298,8 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     if (carry_in || carry_out) {
         carry.pending = carry_out;
         carry.bound = carry_out ? grid * kBlock : 0;
+        carry.maxsteps = p->maxsteps;
+        carry.emit_method = p->emit_method;
         carry.parity ^= 1;
     }
 #if PVT_STATS
@@ -1364,6 +1377,19 @@ int pvt_scene_carry_pending(PvtScene* s, void* stream) {
     for (size_t k = 0; k < s->slot_of.size(); k++)
         if (s->slot_of[k] == reinterpret_cast<hipStream_t>(stream)) return s->carry[k].pending ? 1 : 0;
     return 0;
+}
+
+int pvt_scene_carry_discard(PvtScene* s, void* stream) {
+    if (!s) return fail(PVT_ERR_INVALID, "null scene");
+    std::lock_guard<std::mutex> lock(s->slot_mutex);
+    for (size_t k = 0; k < s->slot_of.size(); k++)
+        if (s->slot_of[k] == reinterpret_cast<hipStream_t>(stream)) {
+            // the parked photons are simply forgotten: the next launch on the stream starts from its own rays (the cursor
+            // blocks keep rotating; the count the abandoned launch left behind is never read)
+            s->carry[k].pending = false;
+            s->carry[k].bound = 0;
+        }
+    return PVT_OK;
 }
 
 int pvt_unpack_records_device(const PvtEventRecords* rec, int64_t n_recorded, int32_t max_events,
@@ -1542,39 +1568,46 @@ thread_local int g_last_multi_reduce = 0;   // 0 none yet, 1 host sum, 2 RCCL on
 
 // RCCL, loaded at run time (no link dependency: a process that already holds an RCCL -- PyTorch's -- keeps using
 // that copy): ncclReduce of `counts[k]` elements of bufs[k][r] (rank r = entry r of `devs`) into rank 0, all in
-// one group.  false + `why` when the library or a call is unavailable; the caller then sums on the host.
-bool rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*> (&bufs)[4], const size_t (&counts)[4],
-                          const bool (&is_f64)[4], std::string* why) {
+// one group.
+// Returns 0 = summed on the devices, 1 = RCCL unavailable (nothing enqueued: the caller may sum on the host),
+// 2 = a call failed AFTER reduces had been enqueued (shard 0's buffers may hold partial sums: an error, no fall-back).
+// Communicators are kept per device list (ncclCommInitAll costs far more than reducing a few KB).
+int rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*> (&bufs)[4], const size_t (&counts)[4],
+                         const bool (&is_f64)[4], std::string* why) {
     typedef int (*InitAll)(void**, int, const int*);
     typedef int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
     typedef int (*Void)();
-    typedef int (*Destroy)(void*);
     static void* lib = nullptr;
     static InitAll init_all = nullptr; static Reduce reduce = nullptr; static Void group_start = nullptr, group_end = nullptr;
-    static Destroy destroy = nullptr;
+    static std::vector<std::pair<std::vector<int>, std::vector<void*>>> comm_cache;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     if (!lib) {
         const char* names[] = {getenv("PVT_RCCL_LIB"), "librccl.so", "librccl.so.1"};
         for (const char* nm : names) if (nm && !lib) lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // a copy already mapped
         for (const char* nm : names) if (nm && !lib) lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) { *why = std::string("dlopen(librccl): ") + dlerror(); return false; }
+        if (!lib) { *why = std::string("dlopen(librccl): ") + dlerror(); return 1; }
         init_all = (InitAll)dlsym(lib, "ncclCommInitAll"); reduce = (Reduce)dlsym(lib, "ncclReduce");
         group_start = (Void)dlsym(lib, "ncclGroupStart"); group_end = (Void)dlsym(lib, "ncclGroupEnd");
-        destroy = (Destroy)dlsym(lib, "ncclCommDestroy");
     }
-    if (!init_all || !reduce || !group_start || !group_end || !destroy) { *why = "RCCL symbols missing"; return false; }
+    if (!init_all || !reduce || !group_start || !group_end) { *why = "RCCL symbols missing"; return 1; }
     const int n = (int)devs.size();
-    std::vector<void*> comms((size_t)n, nullptr);
-    if (int e = init_all(comms.data(), n, devs.data())) { *why = "ncclCommInitAll failed with " + std::to_string(e); return false; }
-    bool ok = true;
+    std::vector<void*>* comms = nullptr;
+    for (auto& entry : comm_cache) if (entry.first == devs) comms = &entry.second;
+    if (!comms) {
+        std::vector<void*> fresh((size_t)n, nullptr);
+        if (int e = init_all(fresh.data(), n, devs.data())) { *why = "ncclCommInitAll failed with " + std::to_string(e); return 1; }
+        comm_cache.emplace_back(devs, fresh);   // (kept for the life of the process)
+        comms = &comm_cache.back().second;
+    }
     constexpr int kInt64 = 4, kFloat64 = 8, kSum = 0;   // rccl.h: ncclInt64, ncclFloat64, ncclSum
-    if (group_start()) ok = false;
+    if (group_start()) { *why = "ncclGroupStart failed"; return 1; }
+    bool ok = true;
     for (int k = 0; k < 4 && ok; k++) {
         if (!counts[k]) continue;
         for (int r = 0; r < n && ok; r++) {
             (void)hipSetDevice(devs[(size_t)r]);
-            if (reduce(bufs[k][(size_t)r], bufs[k][(size_t)r], counts[k], is_f64[k] ? kFloat64 : kInt64, kSum, 0, comms[(size_t)r], nullptr)) ok = false;
+            if (reduce(bufs[k][(size_t)r], bufs[k][(size_t)r], counts[k], is_f64[k] ? kFloat64 : kInt64, kSum, 0, (*comms)[(size_t)r], nullptr)) ok = false;
         }
     }
     if (group_end()) ok = false;
@@ -1582,9 +1615,8 @@ bool rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*>
         (void)hipSetDevice(devs[(size_t)r]);
         if (hipStreamSynchronize(nullptr) != hipSuccess) ok = false;
     }
-    for (void* c : comms) if (c) destroy(c);
-    if (!ok) *why = "an RCCL call failed";
-    return ok;
+    if (!ok) { *why = "an RCCL call failed after reduces had been enqueued"; return 2; }
+    return 0;
 }
 
 // One host-buffer bundle on one device, in phases (pvt_trace_bundle runs them back to back; pvt_trace_bundle_multi
@@ -1624,6 +1656,7 @@ struct HostBundle {
               const PvtTallies* seed, bool want_log, int device) {
         tables = tb;
         params = *pp;
+        params.flags &= ~(int64_t)PVT_FLAG_CARRY_OUT;   // a scene that lives for one call has no next launch to carry photons to
         int rc = pvt_scene_create(tables, device, &scene);
         if (rc != PVT_OK) return rc;
         if (emitter) {
@@ -1854,8 +1887,11 @@ int pvt_trace_bundle_multi(const PvtSceneTables* tables, const PvtEmitterTables*
             const size_t counts[4] = {nR, nR, nB, nR * 8};
             const bool is_f64[4] = {false, false, false, true};
             std::string why;
-            on_device = rccl_reduce_to_first(devs, bufs, counts, is_f64, &why);
-            if (!on_device && force_rccl) rc = fail(PVT_ERR_HIP, "RCCL reduce requested (PVT_MULTI_REDUCE=rccl) but unavailable: " + why);
+            const int how_it_went = rccl_reduce_to_first(devs, bufs, counts, is_f64, &why);
+            on_device = how_it_went == 0;
+            if (how_it_went == 2) rc = fail(PVT_ERR_HIP, "summing the shards' tallies with RCCL failed midway (" + why + "); the first shard's buffers "
+                                                        "may hold partial sums, so nothing is returned");
+            else if (!on_device && force_rccl) rc = fail(PVT_ERR_HIP, "RCCL reduce requested (PVT_MULTI_REDUCE=rccl) but unavailable: " + why);
         }
     }
     g_last_multi_reduce = on_device ? 2 : 1;

@@ -33,7 +33,7 @@ def _host_outputs(compiled, n_rays, record_every, max_events):
 
 def trace_bundle(compiled, positions, directions, wavelengths, seed, maxsteps, max_events,
                  emit_method, num_threads, record_every, *, device=0, devices=None, ray_offset=0,
-                 emitter=None, emit_seed=0, timing=None):
+                 emitter=None, emit_seed=0, timing=None, flags=0):
     """Trace a bundle on the GPU; returns the reference's result dict.
 
     `num_threads` is accepted for signature compatibility and ignored.  With
@@ -66,7 +66,7 @@ def trace_bundle(compiled, positions, directions, wavelengths, seed, maxsteps, m
     for name, _, _ in N.EVENT_LOG_COLUMNS:
         setattr(el, name, N.np_ptr(out[name]))
     params = N.trace_params(n, seed, ray_offset, emit_seed, record_every, maxsteps, max_events,
-                            emit_method)
+                            emit_method, flags=flags)
     ms = C.c_double(0.0)
     if devices is None:
         code = lib.pvt_trace_bundle(C.byref(st), em_ref, rays_ref, C.byref(params), C.byref(tl),

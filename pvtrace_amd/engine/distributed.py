@@ -18,8 +18,8 @@ traces rays with seeds seed + traced + i" (api.py:249-264).  Both map directly:
 * sampled event logs stay on the rank that traced them; shard boundaries are multiples of
   `record_every`, so together they are the single-process log.
 
-`backend="nccl"` is RCCL on ROCm.  The CPU tests run the same code path with
-gloo and an injected tracer.
+`backend="nccl"` is RCCL on ROCm.  The CPU tests run the sharding and the reduction
+(`run_sharded`) with gloo around a trace of their own.
 """
 import time
 
@@ -67,9 +67,32 @@ def all_reduce_tallies(tallies, group=None):
     return tallies
 
 
+def run_sharded(scene, num_rays, max_events, record_every, group, trace_shard):
+    """What every rank of a sharded job does around its own trace: take the index range of the rank, trace it
+    (`trace_shard(compiled, start, stop) -> (tallies, finish)`: `tallies` holds torch tensors -- on whatever device
+    the group's backend reduces -- and `finish(tallies) -> data` turns the reduced tallies and the rank's event log into
+    the reference's `data` dict), sum the tallies over the ranks, wrap the result.  `simulate_sharded` passes the
+    GPU trace; anything that produces the same arrays shards and reduces the same way."""
+    import torch.distributed as dist
+
+    from pvtrace_amd.engine import emit as emit_mod
+    from pvtrace_amd.engine.api import EngineResult
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    start, stop = shard_range(num_rays, rank, world, align=record_every)
+    compiled = compile_scene(scene)
+    sources = emit_mod.sources_for(scene, num_rays)[start:stop]
+    tic = time.perf_counter()
+    tallies, finish = trace_shard(compiled, start, stop)
+    all_reduce_tallies(tallies, group=group)
+    data = finish(tallies)
+    result = EngineResult(compiled, data, sources, max_events, record_every, time.perf_counter() - tic)
+    result.shard = (start, stop)
+    return result
+
+
 def simulate_sharded(scene, num_rays, seed, emit_seed=0, maxsteps=1000, max_events=128,
-                     emit_method="kT", record_every=0, device=None, group=None, tracer=None,
-                     rays=None):
+                     emit_method="kT", record_every=0, device=None, group=None, rays=None):
     """Trace this rank's shard of a `num_rays` job and all-reduce the tallies.
 
     Must be called by every rank of an initialised torch.distributed group.
@@ -79,74 +102,44 @@ def simulate_sharded(scene, num_rays, seed, emit_seed=0, maxsteps=1000, max_even
 
     Returns an `EngineResult` whose recorder tallies are GLOBAL and whose event
     log (if any) covers the local shard; `.shard` = (start, stop).
-
-    `tracer` (tests only) replaces the GPU: ``tracer(compiled, pos, dirs, wl,
-    seed, ray_offset, maxsteps, max_events, emit_method, record_every) -> data``.
     """
     import torch
-    import torch.distributed as dist
 
     from pvtrace_amd.engine import emit as emit_mod
-    from pvtrace_amd.engine.api import EngineResult, _default_device, download
+    from pvtrace_amd.engine.api import _default_device, download
 
     if emit_method not in EMIT_METHODS:
         raise ValueError(f"emit_method must be one of {sorted(EMIT_METHODS)}")
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    start, stop = shard_range(num_rays, rank, world, align=record_every)
-    n_local = stop - start
-    compiled = compile_scene(scene)
-    sources = emit_mod.sources_for(scene, num_rays)[start:stop]
-
-    if tracer is not None:
-        # CPU plumbing path (gloo): same sharding + reduction, injected tracer
-        if rays is None:
-            raise ValueError("the injected-tracer path needs explicit rays")
-        pos, dirs, wl = (np.asarray(a)[start:stop] for a in rays)
-        tic = time.perf_counter()
-        data = tracer(compiled, pos, dirs, wl, seed, start, maxsteps, max_events,
-                      EMIT_METHODS[emit_method], record_every)
-        tallies = {k: torch.from_numpy(np.ascontiguousarray(data[k]).reshape(-1).copy())
-                   for k in ("rec_distinct", "rec_crossings", "rec_sums", "rec_bins")}
-        all_reduce_tallies(tallies, group=group)
-        nrec = int(compiled.rec_node.shape[0])
-        data = dict(data)
-        data["rec_distinct"] = tallies["rec_distinct"].numpy()
-        data["rec_crossings"] = tallies["rec_crossings"].numpy()
-        data["rec_sums"] = tallies["rec_sums"].numpy().reshape(nrec, 4, 2)
-        data["rec_bins"] = tallies["rec_bins"].numpy()
-        result = EngineResult(compiled, data, sources, max_events, record_every,
-                              time.perf_counter() - tic)
-        result.shard = (start, stop)
-        return result
-
     if device is None:
         device = _default_device()
-    emitter = emit_mod.EmitterTables(scene, strict=True) if rays is None else None
-    dscene = native.DeviceScene(compiled, device=device, emitter=emitter)
+    opened = []
+
+    def trace_shard(compiled, start, stop):
+        n_local = stop - start
+        emitter = emit_mod.EmitterTables(scene, strict=True) if rays is None else None
+        dscene = native.DeviceScene(compiled, device=device, emitter=emitter)
+        opened.append(dscene)
+        dev = torch.device("cuda", device)
+        dev_rays = None
+        if rays is not None:
+            dev_rays = tuple(torch.from_numpy(np.ascontiguousarray(np.asarray(a)[start:stop])).to(dev) for a in rays)
+        tallies = dscene.new_tallies()
+        log = (dscene.new_event_log(n_local, record_every, max_events) if record_every > 0 and n_local > 0 else None)
+        if n_local > 0:
+            dscene.trace(dev_rays, n_local, int(seed), tallies, log=log, ray_offset=start,
+                         emit_seed=int(emit_seed), record_every=int(record_every),
+                         maxsteps=int(maxsteps), max_events=int(max_events),
+                         emit_method=EMIT_METHODS[emit_method])
+
+        def finish(reduced):
+            torch.cuda.synchronize(device)
+            return download(compiled, reduced, log, n_local, record_every, max_events)
+
+        return tallies, finish
+
     try:
         with torch.cuda.device(device):
-            dev = torch.device("cuda", device)
-            dev_rays = None
-            if rays is not None:
-                dev_rays = tuple(
-                    torch.from_numpy(np.ascontiguousarray(np.asarray(a)[start:stop])).to(dev)
-                    for a in rays)
-            tallies = dscene.new_tallies()
-            log = (dscene.new_event_log(n_local, record_every, max_events)
-                   if record_every > 0 and n_local > 0 else None)
-            torch.cuda.synchronize(device)
-            tic = time.perf_counter()
-            if n_local > 0:
-                dscene.trace(dev_rays, n_local, int(seed), tallies, log=log, ray_offset=start,
-                             emit_seed=int(emit_seed), record_every=int(record_every),
-                             maxsteps=int(maxsteps), max_events=int(max_events),
-                             emit_method=EMIT_METHODS[emit_method])
-            all_reduce_tallies(tallies, group=group)
-            torch.cuda.synchronize(device)
-            elapsed = time.perf_counter() - tic
-            data = download(compiled, tallies, log, n_local, record_every, max_events)
+            return run_sharded(scene, num_rays, max_events, record_every, group, trace_shard)
     finally:
-        dscene.close()
-    result = EngineResult(compiled, data, sources, max_events, record_every, elapsed)
-    result.shard = (start, stop)
-    return result
+        for dscene in opened:
+            dscene.close()

@@ -53,6 +53,12 @@ class BundlePipeline:
         if os.environ.get("PVT_PIPE_WGS"):   # developer sweep
             self.workgroups_per_cu = int(os.environ["PVT_PIPE_WGS"])
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        # torch hands out streams from a small pool and a resident scene outlives a pipeline: photons an ABANDONED
+        # pipeline left parked on one of these stream handles (an exception between two bundles, an object simply
+        # dropped) belong to a dead job and must not be resumed into this one
+        for s_ in self.streams:
+            if dscene.carry_pending(s_.cuda_stream):
+                dscene.carry_discard(s_.cuda_stream)
         self.slots = [dscene.new_tallies() for _ in range(self.depth)]
         # The kernel ADDS its tallies with atomics (one per non-zero slot per workgroup), so the launches of every
         # stream can add into ONE running total: nothing to fold when the totals are read (the fold was eight tiny
@@ -78,6 +84,11 @@ class BundlePipeline:
         if self._reduced and self.distributed and self.reduce == "end":
             raise RuntimeError("totals already reduced over the ranks; call reset_totals() before submitting more bundles")
         k = self.submitted % self.depth
+        if k in self._parked and self._parked[k] != (maxsteps, max_events, emit_method):
+            raise ValueError(
+                f"bundle traced with (maxsteps, max_events, emit_method) = {(maxsteps, max_events, emit_method)} while photons "
+                f"parked on its stream were traced with {self._parked[k]}: the bundles of a pipeline are parts of one job; "
+                "call reduce_totals() / reset_totals() (they finish what is parked) before changing the rules")
         self.submitted += 1
         stream, tallies, total = self.streams[k], self.slots[k], self.totals[k]
         if k in self._unordered:
@@ -144,6 +155,28 @@ class BundlePipeline:
                                   max_events=max_events, emit_method=emit_method, stream=stream.cuda_stream,
                                   workgroups_per_cu=4, carry_out=False)
         self._parked = {}
+
+    def close(self):
+        """Drop what an unfinished job left parked on the pipeline's streams (nothing is traced)."""
+        for k in list(self._parked):
+            try:
+                self.dscene.carry_discard(self.streams[k].cuda_stream)
+            except Exception:   # noqa: BLE001 -- the scene may be gone already
+                pass
+        self._parked = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def reset_totals(self):
         self.finish_parked()      # photons of earlier bundles must not be tallied into what follows

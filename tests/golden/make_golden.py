@@ -183,16 +183,21 @@ TALLY_SCENES = {
     "nested_cylinders": dict(scene="nested_cylinders", emit_seed=4104, seed=5, emit_method=0),
     "hello_world": dict(scene="hello_world_recorded", emit_seed=4105, seed=6, emit_method=0),
     "bench_slab": dict(scene="bench_slab_recorded", emit_seed=4106, seed=7, emit_method=1),
+    # the scene-size family: 6 x 6 tiles of the headline slab, 37 nodes -- on the GPU this is the
+    # node-grid path, in the reference the loop over every node (_kernel.pyx:666-680)
+    "tiles6": dict(scene="tiles6", emit_seed=4107, seed=8, emit_method=0),
 }
 
 
-def make_config_tallies():
+def make_config_tallies(only=()):
     from oracle import oracle as O
     from pvtrace_amd.engine import compile_scene
     from pvtrace_amd.engine.emit import emit_bundle
     from tests import scenes
 
     for name, spec in TALLY_SCENES.items():
+        if only and name not in only:
+            continue
         scene = scenes.TALLY_SCENES[spec["scene"]]()
         compiled = compile_scene(scene)
         n = 1_000_000
@@ -223,6 +228,9 @@ def make_hist_spectra():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
+    if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
+        make_config_tallies(only=sys.argv[2:])
+        sys.exit(0)
     make_spectra()
     make_optics()
     make_geometry()

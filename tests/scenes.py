@@ -451,10 +451,19 @@ def hello_world_recorded():
     return scene
 
 
+def tiles6():
+    """The 6 x 6 tile array of the scene-size family (benchmarks/configs.py: tiles_lsc; 37 nodes, plain Fresnel
+    surfaces) with `escaping` and `lost` recorders on every tile and the headline's face recorders on a middle one:
+    82 recorders.  Large enough for the kernel's node grid, and the reference kernel can run it."""
+    from benchmarks.configs import tiles_lsc
+    return tiles_lsc(6, recorders="all")
+
+
 TALLY_SCENES = {   # reference-kernel tallies at 10^6 photons (tests/golden/tallies_<name>_1e6.npz)
     "nested_cylinders": nested_cylinders,
     "hello_world_recorded": hello_world_recorded,
     "bench_slab_recorded": lambda: bench_slab(recorders=True),
+    "tiles6": tiles6,
 }
 
 

@@ -1,6 +1,6 @@
 """BASELINE configs other than the headline, pinned to the REFERENCE kernel at 10^6 photons.
 
-tests/golden/tallies_{nested_cylinders,hello_world,bench_slab}_1e6.npz hold the reference kernel's own
+tests/golden/tallies_{nested_cylinders,hello_world,bench_slab,tiles6}_1e6.npz hold the reference kernel's own
 tallies (made by tests/golden/make_golden.py::make_config_tallies with the recipe of the headline file).
 The reference's scheme for engine statistics is tests/test_engine.py:139-166 (Welch comparison of per-ray
 means); north_star's bar is 3 sigma per recorder at 10^6 photons.
@@ -9,7 +9,11 @@ means); north_star's bar is 3 sigma per recorder at 10^6 photons.
 * portable mode -- the arithmetic the GPU runs, bit for bit -- stays within 3 sigma per recorder on the same
   rays, and on independently seeded rays too.  nested_cylinders is the scene with the index-matched A/B
   interface where ~0.7 % of the histories take a different course in portable arithmetic: this is
-  the at-size statistical check of that deviation.
+  the at-size statistical check of that deviation.  tiles6 has such interfaces wholesale: in the reference's
+  rule for the far side of a surface (the node of the second-nearest crossing, _kernel.pyx:700-714) a photon that
+  leaves one tile towards another sees glass beyond the face, not the air gap, so every hop from tile to tile is an
+  index-matched crossing whose reflectivity comes out as 0 or ~1e-33 -- one random draw more or less -- by rounding
+  luck; 5 % of the histories part ways between libm and portable arithmetic, the statistics do not move.
 
 The GPU versions of these checks are in tests/test_gpu_full_size.py.
 """
@@ -26,6 +30,7 @@ CONFIGS = {   # golden file stem -> scene builder in tests/scenes.py
     "nested_cylinders": "nested_cylinders",
     "hello_world": "hello_world_recorded",
     "bench_slab": "bench_slab_recorded",
+    "tiles6": "tiles6",          # 37 nodes: the scene-size family; the GPU serves it through the node grid
 }
 
 
@@ -80,7 +85,7 @@ def test_portable_mode_within_three_sigma_of_the_reference(name):
     assert_within_three_sigma(port, n, g, name + " same rays")
     # same rays, so in fact far closer than sampling noise: the histories that part ways are few
     worst = np.abs(port["rec_distinct"].astype(np.int64) - g["rec_distinct"]).max()
-    assert worst <= {"nested_cylinders": 200}.get(name, 5), (name, int(worst))   # measured: 31 / 0 / 0
+    assert worst <= {"nested_cylinders": 200, "tiles6": 600}.get(name, 5), (name, int(worst))   # measured: 31 / 0 / 0 / 152
     # independent photons (other light samples, other streams)
     pos, dirs, wl, _ = emit_bundle(scene, n, seed=int(g["emit_seed"]) + 1000)
     other = O.trace_bundle(compiled, pos, dirs, wl, int(g["seed"]) + 5_000_000, 1000, 128, int(g["emit_method"]),

@@ -1,6 +1,6 @@
 """N>1 path on CPU: two gloo processes shard a job by index range, trace their
-shards (the oracle is injected as the tracer — there is no GPU here), all-reduce the
-tallies, and must reproduce the single-process result exactly for every integer
+shards (the oracle stands in for the kernel — there is no GPU here; the sharding and the
+reduction are the product's `run_sharded`), all-reduce the tallies, and must reproduce the single-process result exactly for every integer
 tally (f64 moment sums to rounding)."""
 import os
 import socket
@@ -18,27 +18,38 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _oracle_tracer(compiled, pos, dirs, wl, seed, ray_offset, maxsteps, max_events, emit_method,
-                   record_every):
-    from oracle import oracle as O
-
-    return O.trace_bundle(compiled, pos, dirs, wl, seed, maxsteps, max_events, emit_method, 1,
-                          record_every, ray_offset=ray_offset, math_mode=O.MATH_PORTABLE)
-
-
 def _worker(rank, world, port, n, out_dir):
     sys.path.insert(0, ROOT)
+    import torch
     import torch.distributed as dist
 
-    from pvtrace_amd.engine.distributed import shard_range, simulate_sharded
+    from oracle import oracle as O
+    from pvtrace_amd.engine.distributed import run_sharded, shard_range
     from pvtrace_amd.engine.emit import emit_bundle
     from tests import scenes
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     scene = scenes.bench_slab(recorders=True)
     pos, dirs, wl, _ = emit_bundle(scene, n, seed=55)
-    result = simulate_sharded(scene, n, seed=77, record_every=10, max_events=64,
-                              tracer=_oracle_tracer, rays=(pos, dirs, wl))
+
+    def trace_shard(compiled, start, stop):
+        # the product's sharding + reduction around a CPU trace (there is no GPU here): the oracle stands in for
+        # the kernel, with the rank's index range and ray offset
+        data = O.trace_bundle(compiled, pos[start:stop], dirs[start:stop], wl[start:stop], 77, 1000, 64, 0, 1, 10,
+                              ray_offset=start, math_mode=O.MATH_PORTABLE)
+        tallies = {k: torch.from_numpy(np.ascontiguousarray(data[k]).reshape(-1).copy())
+                   for k in ("rec_distinct", "rec_crossings", "rec_sums", "rec_bins")}
+
+        def finish(reduced):
+            out = dict(data)
+            for k in ("rec_distinct", "rec_crossings", "rec_bins"):
+                out[k] = reduced[k].numpy()
+            out["rec_sums"] = reduced["rec_sums"].numpy().reshape(data["rec_sums"].shape)
+            return out
+
+        return tallies, finish
+
+    result = run_sharded(scene, n, 64, 10, None, trace_shard)
     assert result.shard == shard_range(n, rank, world, align=10)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), counts=result.data["counts"],
              **{k: result.data[k] for k in ("rec_distinct", "rec_crossings", "rec_sums", "rec_bins")})

@@ -97,3 +97,90 @@ def test_pipeline_totals_do_not_depend_on_carrying():
         assert second["rec_distinct"][names.index("entering")] + second["rec_distinct"][names.index("reflected")] == 100_000
     finally:
         dscene.close()
+
+
+def test_a_narrower_launch_still_resumes_every_parked_photon():
+    """a launch of 4 workgroups per CU parks up to 64 photons per wave; its successor with 1 workgroup per
+    CU and a handful of new rays has a quarter of the waves.  Every parked photon must still be resumed (the library
+    widens the resuming launch's grid to the width of the one that parked)."""
+    import torch
+
+    scene = scenes.lsc_equivalent()
+    compiled = compile_scene(scene)
+    n, seed = 600_000, 3
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=12)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, seed, 1000, 16, 0, 8, 0, math_mode=O.MATH_PORTABLE)
+    dscene = native.DeviceScene(compiled, device=0)
+    try:
+        dev = torch.device("cuda", 0)
+        rays = tuple(torch.from_numpy(a).to(dev) for a in (pos, dirs, wl))
+        tallies = dscene.new_tallies()
+        cut = n - 100
+        dscene.trace(tuple(t[:cut] for t in rays), cut, seed, tallies, carry_out=True, workgroups_per_cu=4)
+        wide = dscene.launch_info()["grid"]
+        dscene.trace(tuple(t[cut:] for t in rays), n - cut, seed, tallies, ray_offset=cut, carry_out=False, workgroups_per_cu=1)
+        assert dscene.launch_info()["grid"] >= wide
+        torch.cuda.synchronize()
+        got = _host(tallies, compiled)
+        for key in INT_KEYS:
+            assert np.array_equal(got[key], cpu[key]), key
+    finally:
+        dscene.close()
+
+
+def test_parked_photons_keep_their_rules_or_are_refused():
+    """The launch that resumes parked photons must trace by the rules of the launch that parked them (maxsteps,
+    emit_method): anything else is refused, in the C ABI and in BundlePipeline.submit; an abandoned job's photons
+    can be dropped (pvt_scene_carry_discard) and are dropped when a new pipeline takes over the stream."""
+    import torch
+
+    scene = scenes.lsc_equivalent()
+    compiled = compile_scene(scene)
+    dscene = native.DeviceScene(compiled, device=0, emitter=EmitterTables(scene))
+    try:
+        tallies = dscene.new_tallies()
+        dscene.trace(None, 50_000, 1, tallies, emit_seed=2, carry_out=True, maxsteps=1000, emit_method=0)
+        assert dscene.carry_pending()
+        with pytest.raises(ValueError, match="maxsteps"):
+            dscene.trace(None, 50_000, 1, tallies, emit_seed=2, ray_offset=50_000, maxsteps=500, emit_method=0)
+        with pytest.raises(ValueError, match="emit_method"):
+            dscene.trace(None, 0, 0, tallies, maxsteps=1000, emit_method=2)
+        assert dscene.carry_pending()                 # a refused launch changes nothing
+        dscene.carry_discard()
+        assert not dscene.carry_pending()
+        dscene.trace(None, 0, 0, tallies, maxsteps=500, emit_method=2)      # nothing waiting: any rules, a no-op
+        torch.cuda.synchronize()
+
+        # the pipeline says the same in Python, before anything is enqueued
+        pipe = BundlePipeline(dscene, depth=2)
+        pipe.submit(None, 40_000, seed=5, emit_seed=6, maxsteps=1000)
+        pipe.submit(None, 40_000, seed=5, ray_offset=40_000, emit_seed=6, maxsteps=1000)
+        with pytest.raises(ValueError, match="parts of one job"):
+            pipe.submit(None, 40_000, seed=5, ray_offset=80_000, emit_seed=6, maxsteps=200)
+        streams = [s.cuda_stream for s in pipe.streams]
+        assert any(dscene.carry_pending(s) for s in streams)
+        # ... and an abandoned pipeline does not leak its photons into the next job on the scene
+        del pipe
+        assert not any(dscene.carry_pending(s) for s in streams)
+        fresh = BundlePipeline(dscene, depth=2)
+        for k in range(4):
+            fresh.submit(None, 25_000, seed=9, ray_offset=k * 25_000, emit_seed=6)
+        got = fresh.totals_host()
+        names = list(compiled.recorder_names)
+        assert got["rec_distinct"][names.index("entering")] + got["rec_distinct"][names.index("reflected")] == 100_000
+    finally:
+        dscene.close()
+
+
+def test_host_buffer_entry_ignores_the_carry_flag():
+    """pvt_trace_bundle creates a scene, traces once and destroys it: nothing could ever resume parked photons, so the
+    flag is masked there and the tallies are complete."""
+    from pvtrace_amd.engine import _kernel
+
+    scene = scenes.lsc_equivalent()
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, 20_000, seed=3)
+    plain = _kernel.trace_bundle(compiled, pos, dirs, wl, 11, 1000, 16, 0, 1, 0)
+    flagged = _kernel.trace_bundle(compiled, pos, dirs, wl, 11, 1000, 16, 0, 1, 0, flags=native.FLAG_CARRY_OUT)
+    for key in INT_KEYS:
+        assert np.array_equal(plain[key], flagged[key]), key
