@@ -482,6 +482,13 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         idx_class[n] = cls;
     }
     if (!index_ok) return fail(PVT_ERR_INVALID, "refractive indices must be finite and positive");
+    // scenes of few nodes: classes, component records and candidate blocks numbered like the nodes / the reference's ids
+    // (Lay::by_node: the lanes index the tables without reading NI_NCLS / NI_CREC / NI_CAND first)
+    const bool by_node = N <= 16;
+    if (by_node) {
+        idx_first.resize((size_t)N);
+        for (int n = 0; n < N; n++) { idx_class[n] = n; idx_first[(size_t)n] = n; }
+    }
     const int M = (int)idx_first.size();
 
     // Spectra, packed per DISTINCT table.  RN(1/spacing) when EVERY interval of the abscissae has the same bits and
@@ -570,7 +577,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         const int c0 = t->comp_start[n], cc = t->comp_count[n];
         if (cc < 0 || c0 < 0 || c0 + cc > C) return fail(PVT_ERR_INVALID, "component range of a node out of bounds");
         int found = -1;
-        for (int e = 0; e < n && found < 0; e++) {
+        if (by_node) found = c0;   // (one record per component id: NI_CREC == NI_CSTART, which the kernel relies on)
+        for (int e = 0; e < n && found < 0 && !by_node; e++) {
             if (t->comp_count[e] != cc) continue;
             bool same = true;
             for (int k = 0; k < cc && same; k++) same = same_component(c0 + k, t->comp_start[e] + k);
@@ -582,6 +590,10 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         }
         node_crec[n] = found;
     }
+    if (by_node) {
+        rec_comp.resize((size_t)C);
+        for (int c = 0; c < C; c++) rec_comp[(size_t)c] = c;
+    }
     const int CR = (int)rec_comp.size();
     // recorder candidate blocks: only for the nodes somebody listens to
     std::vector<int> node_cand(N, -1);
@@ -589,7 +601,11 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     for (int r = 0; r < R; r++) {
         const int n = t->rec_node[r];
         if (n < 0 || n >= N) return fail(PVT_ERR_INVALID, "recorder on a missing node");
-        if (node_cand[n] < 0) node_cand[n] = n_cand++;
+        if (!by_node && node_cand[n] < 0) node_cand[n] = n_cand++;
+    }
+    if (by_node) {
+        for (int n = 0; n < N; n++) node_cand[n] = n;
+        n_cand = N;
     }
 
     // fixed-stride records, then the pooled spectra
@@ -641,6 +657,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + M * M : -1;
     lay.rot_d = spec_end + (lay.crit_d >= 0 ? 2 * M * M : 0);
     lay.ncls_d = lay.rot_d + Q * RT;
+    lay.by_node = by_node ? 1 : 0;
     NodeGrid grid;
     const bool has_grid = plan_node_grid(t, &grid);
     lay.grid_d = has_grid ? lay.ncls_d + M * 2 : -1;

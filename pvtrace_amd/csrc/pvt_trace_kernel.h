@@ -63,11 +63,12 @@ constexpr unsigned long long kEmitSalt = 0xA5A5A5A55A5A5A5Aull;
 // table element is addressed as base + index*stride + field with compile-time strides
 // and fields; only the eight record bases below live in SGPRs (node records start at 0).
 // Node records are what a photon reads of the node it is in / hits / tests, and what the intersection loop reads of
-// EVERY node: 64 bytes of payload, 72 apart -- the lanes of the grid walk read the records of DIFFERENT nodes in one
-// LDS instruction, and with 64 bytes between records all of them would fall on two of the 32 banks.
+// EVERY node: 64 bytes (one scalar load in the wave-uniform loop; a stride of 72 bytes, meant to spread the per-lane
+// reads of the grid walk over the LDS banks, gained 1 % there and cost the headline scene an integer multiply per
+// record address).
 // Rotations, refractive-index reciprocals and critical angles live in small side tables indexed by CLASS (nodes with
 // bit-identical rotations / refractive indices share an entry), so a scene of 120 tiles costs 12 KB of LDS, not 56.
-enum { ND_T = 0, ND_PARAMS = 3, ND_BITS = 6, ND_N = 7, ND = 9 };  // node doubles: translation of world->local, three shape
+enum { ND_T = 0, ND_PARAMS = 3, ND_BITS = 6, ND_N = 7, ND = 8 };  // node doubles: translation of world->local, three shape
                                                                  // parameters (no shape has four), one word of {bit 0: the
                                                                  // rotation is the identity, bit for bit; bits 8-15: geometry
                                                                  // type; high half: rotation class}, refractive index
@@ -106,7 +107,10 @@ struct Lay {  // record bases (elements) inside the blobs; spectra follow the re
                     // cell the bit mask of the nodes filed under it (x fastest)
     int rot_d;      // rotation classes x RT doubles (every node has one; the identity's is only read by the Lambertian branch)
     int ncls_d;     // refractive-index classes x {n, RN(1/n)}
-    int n_cls;
+    int n_cls;      // refractive-index classes (side of the crit tables)
+    int by_node;    // 1: a scene of few nodes -- index classes and recorder candidate blocks are numbered like the nodes, so the
+                    // lanes index the tables by node without reading NI_NCLS / NI_CAND first (one dependent LDS read fewer
+                    // in the surface branch and in the tally: the headline scene)
 };
 
 struct EmitOff {  // emitter blobs (global only; read once per photon)
@@ -693,12 +697,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     // Launch constants that the loop only asks yes/no questions of, in ONE scalar register.  Kept as separate
     // conditions each becomes a 64-bit lane mask that the allocator holds (spills) for the whole loop; `uf(bit)`
     // re-derives the answer from the word where it is asked (the empty asm keeps the compiler from hoisting it).
-    enum { UF_COATED = 0, UF_FUSE_EXIT, UF_CRIT, UF_HAS_REC, UF_TQ_POS, UF_BINS_LDS, UF_EMIT_FULL, UF_EMIT_KT, UF_LAZY1, UF_LAZY2 };
+    enum { UF_COATED = 0, UF_FUSE_EXIT, UF_CRIT, UF_HAS_REC, UF_TQ_POS, UF_BINS_LDS, UF_EMIT_FULL, UF_EMIT_KT, UF_LAZY1, UF_LAZY2, UF_BY_NODE };
     const unsigned int uflags =
         (A.n_coat > 0 ? 1u << UF_COATED : 0u) | (A.fuse_exit != 0 ? 1u << UF_FUSE_EXIT : 0u) | (L.crit_d >= 0 ? 1u << UF_CRIT : 0u) |
         (A.n_rec > 0 ? 1u << UF_HAS_REC : 0u) | (A.tq_pos ? 1u << UF_TQ_POS : 0u) | (A.bins_in_lds ? 1u << UF_BINS_LDS : 0u) |
         (A.emit_method == PVT_EMIT_FULL ? 1u << UF_EMIT_FULL : 0u) | (A.emit_method == PVT_EMIT_KT ? 1u << UF_EMIT_KT : 0u) |
-        (A.lazy_root == 1 ? 1u << UF_LAZY1 : 0u) | (A.lazy_root == 2 ? 1u << UF_LAZY2 : 0u);
+        (A.lazy_root == 1 ? 1u << UF_LAZY1 : 0u) | (A.lazy_root == 2 ? 1u << UF_LAZY2 : 0u) | (L.by_node ? 1u << UF_BY_NODE : 0u);
     auto uf = [&](int bit) -> bool {
         unsigned int f = uflags;
         asm volatile("" : "+s"(f));
@@ -1620,12 +1624,81 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                         i += 1;
                         b = nxt;
                     }
-                } else {
-                    if (gt == PVT_GEOM_BOX && !inv_ok) {   // 1/d per axis, shared by consecutive nodes whose rotations have the same bits
-                        inv[0] = rcp_normal(d.x); inv[1] = rcp_normal(d.y); inv[2] = rcp_normal(d.z);   // (garbage below 1e-300: never used)
-                        inv_ok = true;
+                } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
+                double tmin = -INFINITY, tmax = INFINITY;
+                bool miss = false;
+                const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+                if (!inv_ok) {   // 1/d per axis, shared by consecutive nodes whose rotations have the same bits
+#pragma unroll
+                    for (int a = 0; a < 3; a++) inv[a] = rcp_normal(dd[a]);   // 1/d (garbage below 1e-300: never used)
+                    inv_ok = true;
+                }
+                // a ray parallel to a pair of faces (a direction component below 1e-300) takes the reference's
+                // inside/outside test for that axis; the wave only runs the general form when a lane holds one
+                if (__ballot(pvt_fabs(dd[0]) < 1e-300 || pvt_fabs(dd[1]) < 1e-300 || pvt_fabs(dd[2]) < 1e-300) == 0ull) {
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const double sz = gpar[a];
+                        const double ta = (-0.5 * sz - oo[a]) * inv[a], tb = (0.5 * sz - oo[a]) * inv[a];
+                        tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                        tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
                     }
-                    shape_hits(gt, gpar[0], gpar[1], gpar[2], o, d, inv[0], inv[1], inv[2], fold);
+                } else
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    double sz = gpar[a];
+                    double lo = -0.5 * sz, hi = 0.5 * sz;
+                    if (pvt_fabs(dd[a]) < 1e-300) {
+                        if (oo[a] < lo || oo[a] > hi) miss = true;
+                    } else {
+                        // (the reference swaps ta, tb into order and keeps the largest entry / smallest exit
+                        // distance: min and max of finite numbers, which is what these are)
+                        const double ta = (lo - oo[a]) * inv[a], tb = (hi - oo[a]) * inv[a];
+                        tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                        tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                    }
+                }
+                if (!miss && !(tmax < tmin)) {
+                    if (tmin > kEps) fold(tmin);
+                    if (tmax > kEps) fold(tmax);
+                }
+            } else if (gt == PVT_GEOM_SPHERE) {  // (:279-298)
+                    double radius = gpar[0];
+                    double a = dot3(d, d), b = 2.0 * dot3(d, o), c = dot3(o, o) - radius * radius;
+                    double disc = b * b - 4.0 * a * c;
+                    if (!(disc < 0.0)) {
+                        double sq = pvt_sqrt(disc);
+                        double t = (-b - sq) / (2.0 * a);
+                        if (t > kEps) fold(t);
+                        t = (-b + sq) / (2.0 * a);
+                        if (t > kEps) fold(t);
+                    }
+                } else {  // capped z cylinder (:301-345)
+                    double half = 0.5 * gpar[0], radius = gpar[1];
+                    double a = d.x * d.x + d.y * d.y;
+                    if (a > 1e-300) {
+                        double b = 2.0 * (o.x * d.x + o.y * d.y);
+                        double c = o.x * o.x + o.y * o.y - radius * radius;
+                        double disc = b * b - 4.0 * a * c;
+                        if (disc >= 0.0) {
+                            double sq = pvt_sqrt(disc);
+                            double t = (-b - sq) / (2.0 * a);
+                            double z = o.z + t * d.z;
+                            if (z > -half && z < half && t > kEps) fold(t);
+                            t = (-b + sq) / (2.0 * a);
+                            z = o.z + t * d.z;
+                            if (z > -half && z < half && t > kEps) fold(t);
+                        }
+                    }
+                    if (pvt_fabs(d.z) > 1e-300) {
+                        double t = (-half - o.z) / d.z;
+                        double x = o.x + t * d.x, y = o.y + t * d.y;
+                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                        t = (half - o.z) / d.z;
+                        x = o.x + t * d.x;
+                        y = o.y + t * d.y;
+                        if (x * x + y * y <= radius * radius && t > kEps) fold(t);
+                    }
                 }
                     // The container is the nearest node the ray starts inside of: crossed exactly once for the
                     // reference's convex shapes (:696-706); a triangle mesh may be non-convex, so it holds the
@@ -1677,7 +1750,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         if (pend) {
             n_container = T.dv(container * ND + ND_N);
             cbase = T.iv(container * NI + NI_CSTART); ccount = T.iv(container * NI + NI_CCOUNT);
-            crec = T.iv(container * NI + NI_CREC);
+            if (uf(UF_BY_NODE)) crec = cbase;   // (scenes of few nodes keep one record per component id)
+            else crec = T.iv(container * NI + NI_CREC);
             if (hit != A.root) {
                 for (int k = 0; k < ccount; k++) {
                     const int ci = L.comp_i + (crec + k) * CI, cd = L.comp_d + (crec + k) * CD;
@@ -1928,18 +2002,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 n1 = T.dv(container * ND + ND_N);
                 n2 = T.dv(adjacent * ND + ND_N);
                 // what depends on the refractive indices alone is tabulated per pair of index CLASSES
-                const int kc = T.iv(container * NI + NI_NCLS), ka = T.iv(adjacent * NI + NI_NCLS);
-                rn2 = T.dv(L.ncls_d + ka * 2 + 1);
+                int kc = container, ka = adjacent;
+                if (!uf(UF_BY_NODE)) { kc = T.iv(container * NI + NI_NCLS); ka = T.iv(adjacent * NI + NI_NCLS); }
+                const int ncls_d = L.ncls_d, n_cls = L.n_cls;
+                rn2 = T.dv(ncls_d + ka * 2 + 1);
                 // critical angle asin(n2/n1): a function of the node pair, tabulated by the host
                 // with the same pvt_asin (small scenes), else computed here
                 bool tir;
                 // (the reference compares acos(c1) with the critical angle; the host has turned that into a
                 // comparison of c1 itself wherever it could prove the two agree for every double)
                 const bool crit_tab = uf(UF_CRIT);
-                const double cc = crit_tab ? T.dv(L.ccrit_d + kc * L.n_cls + ka) : __builtin_nan("");
+                const double cc = crit_tab ? T.dv(L.ccrit_d + kc * n_cls + ka) : __builtin_nan("");
                 if (cc == cc) tir = c1 < cc;
-                else if (crit_tab) tir = pvt_acos(c1) > T.dv(L.crit_d + kc * L.n_cls + ka);
-                else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(L.ncls_d + kc * 2 + 1)));
+                else if (crit_tab) tir = pvt_acos(c1) > T.dv(L.crit_d + kc * n_cls + ka);
+                else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(ncls_d + kc * 2 + 1)));
                 if (tir) {
                     r = 1.0;
                 } else {
@@ -2062,13 +2138,19 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             // recorder with the full tolerance test (its first trip).  Everything else is walked.
             int cs = 0, cn = 0, rbin = -1;
             if (alive && t_sel >= 0) {
-                const int cb = T.iv(t_node * NI + NI_CAND);   // -1: nobody listens to this node
-                const int key = L.cand_i + ((cb < 0 ? 0 : cb) * 7 + t_sel) * 8;
-                if (cb >= 0) {
+                int cb = t_node;       // the node's block of the candidate tables
+                bool listened = true;
+                if (!uf(UF_BY_NODE)) {   // (scenes of many nodes: only the nodes somebody listens to have one)
+                    cb = T.iv(t_node * NI + NI_CAND);
+                    listened = cb >= 0;
+                    cb = listened ? cb : 0;
+                }
+                const int key = L.cand_i + (cb * 7 + t_sel) * 8;
+                if (listened) {
                     cs = T.iv(key);
                     cn = T.iv(key + 1);
                 }
-                if (cb >= 0 && t_normal) {
+                if (listened && t_normal) {
                     const double ax = pvt_fabs(nrm.x), ay = pvt_fabs(nrm.y), az = pvt_fabs(nrm.z);
                     int b = (ax >= ay && ax >= az) ? (nrm.x > 0.0 ? 1 : 0)
                           : (ay >= az)             ? (nrm.y > 0.0 ? 3 : 2)

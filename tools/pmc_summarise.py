@@ -18,7 +18,10 @@ sums = collections.defaultdict(list)
 launches = {}
 STEPS = 6   # tools/gpu_pmc.sh: --steps 6 --warmup 1
 kernel = None
-for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{mode}_*", "pmc_counter_collection.csv"))):
+PASSES = ("fetch", "write", "sq1", "sq2", "sq3", "grbm")   # tools/gpu_pmc.sh (exact names: pmc_pipelined_* would also match pmc_pipelined_cfg5_*)
+for path in [os.path.join(ROOT, "gpurun_out", f"pmc_{mode}_{p}", "pmc_counter_collection.csv") for p in PASSES]:
+    if not os.path.exists(path):
+        continue
     rows = [r for r in csv.DictReader(open(path)) if "trace_kernel" in r["Kernel_Name"]]
     per = collections.defaultdict(list)
     for r in rows:
@@ -35,7 +38,7 @@ c = dict(sums)
 read_b = c["FETCH_SIZE"] * 1024 * 2
 write_b = c["WRITE_SIZE"] * 1024
 out = {
-    "round": 3, "stage": stage, "mode": mode, "config": cfg,
+    "round": 4, "stage": stage, "mode": mode, "config": cfg,
     "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --gpus 1 --steps 6 --warmup 1 "
                "--no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2 --extra-configs none --config " + cfg
                + (" --streams 1" if mode.startswith("serial") else "") + " (one counter set per run; tools/gpu_pmc.sh " + mode.split("_")[0] + " " + cfg + "); "
