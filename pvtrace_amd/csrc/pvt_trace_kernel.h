@@ -2033,7 +2033,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             int coat = -1;
             if (uf(UF_COATED) && fres) {
                 const int cs = T.iv(hit * NI + NI_KSTART), ce = cs + T.iv(hit * NI + NI_KCOUNT);
-                const V3 lpos = local_point(), nloc = local_normal(lpos);
+                // (only the lanes whose node carries coatings; on an unrotated node the normal in the node's frame IS the
+                // world normal computed above, bit for bit -- the same local_normal, not rotated -- so it is not recomputed)
+                V3 lpos{0, 0, 0}, nloc = nrm;
+                if (cs < ce) {
+                    lpos = local_point();
+                    if (!node_ident(node_bits(hit))) nloc = local_normal(lpos);
+                }
                 const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
                 for (int c = cs; c < ce && coat < 0; c++) {
                     bool ok = true;
@@ -2060,7 +2066,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (lamb) {
                     // cosine-weighted about the incoming side's normal, in the node frame
                     double side = dot3(nrm, dir) < 0.0 ? 1.0 : -1.0;
-                    const V3 nloc = local_normal(local_point());
+                    V3 nloc = nrm;   // (unrotated node: the world normal is the local one)
+                    if (!node_ident(node_bits(hit))) nloc = local_normal(local_point());
                     V3 mm{side * nloc.x, side * nloc.y, side * nloc.z};
                     double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
                     V3 sd = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
