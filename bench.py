@@ -263,6 +263,10 @@ def main():
         import torch.distributed as dist
 
         timeout = datetime.timedelta(seconds=args.rccl_timeout_s)
+        # a rank that dies must surface on the others as an exception at their next collective (after the time-out), not
+        # as a watchdog abort: rank 0 then still prints its line, with what it had measured and an `error` field
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         try:
             if backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=dev, timeout=timeout)
@@ -289,11 +293,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def max_over_ranks(dt):
+    rank_seconds = {}   # leg -> every rank's own seconds for its last window (one collective gives the MAX and the spread)
+
+    def max_over_ranks(dt, leg=None):
         if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            t = torch.zeros(world, dtype=torch.float64, device=dev)
+            t[rank] = dt
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            each = [float(v) for v in t.tolist()]
+            if leg is not None:
+                rank_seconds[leg] = each
+            dt = max(each)
         return dt
 
     class Leg:
@@ -348,7 +358,7 @@ def main():
                 self.step(first_step + k, timed_events, tail=k >= steps - tail_wide, closing=k >= steps - args.streams)
             self.pipe.reduce_totals()   # fold the streams' totals; RCCL all-reduce over the ranks (reduce="end")
             fence(self.pipe)
-            return max_over_ranks(time.perf_counter() - t0)
+            return max_over_ranks(time.perf_counter() - t0, leg=self.name)
 
         def spin_up(self, seconds, warmup):
             # Clocks: an idle MI355X needs tens of milliseconds of work to reach its sustained clocks, far more
@@ -398,37 +408,62 @@ def main():
     per_window = n * world * args.steps
     value = per_window / median_dt
 
-    sustained = None
-    if args.sustained_s > 0:
+    errors = []
+    if os.environ.get("PVT_BENCH_DIE_AFTER_MAIN") == str(rank):   # (tests: a rank lost after the timed region)
+        os._exit(3)
+
+    def attempt(what, body):
+        """The legs after the contract's K steps: a failure (a rank gone, a collective timed out) is recorded, not fatal."""
+        try:
+            return body()
+        except Exception as exc:   # noqa: BLE001
+            errors.append(f"{what}: {type(exc).__name__}: {exc}"[:400])
+            return None
+
+    state = {"next_step": next_step}
+
+    def sustained_leg():
         # a short probe gives the step time without the fixed cost of a 20-step window
         probe_steps = 10 * args.steps
-        probe = leg.window(next_step, probe_steps) if args.sustained_s >= 1.0 else median_dt / args.steps * probe_steps
-        next_step += probe_steps
+        probe = (leg.window(state["next_step"], probe_steps) if args.sustained_s >= 1.0
+                 else median_dt / args.steps * probe_steps)
+        state["next_step"] += probe_steps
         sus_steps = max(args.steps, int(args.sustained_s / (probe / probe_steps)))
-        dt = leg.window(next_step, sus_steps)
-        next_step += sus_steps
-        sustained = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt,
-                     "value": n * world * sus_steps / dt}
-    strong = None
-    if args.total_photons > 0:
+        dt = leg.window(state["next_step"], sus_steps)
+        state["next_step"] += sus_steps
+        out = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt, "value": n * world * sus_steps / dt}
+        if distributed and leg.name in rank_seconds:
+            each = rank_seconds[leg.name]
+            out["seconds_per_rank"] = each        # every rank's own barrier-to-barrier time for this leg
+            out["rank_spread"] = (max(each) - min(each)) / max(each)
+        return out
+
+    def strong_leg(sustained):
         # BASELINE configs[2]: ONE job of `total` photons, rank r traces the index range
         # [r*total/world, (r+1)*total/world) in bundles of n (ray seed = seed + global index), the tallies
         # are all-reduced once at the end; time = barrier to barrier, max over ranks
         from pvtrace_amd.engine.distributed import shard_range
 
+        def job(pipe, lo, hi, fenced):
+            pipe.reset_totals()
+            fenced()
+            t0 = time.perf_counter()
+            at, k = lo, 0
+            while at < hi:
+                m = min(n, hi - at)
+                rays = leg.ray_sets[k % len(leg.ray_sets)]
+                if rays is not None and m != leg.n:
+                    rays = tuple(t[:m] for t in rays)
+                pipe.submit(rays, m, seed=777, ray_offset=at, emit_seed=4242 + k * world * leg.n, maxsteps=1000, max_events=128,
+                            emit_method=leg.method, timed=False, tail=at + m >= hi, closing=at + m * args.streams >= hi)
+                at += m
+                k += 1
+            pipe.reduce_totals()
+            fenced()
+            return time.perf_counter() - t0
+
         lo, hi = shard_range(args.total_photons, rank, world)
-        leg.pipe.reset_totals()
-        fence(leg.pipe)
-        t0 = time.perf_counter()
-        at, k = lo, 0
-        while at < hi:
-            m = min(n, hi - at)
-            leg.step(k, False, tail=at + m >= hi, m=m, offset=at, seed=777, closing=at + m * args.streams >= hi)
-            at += m
-            k += 1
-        leg.pipe.reduce_totals()
-        fence(leg.pipe)
-        dt = max_over_ranks(time.perf_counter() - t0)
+        dt = max_over_ranks(job(leg.pipe, lo, hi, lambda: fence(leg.pipe)), leg="strong")
         st = leg.pipe.totals_host()
         names = list(leg.compiled.recorder_names)
         tallied = None
@@ -436,6 +471,8 @@ def main():
             tallied = int(st["rec_distinct"][names.index("entering")] + st["rec_distinct"][names.index("reflected")])
         strong = {"scaling": "strong", "total_photons": args.total_photons, "seconds": dt,
                   "value": args.total_photons / dt, "photons_tallied": tallied}
+        if distributed and "strong" in rank_seconds:
+            strong["seconds_per_rank"] = rank_seconds["strong"]
         if sustained is not None:
             # What to expect at N GPUs: a rank traces total/(N n) bundles at the sustained step time, plus the part
             # of a job that does not shrink with N -- the ramp and the drain of its last bundles, the fold of the
@@ -450,65 +487,99 @@ def main():
                 "efficiency": {str(g): (bundles * t_step + t_fixed) / (g * (bundles / g * t_step + t_fixed))
                                for g in (2, 4, 8)},
             }
+        if world > 1:
+            # ... and what it IS at this N: rank 0 traces the whole job alone (its own pipeline, no collective) while
+            # the others wait; efficiency = T(1) / (N T(N)), both measured in this run
+            alone = None
+            if rank == 0:
+                solo = BundlePipeline(leg.dscene, depth=args.streams, distributed=False)
+                solo.wait_for_inputs()
+                for _ in range(2):   # (the first pass pays for the new pipeline's streams and buffers)
+                    alone = job(solo, 0, args.total_photons, lambda: (solo.synchronize(), torch.cuda.synchronize(dev)))
+                solo.close()
+            fence(leg.pipe)
+            if rank == 0:
+                strong["measured"] = {"seconds_one_gpu": alone, "seconds_n_gpus": dt, "n_gpus": world,
+                                      "efficiency": alone / (world * dt)}
+        return strong
 
     # ------------------------------------------------------------------ the other configs, same measurement
-    extra = {}
-    wanted = [c for c in args.extra_configs.split(",") if c and c != "none"] if args.config == "cfg2" else []
-    for name in wanted:
+    def config_leg(name):
         bundles = max(1, args.config_photons // n)
         other = Leg(name, n)
-        other.spin_up(min(args.spinup_s, 0.1), 2)
-        dts, kms = [], []
-        for w in range(5):
-            dts.append(other.window(100 + w * bundles, bundles, timed_events=True))
-            kms += other.pipe.kernel_ms()
-        frac = other.fractions(n * world * bundles)
-        dts.sort()
-        photons = n * world * bundles
-        v = photons / dts[len(dts) // 2]
-        sus = None
-        if args.config_sustained_s > 0:
-            sus_steps = max(bundles, int(args.config_sustained_s / (dts[len(dts) // 2] / bundles)))
-            dt = other.window(100_000, sus_steps)
-            sus = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt, "value": n * world * sus_steps / dt}
-        _, side = load_pmc(name, v / world, cus)
-        extra[name] = {
-            "workload": CONFIGS[name]["workload"], "photons_per_gpu": n * bundles, "bundles": bundles,
-            "emission": "device (in the trace kernel)", "bundles_in_flight": args.streams,
-            "value": v, "unit": "photons/s", "windows": len(dts), "min": photons / dts[-1], "max": photons / dts[0],
-            "ms_per_window": dts[len(dts) // 2] * 1e3, "kernel_ms_mean": sum(kms) / len(kms),
-            "launch": other.dscene.launch_info(), "instruction_side": side, "tallies": frac, "sustained": sus,
-            "note": "a fenced window ends with the longest history of its last bundles traced alone (cfg4: photons "
-                    "trapped by total internal reflection for hundreds of steps at ~4 us each, DESIGN.md §6); "
-                    "`sustained` is the same stream without intermediate fences",
-        }
-        other.close()
+        try:
+            other.spin_up(min(args.spinup_s, 0.1), 2)
+            dts, kms = [], []
+            for w in range(5):
+                dts.append(other.window(100 + w * bundles, bundles, timed_events=True))
+                kms += other.pipe.kernel_ms()
+            frac = other.fractions(n * world * bundles)
+            dts.sort()
+            photons = n * world * bundles
+            v = photons / dts[len(dts) // 2]
+            sus = None
+            if args.config_sustained_s > 0:
+                sus_steps = max(bundles, int(args.config_sustained_s / (dts[len(dts) // 2] / bundles)))
+                dt = other.window(100_000, sus_steps)
+                sus = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt, "value": n * world * sus_steps / dt}
+            _, side = load_pmc(name, v / world, cus)
+            return {
+                "workload": CONFIGS[name]["workload"], "photons_per_gpu": n * bundles, "bundles": bundles,
+                "emission": "device (sampled by the wave that claims a chunk of rays, in the trace kernel)", "bundles_in_flight": args.streams,
+                "value": v, "unit": "photons/s", "windows": len(dts), "min": photons / dts[-1], "max": photons / dts[0],
+                "ms_per_window": dts[len(dts) // 2] * 1e3, "kernel_ms_mean": sum(kms) / len(kms),
+                "launch": other.dscene.launch_info(), "instruction_side": side, "tallies": frac, "sustained": sus,
+                "note": "a fenced window ends with the longest history of its last bundles traced alone (cfg4: photons "
+                        "trapped by total internal reflection for hundreds of steps at ~4 us each, DESIGN.md §6); "
+                        "`sustained` is the same stream without intermediate fences",
+            }
+        finally:
+            other.close()
 
     # ------------------------------------------------------------------ scene size: photons/s against the node count
-    scaling = None
-    sizes = ([int(k) for k in args.scene_sizes.split(",") if k and k != "none"]
-             if args.config == "cfg2" and args.extra_configs != "none" else [])   # ('--extra-configs none': the main config only)
-    if sizes:
-        scaling = {"what": "k x k tile arrays of the headline slab in one world (benchmarks/configs.py: tiles_lsc), device "
-                           "emission, same pipeline as the other configs; the reference intersects every node in every step "
-                           "(_kernel.pyx:666-680), this engine walks a node grid from 8 nodes on (DESIGN.md)",
-                   "photons_per_gpu_per_window": n * 10, "sizes": {}}
-        for k in sizes:
-            name = f"tiles{k}"
-            other = Leg(name, n)
+    def size_leg(k):
+        name = f"tiles{k}"
+        other = Leg(name, n)
+        try:
             other.spin_up(min(args.spinup_s, 0.1), 2)
             dts = sorted(other.window(100 + w * 10, 10) for w in range(3))
             v = n * world * 10 / dts[1]
             sus_steps = max(10, int(1.0 / (dts[1] / 10)))
             dt = other.window(100_000, sus_steps)
             _, side = load_pmc(name, v / world, cus)
-            scaling["sizes"][name] = {
+            return {
                 "nodes": k * k + 1, "value": v, "sustained": n * world * sus_steps / dt, "unit": "photons/s",
                 "launch": other.dscene.launch_info(), "node_grid": native.node_grid_plan(other.compiled) is not None,
                 "valu_wave_instructions_per_photon": (side or {}).get("valu_wave_instructions_per_photon"),
                 "valu_lane_utilisation": (side or {}).get("valu_lane_utilisation"),
             }
+        finally:
             other.close()
+
+    sustained = attempt("sustained leg", sustained_leg) if args.sustained_s > 0 and not errors else None
+    strong = attempt("strong-scaling leg", lambda: strong_leg(sustained)) if args.total_photons > 0 and not errors else None
+    extra = {}
+    wanted = [c for c in args.extra_configs.split(",") if c and c != "none"] if args.config == "cfg2" else []
+    for name in wanted:
+        if errors:
+            break
+        got = attempt(f"config {name}", lambda: config_leg(name))
+        if got is not None:
+            extra[name] = got
+    scaling = None
+    sizes = ([int(k) for k in args.scene_sizes.split(",") if k and k != "none"]
+             if args.config == "cfg2" and args.extra_configs != "none" else [])   # ('--extra-configs none': the main config only)
+    if sizes and not errors:
+        scaling = {"what": "k x k tile arrays of the headline slab in one world (benchmarks/configs.py: tiles_lsc), device "
+                           "emission, same pipeline as the other configs; the reference intersects every node in every step "
+                           "(_kernel.pyx:666-680), this engine walks a node grid from 8 nodes on (DESIGN.md)",
+                   "photons_per_gpu_per_window": n * 10, "sizes": {}}
+        for k in sizes:
+            if errors:
+                break
+            got = attempt(f"scene size tiles{k}", lambda: size_leg(k))
+            if got is not None:
+                scaling["sizes"][f"tiles{k}"] = got
 
     if rank == 0:
         achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9 if leg.array_input else 0.0
@@ -571,13 +642,18 @@ def main():
             out["configs"] = extra
         if scaling:
             out["scene_scaling"] = scaling
+        if errors:
+            out["error"] = "; ".join(errors)   # (everything above was measured before the failure)
         if not args.no_cpu_baseline and world == 1 and leg.array_input:   # the CPU referee is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(leg.compiled, *leg.host_rays)
         print(json.dumps(out), flush=True)
     leg.close()
-    if distributed:
+    if distributed and not errors:
         dist.barrier()
         dist.destroy_process_group()
+    if errors:
+        sys.stdout.flush()
+        os._exit(1)   # (a lost rank leaves the process group unusable: no tidy shutdown to wait for)
 
 
 if __name__ == "__main__":

@@ -376,6 +376,39 @@ def test_device_list_entry_sums_the_tallies_with_rccl_when_asked(monkeypatch):
     assert_bundles_identical(two, one, sums_rtol=1e-12, what="host sum")
 
 
+def test_rccl_reduce_of_a_ten_thousand_bin_scene_and_the_reduce_overrides(monkeypatch):
+    """The device-side sum of pvt_trace_bundle_multi at the buffer sizes of a real scene (a 100 x 100 heat map: 10 000
+    bins next to the recorder counts) -- as a one-rank communicator, the only kind this box has -- twice in a row (the
+    communicator of a device list is built once and kept), then the same job under PVT_MULTI_REDUCE=host and over a
+    device list that names the GPU three times (host sum): every variant is the single-device result."""
+    from pvtrace_amd.engine import Heatmap, Recorder, _kernel, native
+
+    scene = scenes.bench_slab(recorders=False)
+    slab = scene.root.children[0]
+    slab.recorders = [Recorder("map", event="entering", histograms=[Heatmap("x", "y", (-2.5, 2.5, 100), (-2.5, 2.5, 100))]),
+                      Recorder("lost", event="lost"), Recorder("out", event="escaping")]
+    compiled = compile_scene(scene)
+    assert int(compiled.total_bins) == 10_000
+    pos, dirs, wl, _ = emit_bundle(scene, 20_000, seed=4)
+    lib = native.load_library()
+    one = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 1, 1, 0)
+    assert one["rec_bins"].sum() == one["rec_distinct"][0] > 10_000
+    monkeypatch.setenv("PVT_MULTI_REDUCE", "rccl")
+    for attempt in range(2):
+        forced = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 1, 1, 0, devices=[0])
+        assert lib.pvt_last_multi_reduce() == 2
+        assert_bundles_identical(forced, one, sums_rtol=1e-12, what=f"rccl, one rank, attempt {attempt}")
+    monkeypatch.setenv("PVT_MULTI_REDUCE", "host")
+    for devices in ([0], [0, 0, 0]):
+        host = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 1, 1, 0, devices=devices)
+        assert_bundles_identical(host, one, sums_rtol=1e-12, what=f"host sum, devices={devices}")
+    assert lib.pvt_last_multi_reduce() == 1
+    monkeypatch.delenv("PVT_MULTI_REDUCE")
+    thrice = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 1, 1, 0, devices=[0, 0, 0])
+    assert lib.pvt_last_multi_reduce() == 1            # a repeated id can never be an RCCL communicator: host sum
+    assert_bundles_identical(thrice, one, sums_rtol=1e-12, what="repeated device id")
+
+
 @pytest.mark.parametrize("emission", ["host", "device"])
 def test_simulate_over_a_device_list_equals_one_device(emission):
     scene = scenes.bench_slab(recorders=True)

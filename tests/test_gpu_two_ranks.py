@@ -111,6 +111,12 @@ def _check_two_rank_line(out):
     assert out["value"] == out["repeats"]["median"] and out["repeats"]["min"] <= out["value"] <= out["repeats"]["max"]
     eff = out["strong_scaling"]["predicted"]["efficiency"]
     assert 0.0 < eff["8"] <= eff["4"] <= eff["2"] <= 1.0
+    measured = out["strong_scaling"]["measured"]          # rank 0 alone against both ranks, same run
+    assert measured["n_gpus"] == 2 and measured["seconds_one_gpu"] > 0 and 0.0 < measured["efficiency"] < 10.0   # (two ranks on ONE GPU: not a speed-up)
+    assert len(out["strong_scaling"]["seconds_per_rank"]) == 2 and len(out["sustained"]["seconds_per_rank"]) == 2
+    assert "error" not in out
+    sizes = out["scene_scaling"]["sizes"]
+    assert sizes["tiles11"]["nodes"] == 122 and sizes["tiles11"]["node_grid"] and not sizes["tiles1"]["node_grid"]
     for name, per_rank in (("cfg4", 60000), ("cfg5", 60000)):   # the other configs: 3 bundles of 20 000 per rank
         leg = out["configs"][name]
         assert leg["value"] > 0 and leg["photons_per_gpu"] == per_rank and leg["kernel_ms_mean"] > 0
@@ -180,3 +186,26 @@ def test_bench_script_over_rccl_with_one_rank():
     assert out["strong_scaling"]["photons_tallied"] == 400001
     assert abs(out["tallies"]["entering"] + out["tallies"]["reflected"] - 1.0) < 1e-12
     assert out["configs"]["cfg4"]["sustained"]["value"] > 0 and out["configs"]["cfg5"]["value"] > 0
+
+
+@pytest.mark.timeout(1800)
+def test_rank_zero_still_prints_its_line_when_another_rank_is_lost_after_the_timed_region():
+    """the driver reads ONE line from rank 0.  A rank that dies after the contract's K steps (here:
+    made to, right after the main windows) must not take that line with it: rank 0 reports what it had measured,
+    with an `error` field naming the leg that failed."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, PVT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PVT_BENCH_DIE_AFTER_MAIN="1")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--photons", "20000", "--repeats", "2", "--sustained-s", "0.02", "--total-photons", "100001",
+           "--ray-buffers", "2", "--spinup-s", "0", "--no-cpu-baseline", "--config-photons", "60000", "--rccl-timeout-s", "30"]
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
+    assert lines, done.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["rccl_ranks"] == 2      # the timed region is all there
+    assert "error" in out and "leg" in out["error"]
+    assert done.returncode != 0
