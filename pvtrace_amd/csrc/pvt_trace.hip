@@ -1076,14 +1076,17 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
 template <bool RECORD, bool TAB_LDS, int SEENW>
 hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
     const bool mesh = a.bvh != nullptr;
-    if constexpr (TAB_LDS && (!PVT_DEV_VARIANTS || SEENW == 1)) {
+    if constexpr (TAB_LDS && (!PVT_DEV_VARIANTS || SEENW == 1) && PVT_DEV_VARIANTS != 2) {
         if (a.lay.grid_d >= 0 && !mesh && (!PVT_DEV_VARIANTS || !emit)) {   // many nodes: per-lane walk of the node grid
             if (emit && !PVT_DEV_VARIANTS) hipLaunchKernelGGL((trace_kernel_grid<RECORD, SEENW, !PVT_DEV_VARIANTS>), dim3(grid), dim3(kBlock), lds, st, a);
             else hipLaunchKernelGGL((trace_kernel_grid<RECORD, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
             return hipGetLastError();
         }
     }
-#if PVT_DEV_VARIANTS
+#if PVT_DEV_VARIANTS == 2   // developer builds of the MESH variants only (tables in LDS, <= 64 recorders, array input)
+    if (emit || !mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
+    if constexpr (TAB_LDS && SEENW == 1) hipLaunchKernelGGL((trace_kernel<RECORD, true, 1, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
+#elif PVT_DEV_VARIANTS
     if (emit || mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
     if constexpr (TAB_LDS && SEENW == 1) {
         if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, true, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);

@@ -21,6 +21,9 @@
 #ifndef PVT_WAVE_SCALAR
 #define PVT_WAVE_SCALAR 1
 #endif
+#ifndef PVT_MESH_FULL_LANES
+#define PVT_MESH_FULL_LANES 1   // lanes with full leaf slots that end a walk phase of the mesh walk
+#endif
 #ifndef PVT_LOG_STORES
 #define PVT_LOG_STORES 16   // bytes per store of an event record (8: from the value registers; 16: assembled vectors)
 #endif
@@ -1572,57 +1575,97 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     for (int a = 0; a < 3; a++) minv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
                     long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
                     int i = T.iu(node * NI + NI_MESH);
-                    const int end = A.bvh[i].skip;
-                    pvt::BvhNode b = A.bvh[i];   // 32 bytes: two 16-byte loads
-                    while (i < end) {
-                        // the successor after a HIT is the next record (depth-first order): fetched while this box is
-                        // tested (one record past the array's end exists: the host appends a sentinel)
-                        const pvt::BvhNode nxt = A.bvh[i + 1];
-                        double tmin = -INFINITY, tmax = INFINITY;
+                    // (the two table pointers in registers for the walk: the build keeps loop invariants where they are used --
+                    // good for the photon loop as a whole, but here that is a scalar load of the kernel argument, and a wait
+                    // for it, in every iteration of the walk)
+                    const pvt::BvhNode* bvh = A.bvh;
+                    const pvt::MeshTri* tris = A.tris;
+                    asm volatile("" : "+s"(bvh), "+s"(tris));
+                    const int end = bvh[i].skip;
+                    pvt::BvhNode b = bvh[i];   // 32 bytes: two 16-byte loads
+                    // The triangle tests are DEFERRED: a lane that reaches a leaf only notes it (four slots in registers) and
+                    // walks on until its slots are full; when every lane of the wave has stopped -- slots full or walk
+                    // over -- the notes are worked off together, every lane on one of its leaves at once, and the walks
+                    // resume.  Tested inside the walk, the watertight
+                    // test (185 vector instructions against the 50 of a box) ran in four iterations out of five for
+                    // the one or two lanes that happened to stand at a leaf.  (Crossings are ordered by (t, face): the
+                    // order they are found in does not matter.)
+                    // (A mesh of a few triangles -- a tree of a handful of nodes, leaves of up to eight triangles -- has no
+                    // walk to speak of to keep going: its leaves are tested as they are met.  Wave-uniform: the node is.)
+                    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;
+                    const int qcap = end - i <= 15 ? 1 : 4;
+                    for (;;) {
+                        // ---- walk: every lane goes on until its walk is over or its slots are full
+                        for (;;) {
+                            const bool go = i < end && qn < qcap;
+                            if (__ballot(go) == 0ull || __popcll(__ballot(i < end && qn >= qcap)) >= PVT_MESH_FULL_LANES) break;
+                            if (go) {
+                                // the successor after a HIT is the next record (depth-first order): fetched while this box
+                                // is tested (one record past the array's end exists: the host appends a sentinel)
+                                const pvt::BvhNode nxt = bvh[i + 1];
+                                double tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
-                        for (int a = 0; a < 3; a++) {
-                            const double ta = ((double)b.lo[a] - oo[a]) * minv[a], tb = ((double)b.hi[a] - oo[a]) * minv[a];
-                            tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
-                            tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
-                        }
-                        if (tmax < tmin || tmax < 0.0) { i = b.skip; if (i < end) b = A.bvh[i]; continue; }
-                        const int tn = b.leaf & 15, tri_start = b.leaf >> 4;
-                        const pvt::MeshTri* tr = A.tris + tri_start;
-                        for (int k = 0; k < tn; k++, tr++) {
-                            double va[3], vb[3], vc[3];
-#pragma unroll
-                            for (int a = 0; a < 3; a++) {
-                                va[a] = tr->v[a] - oo[a]; vb[a] = tr->v[3 + a] - oo[a]; vc[a] = tr->v[6 + a] - oo[a];
+                                for (int a = 0; a < 3; a++) {
+                                    const double ta = ((double)b.lo[a] - oo[a]) * minv[a], tb = ((double)b.hi[a] - oo[a]) * minv[a];
+                                    tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
+                                    tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                                }
+                                if (tmax < tmin || tmax < 0.0) {
+                                    i = b.skip;
+                                    if (i < end) b = bvh[i];
+                                } else {
+                                    if ((b.leaf & 15) != 0) {   // a leaf: its triangles later (the newest note first: any order will do)
+                                        q3 = q2; q2 = q1; q1 = q0; q0 = b.leaf;
+                                        qn += 1;
+                                    }
+                                    i += 1;
+                                    b = nxt;
+                                }
                             }
-                            const double az_ = pick(va, kz), bz_ = pick(vb, kz), cz_ = pick(vc, kz);
-                            const double axs = pick(va, kx) - shx * az_, ays = pick(va, ky) - shy * az_;
-                            const double bxs = pick(vb, kx) - shx * bz_, bys = pick(vb, ky) - shy * bz_;
-                            const double cxs = pick(vc, kx) - shx * cz_, cys = pick(vc, ky) - shy * cz_;
-                            const double u = cxs * bys - cys * bxs;
-                            const double v = axs * cys - ays * cxs;
-                            const double w = bxs * ays - bys * axs;
-                            if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) continue;
-                            const double det = u + v + w;
-                            if (det == 0.0) continue;
-                            const double sg = det < 0.0 ? -1.0 : 1.0;
-                            auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
-                            if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) continue;
-                            if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) continue;
-                            if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
-                            const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
-                            if (!(t > kEps)) continue;
-                            const long long face = tr->face;
-                            const int tri = tri_start + k;
-                            if (nl == 0 || t < tfirst) tfirst = t;
-                            nl += 1;
-                            if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
-                            else if (t < t1 || (t == t1 && f1 >= 0 && face < f1)) {
-                                t2 = t1; n2 = n1; f2 = f1; t1 = t; n1 = node; tri1 = tri; f1 = face;
-                            } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
-                            nhits += 1;
                         }
-                        i += 1;
-                        b = nxt;
+                        // ---- the noted leaves, every lane on one of its own at a time
+                        while (__ballot(qn > 0) != 0ull) {
+                            if (qn > 0) {
+                                const int leaf = q0;
+                                q0 = q1; q1 = q2; q2 = q3; qn -= 1;
+                                const int tn = leaf & 15, tri_start = leaf >> 4;
+                                const pvt::MeshTri* tr = tris + tri_start;
+                                for (int k = 0; k < tn; k++, tr++) {
+                                    double va[3], vb[3], vc[3];
+#pragma unroll
+                                    for (int a = 0; a < 3; a++) {
+                                        va[a] = tr->v[a] - oo[a]; vb[a] = tr->v[3 + a] - oo[a]; vc[a] = tr->v[6 + a] - oo[a];
+                                    }
+                                    const double az_ = pick(va, kz), bz_ = pick(vb, kz), cz_ = pick(vc, kz);
+                                    const double axs = pick(va, kx) - shx * az_, ays = pick(va, ky) - shy * az_;
+                                    const double bxs = pick(vb, kx) - shx * bz_, bys = pick(vb, ky) - shy * bz_;
+                                    const double cxs = pick(vc, kx) - shx * cz_, cys = pick(vc, ky) - shy * cz_;
+                                    const double u = cxs * bys - cys * bxs;
+                                    const double v = axs * cys - ays * cxs;
+                                    const double w = bxs * ays - bys * axs;
+                                    if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) continue;
+                                    const double det = u + v + w;
+                                    if (det == 0.0) continue;
+                                    const double sg = det < 0.0 ? -1.0 : 1.0;
+                                    auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
+                                    if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) continue;
+                                    if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) continue;
+                                    if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
+                                    const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
+                                    if (!(t > kEps)) continue;
+                                    const long long face = tr->face;
+                                    const int tri = tri_start + k;
+                                    if (nl == 0 || t < tfirst) tfirst = t;
+                                    nl += 1;
+                                    if (nhits == 0) { t1 = t; n1 = node; tri1 = tri; f1 = face; }
+                                    else if (t < t1 || (t == t1 && f1 >= 0 && face < f1)) {
+                                        t2 = t1; n2 = n1; f2 = f1; t1 = t; n1 = node; tri1 = tri; f1 = face;
+                                    } else if (n2 < 0 || t < t2 || (t == t2 && f2 >= 0 && face < f2)) { t2 = t; n2 = node; f2 = face; }
+                                    nhits += 1;
+                                }
+                            }
+                        }
+                        if (__ballot(i < end) == 0ull) break;
                     }
                 } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
                 double tmin = -INFINITY, tmax = INFINITY;
