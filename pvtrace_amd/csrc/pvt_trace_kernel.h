@@ -509,6 +509,21 @@ __device__ __forceinline__ void emit_one(const KArgs& A, unsigned long long gi, 
     dir.z = m[8] * ld.x + m[9] * ld.y + m[10] * ld.z;
 }
 
+// The sampler as a FUNCTION (trace kernels, device emission): called by the wave that claims a chunk of rays, once per 64
+// rays -- its 15 KB of code then sit beside the trace kernel's text instead of inside it (every EMIT variant as large
+// as its array-input twin plus a call), at the price of the caller's live registers going through scratch around the call.
+#ifndef PVT_EMIT_CALL
+#define PVT_EMIT_CALL 1
+#endif
+__device__ __attribute__((noinline)) void emit_chunk(const KArgs* A, unsigned long long gi, double* pool) {
+    V3 ep, ed;
+    double ew;
+    emit_one(*A, gi, ep, ed, ew);
+    pool[0] = ep.x; pool[64] = ep.y; pool[128] = ep.z;
+    pool[192] = ed.x; pool[256] = ed.y; pool[320] = ed.z;
+    pool[384] = ew;
+}
+
 __global__ void __launch_bounds__(kBlock) emit_kernel(KArgs A, double* opos, double* odir, double* owl) {
     unsigned int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= A.n_rays) return;
@@ -1024,13 +1039,18 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     unsigned int lane_here = (unsigned int)lane;
                     asm volatile("" : "+v"(lane_here));
                     if (b + lane_here < w_end) {
+                        double* pool = ak->emit_pool + ((unsigned long long)blockIdx.x * kWaves + (unsigned long long)wave) * (7 * 64) + lane_here;
+                        const unsigned long long gi_ = A.ray_offset + (unsigned long long)ray_lo + (unsigned long long)b + (unsigned long long)lane_here;
+#if PVT_EMIT_CALL
+                        emit_chunk((const KArgs*)ak, gi_, pool);
+#else
                         V3 ep, ed;
                         double ew;
-                        emit_one(A, A.ray_offset + (unsigned long long)ray_lo + (unsigned long long)b + (unsigned long long)lane_here, ep, ed, ew);
-                        double* pool = ak->emit_pool + ((unsigned long long)blockIdx.x * kWaves + (unsigned long long)wave) * (7 * 64) + lane_here;
+                        emit_one(A, gi_, ep, ed, ew);
                         pool[0] = ep.x; pool[64] = ep.y; pool[128] = ep.z;
                         pool[192] = ed.x; pool[256] = ed.y; pool[320] = ed.z;
                         pool[384] = ew;
+#endif
                     }
                 }
                 if (seed_pool) {

@@ -48,12 +48,13 @@ def test_register_budgets_of_the_built_kernels(tmp_path):
     for name, m in kernels.items():
         if "trace_kernel" not in name:                       # emit / unpack / pack / self-test kernels
             assert m["vgpr_spill_count"] == 0 and m["sgpr_spill_count"] == 0, (name, m)
-    # Code size against the 64 KB instruction cache a pair of CUs shares.  Array-input variants: the whole kernel within
-    # 58 KB.  Emitter variants carry the light sampler (~15 KB) on top, but OUTSIDE the step loop: a wave runs it once
-    # per 64 rays it claims (inlined into the refill it ran every iteration: -6 ... -16 % throughput)
+    # Code size against the 64 KB instruction cache a pair of CUs shares: every variant of analytic scenes within 58 KB,
+    # the emitter variants included -- the light sampler is a FUNCTION of its own (`emit_chunk`, 14 KB),
+    # called by the wave that claims a chunk of rays, not code inlined into the step loop (where it ran every iteration:
+    # -6 ... -16 % throughput) or into the kernel's text (66-69 KB)
     for name, m in {**analytic, **grid}.items():
-        emitter = name.endswith("ELb1EEEvNS_5KArgsE")
-        assert m["text_bytes"] <= (70 if emitter else 58) * 1024, (name, m)
+        assert m["text_bytes"] <= 58 * 1024, (name, m)
+        assert m["private_segment_fixed_size"] == 0 or "ELi4E" in name, (name, m)   # the call costs no scratch
 
 
 def test_build_warns_when_the_headline_variant_leaves_its_budget():
