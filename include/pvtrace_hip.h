@@ -303,6 +303,9 @@ int pvt_scene_carry_pending(PvtScene* scene, void* stream);
 /* Forget the photons parked on `stream` (a job abandoned half-way: an exception between two bundles, a consumer that
  * went away).  The next launch on the stream then starts from its own rays alone. */
 int pvt_scene_carry_discard(PvtScene* scene, void* stream);
+/* A scene that is put aside for later (a cache of resident scenes): frees the staging buffers of pvt_trace_device (up to
+ * 1 GiB per stream that asked for column arrays) and forgets parked photons on every stream.  The tables stay. */
+int pvt_scene_trim(PvtScene* scene);
 
 /* Records -> column arrays (all DEVICE pointers), one coalesced pass; `prefill` != 0 also writes the
  * reference's fill values (0 / -1) into the rows no event reached, else those rows are left alone.

@@ -1412,6 +1412,21 @@ int pvt_scene_carry_discard(PvtScene* s, void* stream) {
     return PVT_OK;
 }
 
+int pvt_scene_trim(PvtScene* s) {
+    if (!s) return fail(PVT_ERR_INVALID, "null scene");
+    std::lock_guard<std::mutex> lock(s->slot_mutex);
+    bool any = false;
+    for (auto* b : s->stage) any = any || b != nullptr;
+    if (any) {
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipDeviceSynchronize());   // (an unpack pass may still read a staging buffer)
+        for (size_t k = 0; k < s->stage.size(); k++)
+            if (s->stage[k]) { (void)hipFree(s->stage[k]); s->stage[k] = nullptr; s->stage_bytes[k] = 0; }
+    }
+    for (auto& c : s->carry) { c.pending = false; c.bound = 0; }   // a scene put aside carries nobody's photons
+    return PVT_OK;
+}
+
 int pvt_unpack_records_device(const PvtEventRecords* rec, int64_t n_recorded, int32_t max_events,
                               const PvtEventLog* out, int prefill, void* stream) {
     if (!rec || !out || !rec->rows || !rec->counts || n_recorded < 0 || max_events < 1)

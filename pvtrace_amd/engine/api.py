@@ -407,6 +407,7 @@ def _release_scene(key, dscene):
         dscene.close()
         return
     evicted = None
+    dscene.trim()   # a scene put aside keeps its tables only: no staging buffers, nobody's parked photons
     with _RESIDENT_LOCK:
         _RESIDENT.append((key, dscene))
         if len(_RESIDENT) > _RESIDENT_MAX:

@@ -233,6 +233,7 @@ def declare_signatures(lib, names):
              C.POINTER(PvtEventRecords), vp], C.c_int),
         "pvt_scene_carry_pending": ([vp, vp], C.c_int),
         "pvt_scene_carry_discard": ([vp, vp], C.c_int),
+        "pvt_scene_trim": ([vp], C.c_int),
         "pvt_last_multi_reduce": ([], C.c_int),
         "pvt_unpack_records_device": (
             [C.POINTER(PvtEventRecords), C.c_int64, C.c_int32, C.POINTER(PvtEventLog), C.c_int, vp], C.c_int),
@@ -269,7 +270,7 @@ ABI_SYMBOLS = (
     "pvt_scene_set_emitter", "pvt_scene_destroy", "pvt_trace_device", "pvt_trace_bundle",
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
     "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
-    "pvt_scene_carry_pending", "pvt_last_multi_reduce", "pvt_node_grid_plan", "pvt_scene_carry_discard",
+    "pvt_scene_carry_pending", "pvt_last_multi_reduce", "pvt_node_grid_plan", "pvt_scene_carry_discard", "pvt_scene_trim",
 )
 
 _lib = None
@@ -584,6 +585,10 @@ class DeviceScene:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         return bool(self.lib.pvt_scene_carry_pending(self.handle, C.c_void_p(stream)))
+
+    def trim(self):
+        """Before the scene is put aside for reuse: free staging buffers, forget parked photons (pvt_scene_trim)."""
+        check(self.lib.pvt_scene_trim(self.handle), "pvt_scene_trim")
 
     def carry_discard(self, stream=None):
         """Forget the photons parked on `stream` (an abandoned job)."""
