@@ -9,10 +9,13 @@
 // face id) so a leaf is one contiguous run of 104-byte records.  Nodes are 32 bytes (f32 boxes
 // rounded outwards): culling is only a filter, the triangle test itself stays f64.
 //
-// The boxes are padded by 1e-7 of the mesh diagonal: culling must be conservative with respect
-// to the (differently rounded) watertight triangle test, so that the set of crossings found
-// through the BVH equals the set a brute-force loop over the faces finds (which is what
-// oracle/pvt_oracle.c does) bit for bit.
+// The boxes are stored RELATIVE TO THE CENTRE of the mesh's bounding box and padded by 4e-6 of its diagonal:
+// the kernel tests them in f32 against a ray re-originated at its entry into the root box, so every
+// quantity of the test is of the mesh's own size and the test's rounding displaces a plane by at most ~5e-7
+// of the diagonal (four roundings of 2^-24 relative, on differences of at most two diagonals).  Culling must
+// be conservative with respect to the exact (f64) watertight triangle test, so that the set of crossings
+// found through the BVH equals the set a brute-force loop over the faces finds (which is what
+// oracle/pvt_oracle.c does) bit for bit: the padding is eight times the rounding.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -23,7 +26,7 @@
 namespace pvt {
 
 struct BvhNode {      // 32 bytes: two nodes per 64-byte line, half the traffic of f64 boxes
-    float lo[3], hi[3];   // box rounded OUTWARDS to f32 (after the padding below): still conservative
+    float lo[3], hi[3];   // box relative to the mesh's centre, padded, rounded OUTWARDS to f32: still conservative
     int skip;             // next node when this subtree is culled or finished
     int leaf;             // leaves: (first triangle record << 4) | triangle count (1..8); inner: 0
 };
@@ -44,8 +47,9 @@ public:
                std::vector<BvhNode>& nodes, std::vector<MeshTri>& tris)
         : v_(vertices), f_(faces), n_(normals), nodes_(nodes), tris_(tris) {}
 
-    // Adds the BVH of faces [f0, f0 + count) and returns the index of its root node.
-    int add_mesh(int f0, int count) {
+    // Adds the BVH of faces [f0, f0 + count) and returns the index of its root node; `centre` (nullable) receives
+    // the point the boxes are relative to.
+    int add_mesh(int f0, int count, double* centre = nullptr) {
         order_.resize(count);
         std::iota(order_.begin(), order_.end(), f0);
         cx_.resize(3 * (size_t)count);
@@ -65,7 +69,11 @@ public:
         }
         double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
                                 (hi[2] - lo[2]) * (hi[2] - lo[2]));
-        pad_ = 1e-7 * diag + 1e-300;
+        pad_ = 4e-6 * diag + 1e-300;
+        for (int a = 0; a < 3; a++) {
+            c_[a] = 0.5 * (lo[a] + hi[a]);
+            if (centre) centre[a] = c_[a];
+        }
         f0_ = f0;
         leaf_ = count <= kSmallMesh ? kSmallLeaf : kLargeLeaf;
         const int root = (int)nodes_.size();
@@ -92,8 +100,8 @@ private:
         double lo[3], hi[3];
         bounds(begin, end, lo, hi);
         for (int a = 0; a < 3; a++) {
-            nodes_[me].lo[a] = std::nextafter((float)(lo[a] - pad_), -INFINITY);   // (float) rounds to nearest:
-            nodes_[me].hi[a] = std::nextafter((float)(hi[a] + pad_), INFINITY);    // one more step outwards
+            nodes_[me].lo[a] = std::nextafter((float)(lo[a] - pad_ - c_[a]), -INFINITY);   // (float) rounds to nearest:
+            nodes_[me].hi[a] = std::nextafter((float)(hi[a] + pad_ - c_[a]), INFINITY);    // one more step outwards
         }
         if (end - begin <= leaf_) {
             nodes_[me].leaf = ((int)tris_.size() << 4) | (end - begin);
@@ -205,6 +213,7 @@ private:
     std::vector<int> order_;
     std::vector<double> cx_;
     double pad_ = 0.0;
+    double c_[3] = {0.0, 0.0, 0.0};
     int f0_ = 0;
     int leaf_ = kLargeLeaf;
 };

@@ -786,8 +786,10 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         q[NI_NCLS] = idx_class[n];
         if (t->geom_type[n] == PVT_GEOM_MESH) {
             const int f0 = t->mesh_face_start[n], fc = t->mesh_face_count[n];
+            double centre[3];
             q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris)
-                             .add_mesh(f0, fc);
+                             .add_mesh(f0, fc, centre);
+            for (int c = 0; c < 3; c++) d[ND_PARAMS + c] = centre[c];   // a mesh has no shape parameters: the point its boxes are relative to
         }
     }
     for (int rc = 0; rc < CR; rc++) {
@@ -1550,7 +1552,8 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
     if (fc <= 0 || f0 < 0 || f0 + fc > t->n_mesh_faces) return fail(PVT_ERR_INVALID, "mesh face range out of bounds");
     std::vector<pvt::BvhNode> nodes;
     std::vector<pvt::MeshTri> tris;
-    const int root = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, nodes, tris).add_mesh(f0, fc);
+    double centre[3];
+    const int root = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, nodes, tris).add_mesh(f0, fc, centre);
     if (root != 0 || nodes.empty() || nodes[0].skip != (int)nodes.size()) return fail(PVT_ERR_INVALID, "root skip link");
     std::vector<int> seen(fc, 0);
     int leaves = 0, max_depth = 0;
@@ -1578,7 +1581,7 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
                     for (int a = 0; a < 3; a++) {
                         if (tr.v[3 * c + a] != t->mesh_vertices[3 * (size_t)t->mesh_faces[3 * (size_t)tr.face + c] + a])
                             return fail(PVT_ERR_INVALID, "gathered vertex differs from the table");
-                        if (tr.v[3 * c + a] < b.lo[a] || tr.v[3 * c + a] > b.hi[a])
+                        if (tr.v[3 * c + a] - centre[a] < b.lo[a] || tr.v[3 * c + a] - centre[a] > b.hi[a])
                             return fail(PVT_ERR_INVALID, "triangle outside its leaf box");
                     }
             }

@@ -1584,7 +1584,19 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     auto pick = [](const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
                     const double dz = pick(dd, kz);
                     if (dz < 0.0) { int tmp = kx; kx = ky; ky = tmp; }
-                    const double shx = pick(dd, kx) / dz, shy = pick(dd, ky) / dz, shz = 1.0 / dz;
+                    // (the shear constants feed the exact triangle test: the short division sequences give RN(x / dz) and RN(1 / dz)
+                    // bit for bit when dz -- the dominant direction component -- is an ordinary number and the numerators are zero
+                    // or not tiny, which a wave checks once; anything else takes the general divisions)
+                    double shx, shy, shz;
+                    {
+                        const double sx_ = pick(dd, kx), sy_ = pick(dd, ky);
+                        auto ordinary = [](double x) { return x == 0.0 || (pvt_fabs(x) > 1e-280 && pvt_fabs(x) < 1e280); };
+                        if (__ballot(!(pvt_fabs(dz) > 1e-100 && pvt_fabs(dz) < 1e100) || !ordinary(sx_) || !ordinary(sy_)) == 0ull) {
+                            shx = div_normal(sx_, dz); shy = div_normal(sy_, dz); shz = rcp_normal(dz);
+                        } else {
+                            shx = sx_ / dz; shy = sy_ / dz; shz = 1.0 / dz;
+                        }
+                    }
                     // Box culling only has to be conservative (a false hit costs a triangle test, a
                     // false miss would lose a crossing).  A ray parallel to a slab gets a huge finite
                     // reciprocal instead of inf: inside the slab the two plane distances then have
@@ -1592,17 +1604,40 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // of range, or a harmless false hit), and 0 * inf = NaN can never arise.
                     double minv[3];
 #pragma unroll
-                    for (int a = 0; a < 3; a++) minv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : 1.0 / dd[a];
+                    for (int a = 0; a < 3; a++) minv[a] = pvt_fabs(dd[a]) < 1e-300 ? 1e300 : rcp_normal(dd[a]);   // (culling only)
                     long long f1 = -1, f2 = -1;   // faces of this node's entries in (t1, t2)
                     int i = T.iu(node * NI + NI_MESH);
                     // (the two table pointers in registers for the walk: the build keeps loop invariants where they are used --
                     // good for the photon loop as a whole, but here that is a scalar load of the kernel argument, and a wait
                     // for it, in every iteration of the walk)
+                    // (the record after a hit is the next one in memory and is named before the test -- the compiler issues that
+                    // load after the test all the same, one load per iteration whatever the outcome: measured faster than
+                    // forcing it early, which spends a second load on every culled inner node)
                     const pvt::BvhNode* bvh = A.bvh;
                     const pvt::MeshTri* tris = A.tris;
                     asm volatile("" : "+s"(bvh), "+s"(tris));
-                    const int end = bvh[i].skip;
+                    int end = bvh[i].skip;
                     pvt::BvhNode b = bvh[i];   // 32 bytes: two 16-byte loads
+                    // The boxes are tested in f32, relative to the mesh's centre (the node's parameter slots) and from where
+                    // the ray ENTERS the root box -- every quantity then has the mesh's own size, the test's rounding displaces
+                    // a plane by < 5e-7 of the mesh's diagonal, and the host pads every box by 4e-6 of it (pvt_bvh.h).
+                    float of[3], invf[3];
+                    {
+                        double t_near = 0.0, t_far = INFINITY;
+                        const double cc[3] = {gpar[0], gpar[1], gpar[2]};
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const double ta = (((double)b.lo[a] + cc[a]) - oo[a]) * minv[a], tb = (((double)b.hi[a] + cc[a]) - oo[a]) * minv[a];
+                            t_near = __builtin_fmax(t_near, __builtin_fmin(ta, tb));
+                            t_far = __builtin_fmin(t_far, __builtin_fmax(ta, tb));
+                        }
+                        if (t_far < t_near) end = i;   // the ray misses the mesh's box altogether
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            of[a] = (float)((oo[a] - cc[a]) + dd[a] * t_near);
+                            invf[a] = pvt_fabs(dd[a]) < 1e-20 ? 1e20f : (float)minv[a];   // (a component this small: the ray is parallel to the pair of planes)
+                        }
+                    }
                     // The triangle tests are DEFERRED: a lane that reaches a leaf only notes it (four slots in registers) and
                     // walks on until its slots are full; when every lane of the wave has stopped -- slots full or walk
                     // over -- the notes are worked off together, every lane on one of its leaves at once, and the walks
@@ -1623,14 +1658,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                                 // the successor after a HIT is the next record (depth-first order): fetched while this box
                                 // is tested (one record past the array's end exists: the host appends a sentinel)
                                 const pvt::BvhNode nxt = bvh[i + 1];
-                                double tmin = -INFINITY, tmax = INFINITY;
+                                float tmin = 0.0f, tmax = INFINITY;
 #pragma unroll
                                 for (int a = 0; a < 3; a++) {
-                                    const double ta = ((double)b.lo[a] - oo[a]) * minv[a], tb = ((double)b.hi[a] - oo[a]) * minv[a];
-                                    tmin = __builtin_fmax(tmin, __builtin_fmin(ta, tb));
-                                    tmax = __builtin_fmin(tmax, __builtin_fmax(ta, tb));
+                                    const float ta = (b.lo[a] - of[a]) * invf[a], tb = (b.hi[a] - of[a]) * invf[a];
+                                    tmin = __builtin_fmaxf(tmin, __builtin_fminf(ta, tb));
+                                    tmax = __builtin_fminf(tmax, __builtin_fmaxf(ta, tb));
                                 }
-                                if (tmax < tmin || tmax < 0.0) {
+                                if (tmax < tmin) {
                                     i = b.skip;
                                     if (i < end) b = bvh[i];
                                 } else {
@@ -1663,14 +1698,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                                     const double u = cxs * bys - cys * bxs;
                                     const double v = axs * cys - ays * cxs;
                                     const double w = bxs * ays - bys * axs;
-                                    if ((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) continue;
+                                    // (one flag instead of a chain of exits: every lane of the trip is on a triangle of its own, and each
+                                    // early exit was a pair of exec-mask instructions and a branch for all of them)
                                     const double det = u + v + w;
-                                    if (det == 0.0) continue;
-                                    const double sg = det < 0.0 ? -1.0 : 1.0;
-                                    auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
-                                    if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) continue;
-                                    if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) continue;
-                                    if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) continue;
+                                    bool ok = !((u < 0.0 || v < 0.0 || w < 0.0) && (u > 0.0 || v > 0.0 || w > 0.0)) && det != 0.0;
+                                    // exact zeros of an edge function (a ray through an edge or a vertex): the ownership rule, only when a
+                                    // lane of the wave has one
+                                    if (__ballot(ok && (u == 0.0 || v == 0.0 || w == 0.0)) != 0ull) {
+                                        const double sg = det < 0.0 ? -1.0 : 1.0;
+                                        auto owned = [](double gx, double gy) { return gx > 0.0 || (gx == 0.0 && gy > 0.0); };
+                                        if (u == 0.0 && !owned(sg * (cys - bys), sg * (bxs - cxs))) ok = false;
+                                        if (v == 0.0 && !owned(sg * (ays - cys), sg * (cxs - axs))) ok = false;
+                                        if (w == 0.0 && !owned(sg * (bys - ays), sg * (axs - bxs))) ok = false;
+                                    }
+                                    if (!ok) continue;
                                     const double t = (u * (shz * az_) + v * (shz * bz_) + w * (shz * cz_)) / det;
                                     if (!(t > kEps)) continue;
                                     const long long face = tr->face;
