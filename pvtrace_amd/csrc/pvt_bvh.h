@@ -25,7 +25,7 @@
 
 namespace pvt {
 
-struct BvhNode {      // 32 bytes: two nodes per 64-byte line, half the traffic of f64 boxes
+struct alignas(16) BvhNode {      // 32 bytes: two nodes per 64-byte line, half the traffic of f64 boxes
     float lo[3], hi[3];   // box relative to the mesh's centre, padded, rounded OUTWARDS to f32: still conservative
     int skip;             // next node when this subtree is culled or finished
     int leaf;             // leaves: (first triangle record << 4) | triangle count (1..8); inner: 0
@@ -217,5 +217,92 @@ private:
     int f0_ = 0;
     int leaf_ = kLargeLeaf;
 };
+
+// ---- the top of the trees, for LDS ------------------------------------------------------------------------
+// The kernel's walk waits for its records far longer than it computes with them, and every ray passes the top
+// levels of a tree.  `stage_top` picks, for every tree, the levels that fit a budget of records (small trees
+// whole, the rest sharing what is left), copies them -- in depth-first order, so the successor after a hit is
+// still the next record -- to `top`, the image a workgroup loads into LDS, and re-writes the links:
+//   * a cursor / link is a record's index in `nodes`, or kTopFlag | slot in `top`; the tree's end stays what it was
+//     (the root's old skip link: the walk is over when the cursor equals it);
+//   * `skip` of every record, in both arrays, names its target in that form (a skip link leads to a sibling or to
+//     an ancestor's sibling -- never deeper than its source -- so links INTO the copy come from everywhere, links
+//     out of it only from its last level);
+//   * an inner record on the copy's last level names its first child -- record i + 1 of `nodes` -- in `leaf`
+//     as (i + 1) << 4 (count bits zero: still not a leaf); other inner records of the copy keep 0: next slot;
+//   * the root's record in `nodes` (never walked when a copy exists) names its slot in `leaf` as (slot + 1) << 4.
+// Trees without a copy (no budget, or a single leaf) are left as they were.  Results never depend on any of this.
+constexpr int kTopFlag = 1 << 30;
+
+inline void stage_top(std::vector<BvhNode>& nodes, const std::vector<int>& roots, size_t budget, std::vector<BvhNode>& top) {
+    top.clear();
+    struct Tree { int root, end; std::vector<int> depth; std::vector<size_t> per_level; };
+    std::vector<Tree> trees;
+    for (int r : roots) {
+        Tree t{r, nodes[r].skip, {}, {}};
+        if ((nodes[r].leaf & 15) != 0) continue;   // a single leaf
+        t.depth.resize(t.end - r);
+        std::vector<int> open_end;
+        for (int i = r; i < t.end; i++) {
+            while (!open_end.empty() && open_end.back() <= i) open_end.pop_back();
+            const size_t d = open_end.size();
+            t.depth[i - r] = (int)d;
+            if (t.per_level.size() <= d) t.per_level.resize(d + 1, 0);
+            t.per_level[d] += 1;
+            if ((nodes[i].leaf & 15) == 0) open_end.push_back(nodes[i].skip);
+        }
+        trees.push_back(std::move(t));
+    }
+    // small trees first: what they leave of their share goes to the larger ones
+    std::vector<size_t> by_size(trees.size());
+    std::iota(by_size.begin(), by_size.end(), (size_t)0);
+    std::sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) {
+        const int na = trees[a].end - trees[a].root, nb = trees[b].end - trees[b].root;
+        return na < nb || (na == nb && a < b);
+    });
+    std::vector<int> last_level(trees.size(), -1);
+    size_t left = budget;
+    for (size_t k = 0; k < by_size.size(); k++) {
+        const Tree& t = trees[by_size[k]];
+        const size_t share = left / (by_size.size() - k);
+        size_t count = 0;
+        int L = -1;
+        for (size_t d = 0; d < t.per_level.size() && count + t.per_level[d] <= share; d++) { count += t.per_level[d]; L = (int)d; }
+        if (L < 1) continue;   // (the root alone is not worth a copy)
+        last_level[by_size[k]] = L;
+        left -= count;
+    }
+    for (size_t k = 0; k < trees.size(); k++) {   // (slots in scene order)
+        const Tree& t = trees[k];
+        const int L = last_level[k];
+        if (L < 0) continue;
+        const int base = (int)top.size();
+        std::vector<int> slot(t.end - t.root, -1);
+        int next = base;
+        for (int i = t.root; i < t.end; i++)
+            if (t.depth[i - t.root] <= L) slot[i - t.root] = next++;
+        for (int i = t.root; i < t.end; i++) {
+            const int target = nodes[i].skip;
+            const int link = target == t.end ? t.end : (slot[target - t.root] >= 0 ? (kTopFlag | slot[target - t.root]) : target);
+            nodes[i].skip = link;
+            if (slot[i - t.root] >= 0) {
+                BvhNode b = nodes[i];
+                if ((b.leaf & 15) == 0 && t.depth[i - t.root] == L) b.leaf = (i + 1) << 4;
+                top.push_back(b);
+            }
+        }
+        nodes[t.root].leaf = (base + 1) << 4;
+    }
+}
+
+// What the kernel's walk does with a cursor, restated for the host-side check of `stage_top` (pvt_mesh_bvh_check):
+// the record a cursor names, and the cursor after it for a hit / a miss.
+inline const BvhNode& at_cursor(const std::vector<BvhNode>& nodes, const std::vector<BvhNode>& top, int cursor) {
+    return (cursor & kTopFlag) ? top[cursor & ~kTopFlag] : nodes[cursor];
+}
+inline int next_cursor(const BvhNode& b, int cursor, bool hit) {
+    if (!hit || (b.leaf & 15) != 0) return b.skip;
+    return b.leaf != 0 ? (b.leaf >> 4) : cursor + 1;
+}
 
 }  // namespace pvt

@@ -99,6 +99,9 @@ struct PvtScene {
     int* d_ei = nullptr;
     pvt::BvhNode* d_bvh = nullptr;      // triangle meshes: BVH nodes + gathered triangles
     pvt::MeshTri* d_tris = nullptr;
+    pvt::BvhNode* d_bvh_top = nullptr;  // the top levels of the trees as a workgroup copies them to LDS (pvt_bvh.h: stage_top)
+    int top_n = 0;                      // ... records of it
+    int meshq = 0;                      // leaves a lane of a mesh walk notes in LDS before their triangles are tested (1 or kMeshQ)
     unsigned int* d_set_cursor = nullptr;   // kCursorSlots x kMaxSets cursors: launches with tally sets
     unsigned int* d_cursor = nullptr;   // kCursorSlots cursors (64 B apart), one per stream: launches on
                                         // different streams may overlap, each needs its own
@@ -137,6 +140,11 @@ struct PvtScene {
     bool consolidate = true;        // developer switches (environment), read once at scene creation
     double dev_blocks_per_cu = 0.0;
 };
+
+namespace {
+struct LdsPlan { size_t bytes; bool tab_lds; int bins_in_lds, xslots, tq_pos; bool ok; };
+LdsPlan plan_lds(const PvtScene* s, bool record);   // (defined with the launch code)
+}  // namespace
 
 extern "C" {
 
@@ -427,6 +435,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     const int N = t->n_nodes, C = t->n_components, R = t->n_recorders, H = t->n_hists, K = t->n_coatings;
     std::vector<pvt::BvhNode> bvh_nodes;
     std::vector<pvt::MeshTri> bvh_tris;
+    std::vector<int> bvh_roots;
     for (int n = 0; n < N; n++) {
         const int g = t->geom_type[n];
         if (g < PVT_GEOM_BOX || g > PVT_GEOM_MESH) return fail(PVT_ERR_INVALID, "unknown geometry type");
@@ -789,6 +798,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             double centre[3];
             q[NI_MESH] = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, bvh_nodes, bvh_tris)
                              .add_mesh(f0, fc, centre);
+            bvh_roots.push_back(q[NI_MESH]);
             for (int c = 0; c < 3; c++) d[ND_PARAMS + c] = centre[c];   // a mesh has no shape parameters: the point its boxes are relative to
         }
     }
@@ -986,7 +996,29 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMemset(s->d_cursor, 0, 64 * kCursorSlots + 256));
     HIP_TRY(hipMalloc(&s->d_set_cursor, (size_t)kCursorSlots * kMaxSets * 4));
     if (!bvh_nodes.empty()) {
-        bvh_nodes.push_back(pvt::BvhNode{});   // sentinel: the walk fetches one record ahead of the one it tests
+        // a lane of a walk notes kMeshQ leaves before their triangles are tested -- one, in trees of a handful of records
+        // (the kernel applies the same rule per tree)
+        s->meshq = 1;
+        for (int r : bvh_roots)
+            if (bvh_nodes[r].skip - r > 15) s->meshq = kMeshQ;
+        // The top levels of the trees go to LDS (pvt_bvh.h: stage_top), as many records as leave four workgroups per CU
+        // -- the mesh variants' four waves per SIMD -- their LDS in either kind of launch (tallies / histories).
+        {
+            const LdsPlan tally = plan_lds(s, false), hist = plan_lds(s, true);
+            const size_t other = (tally.bytes > hist.bytes ? tally.bytes : hist.bytes) + (size_t)s->meshq * kBlock * 4;
+            const size_t per_wg = 39 * 1024;
+            size_t room = tally.ok && hist.ok && other < per_wg ? per_wg - other : 0;
+            if (room > 24 * 1024) room = 24 * 1024;
+            if (const char* env = getenv("PVT_MESH_TOP_BYTES")) room = (size_t)atoll(env);   // (developer override; 0: no copy)
+            std::vector<pvt::BvhNode> top;
+            pvt::stage_top(bvh_nodes, bvh_roots, room / sizeof(pvt::BvhNode), top);
+            s->top_n = (int)top.size();
+            if (s->top_n > 0) {
+                HIP_TRY(hipMalloc(&s->d_bvh_top, top.size() * sizeof(pvt::BvhNode)));
+                HIP_TRY(hipMemcpy(s->d_bvh_top, top.data(), top.size() * sizeof(pvt::BvhNode), hipMemcpyHostToDevice));
+            }
+        }
+        bvh_nodes.push_back(pvt::BvhNode{});   // (one record past the end, kept for walks that fetch ahead)
         HIP_TRY(hipMalloc(&s->d_bvh, bvh_nodes.size() * sizeof(pvt::BvhNode)));
         HIP_TRY(hipMalloc(&s->d_tris, bvh_tris.size() * sizeof(pvt::MeshTri)));
         HIP_TRY(hipMemcpy(s->d_bvh, bvh_nodes.data(), bvh_nodes.size() * sizeof(pvt::BvhNode), hipMemcpyHostToDevice));
@@ -1043,6 +1075,7 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_cursor) (void)hipFree(s->d_cursor);
     if (s->d_set_cursor) (void)hipFree(s->d_set_cursor);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
+    if (s->d_bvh_top) (void)hipFree(s->d_bvh_top);
     if (s->d_tris) (void)hipFree(s->d_tris);
     for (auto* b : s->stage) if (b) (void)hipFree(b);
     for (auto& c : s->carry) for (auto* b : c.buf) if (b) (void)hipFree(b);
@@ -1153,6 +1186,35 @@ int check_trace_args(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
 
 // Enqueue ONE trace kernel.  `log_rows` / `log_counts`: the event records of the recorded rays (device memory,
 // null when record_every == 0); counts are cleared here.
+// LDS of a launch, before what mesh walks add: recorder accumulators + control words, tables if they fit, bins if
+// they fit, then the drain-phase consolidation buffer (kXSlots photon states, also the seed pools) within 40 KB.
+// `s->meshq` and `s->top_n` (mesh scenes) are reserved first, so that what is decided here still fits with them.
+LdsPlan plan_lds(const PvtScene* s, bool record) {
+    LdsPlan lp{0, false, 0, 0, 0, true};
+    const size_t reserved = (size_t)s->meshq * kBlock * 4 + (size_t)s->top_n * sizeof(pvt::BvhNode);
+    const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 8) + (size_t)((s->n_rec + 1) & ~1) * 4 + CTL_WORDS * 4;
+    const size_t tab_bytes = (size_t)s->nd * 8 + (size_t)((s->ni + 1) & ~1) * 4;
+    const size_t bins_bytes = ((size_t)s->total_bins * 4 + 7) & ~(size_t)7;
+    const size_t lds_limit = s->lds_limit - reserved;
+    const size_t budget = (64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit) - reserved;  // keep >= 2 workgroups per CU
+    // per-wave queues of first crossings awaiting their statistics (kernel: tally_flush)
+    lp.tq_pos = s->hist_reads_position ? 1 : 0;
+    const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((lp.tq_pos ? 7 : 4) * 8 + 4);
+    if (acc_bytes + tq_bytes > lds_limit) { lp.ok = false; return lp; }
+    lp.tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget;
+    size_t lds = acc_bytes + tq_bytes + (lp.tab_lds ? tab_bytes : 0);
+    lp.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
+    if (lp.bins_in_lds) lds += bins_bytes;
+    const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 1 : 0);
+    const size_t xbytes = (size_t)kXSlots * xw * 8;
+    if (s->consolidate && lds + xbytes <= 40 * 1024 && lds + xbytes <= lds_limit) {
+        lp.xslots = kXSlots;
+        lds += xbytes;
+    }
+    lp.bytes = (lds + 15) & ~(size_t)15;
+    return lp;
+}
+
 int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, const PvtTallies* tl,
                  unsigned long long* log_rows, int* log_counts, hipStream_t st) {
     const int slot = slot_of_stream(s, st);
@@ -1217,28 +1279,22 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     a.cursor_next = nullptr;
 #endif
 
-    // LDS budget: recorder accumulators + control words, tables if they fit, bins if they fit, then the
-    // drain-phase consolidation buffer (kXSlots photon states, also the seed pools) within 40 KB
-    const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 8) + (size_t)((s->n_rec + 1) & ~1) * 4 + CTL_WORDS * 4;
-    const size_t tab_bytes = (size_t)s->nd * 8 + (size_t)((s->ni + 1) & ~1) * 4;
-    const size_t bins_bytes = ((size_t)s->total_bins * 4 + 7) & ~(size_t)7;
-    const size_t budget = 64 * 1024 < s->lds_limit ? 64 * 1024 : s->lds_limit;  // keep >= 2 workgroups per CU
-    // per-wave queues of first crossings awaiting their statistics (kernel: tally_flush)
-    a.tq_pos = s->hist_reads_position ? 1 : 0;
-    const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((a.tq_pos ? 7 : 4) * 8 + 4);
-    if (acc_bytes + tq_bytes > s->lds_limit) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
-    const bool tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget;
-    size_t lds = acc_bytes + tq_bytes + (tab_lds ? tab_bytes : 0);
-    a.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
-    if (a.bins_in_lds) lds += bins_bytes;
-    const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 1 : 0);
-    const size_t xbytes = (size_t)kXSlots * xw * 8;
-    a.xslots = 0;
-    if (s->consolidate && lds + xbytes <= 40 * 1024 && lds + xbytes <= s->lds_limit) {
-        a.xslots = kXSlots;
-        lds += xbytes;
+    const LdsPlan lp = plan_lds(s, record);
+    if (!lp.ok) return fail(PVT_ERR_INVALID, "recorder accumulators exceed LDS");
+    a.tq_pos = lp.tq_pos;
+    a.bins_in_lds = lp.bins_in_lds;
+    a.xslots = lp.xslots;
+    const bool tab_lds = lp.tab_lds;
+    size_t lds = lp.bytes;
+    a.meshq_off = -1;
+    a.top_off = 0; a.top_n = 0; a.bvh_top = nullptr;
+    if (a.bvh) {   // mesh walks: the lanes' noted leaves, then the copy of the trees' top levels
+        a.meshq_off = (int)lds;
+        lds += (size_t)s->meshq * kBlock * 4;
+        a.top_off = (int)lds; a.top_n = s->top_n; a.bvh_top = s->d_bvh_top;
+        lds += (size_t)s->top_n * sizeof(pvt::BvhNode);
+        if (lds > s->lds_limit) return fail(PVT_ERR_INVALID, "mesh staging exceeds LDS");
     }
-    lds = (lds + 15) & ~(size_t)15;
 
     // persistent grid: enough workgroups to fill every CU a few times over,
     // never more than the rays can feed
@@ -1339,6 +1395,10 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
         if (a.lay.grid_d >= 0)
             fprintf(stderr, "[pvt stats] grid walk per wave-iteration: cell rounds %.2f  node-test trips %.2f  (lanes per trip %.1f, lanes per cell round %.1f)\n",
                     (double)c[25] / c[1], (double)c[26] / c[1], (double)c[27] / (c[26] + 1e-9), (double)c[28] / (c[25] + 1e-9));
+        if (a.bvh)
+            fprintf(stderr, "[pvt stats] mesh walk per wave-iteration: box trips %.2f (lanes per trip %.1f)  triangle trips %.2f (lanes per trip %.1f);  per lane-step: boxes %.2f triangles %.2f\n",
+                    (double)c[25] / c[1], (double)c[26] / (c[25] + 1e-9), (double)c[27] / c[1], (double)c[28] / (c[27] + 1e-9),
+                    (double)c[26] / c[2], (double)c[28] / c[2]);
         fprintf(stderr, "[pvt stats] bulk lanes/iteration: live %.1f absorbed %.1f re-emitted %.1f surface %.1f exit %.1f terminal-selector %.1f terminal %.1f\n",
                 c[17] / bi, c[18] / bi, c[19] / bi, c[20] / bi, c[21] / bi, c[22] / bi, c[23] / bi);
     }
@@ -1592,6 +1652,38 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
         }
     }
     for (int k = 0; k < fc; k++) if (seen[k] != 1) return fail(PVT_ERR_INVALID, "face missing from the tree");
+    // the copy of the top levels for LDS (pvt_bvh.h: stage_top), at several budgets: the walk through cursors must name the
+    // same records, in the same order, with the same successors after a hit and after a miss as the plain tree
+    for (size_t budget : {(size_t)3, (size_t)7, (size_t)64, (size_t)768, nodes.size()}) {
+        std::vector<pvt::BvhNode> staged = nodes, top;
+        pvt::stage_top(staged, std::vector<int>{0}, budget, top);
+        if (top.size() > budget) return fail(PVT_ERR_INVALID, "copy of the top levels exceeds its budget");
+        const int end = (int)nodes.size();
+        std::vector<int> cursor_of(nodes.size() + 1, -1);
+        cursor_of[nodes.size()] = end;
+        int c = 0;
+        if (!top.empty()) {
+            if ((staged[0].leaf & 15) != 0 || staged[0].leaf == 0) return fail(PVT_ERR_INVALID, "root does not name its copy");
+            c = pvt::kTopFlag | ((staged[0].leaf >> 4) - 1);
+        }
+        for (int i = 0; i < end; i++) {   // a walk that hits every box visits the records in order
+            if (c == end) return fail(PVT_ERR_INVALID, "staged walk ends early");
+            if ((c & pvt::kTopFlag) ? (size_t)(c & ~pvt::kTopFlag) >= top.size() : (c <= 0 && i > 0) || c >= end)
+                return fail(PVT_ERR_INVALID, "cursor out of range");
+            cursor_of[i] = c;
+            const pvt::BvhNode& b = pvt::at_cursor(staged, top, c);
+            for (int a = 0; a < 3; a++)
+                if (b.lo[a] != nodes[i].lo[a] || b.hi[a] != nodes[i].hi[a]) return fail(PVT_ERR_INVALID, "staged walk out of order");
+            if ((nodes[i].leaf & 15) != 0 && b.leaf != nodes[i].leaf) return fail(PVT_ERR_INVALID, "staged leaf differs");
+            if ((nodes[i].leaf & 15) == 0 && (b.leaf & 15) != 0) return fail(PVT_ERR_INVALID, "staged inner record reads as a leaf");
+            c = pvt::next_cursor(b, c, true);
+        }
+        if (c != end) return fail(PVT_ERR_INVALID, "staged walk does not end at the tree's end");
+        for (int i = 0; i < end; i++) {   // ... and a miss leads where the plain skip link leads
+            const pvt::BvhNode& b = pvt::at_cursor(staged, top, cursor_of[i]);
+            if (pvt::next_cursor(b, cursor_of[i], false) != cursor_of[nodes[i].skip]) return fail(PVT_ERR_INVALID, "staged skip link differs");
+        }
+    }
     if (n_bvh_nodes) *n_bvh_nodes = (int32_t)nodes.size();
     if (n_leaves) *n_leaves = leaves;
     if (depth_out) *depth_out = max_depth;

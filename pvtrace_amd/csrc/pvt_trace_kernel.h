@@ -10,6 +10,9 @@
 #ifndef PVT_CARRY_OUT
 #define PVT_CARRY_OUT 1
 #endif
+#ifndef PVT_MESH_Q
+#define PVT_MESH_Q 8
+#endif
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
@@ -187,7 +190,14 @@ struct KArgs {
     // and the sampler's code (a fifth of the kernel's text) out of the step loop -- and parks them in its own
     // [7][64] doubles here (position, direction, wavelength; global memory, L2-resident); refilled lanes read theirs.
     double* emit_pool;
+    // Mesh walks: byte offset in LDS of the workgroup's [kMeshQ][kBlock] words of noted leaves (-1: none)
+    int meshq_off;
+    // Mesh walks: the TOP of every tree (pvt_bvh.h: stage_top) is copied to LDS when a launch starts -- `top_n` records
+    // from `bvh_top` to byte offset `top_off`; cursors with pvt::kTopFlag set index that copy
+    int top_off, top_n;
+    const pvt::BvhNode* bvh_top;
 };
+constexpr int kMeshQ = PVT_MESH_Q;    // leaves a lane notes before its triangles are tested
 constexpr int kCarryBase = 14;     // u64 words of a parked photon before its seen-mask
 constexpr int kCarryStride = 18;   // words per parked photon (room for the four-word mask of scenes with > 64 recorders)
 
@@ -750,6 +760,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     int tq_n = 0;   // wave-uniform
     if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 4 && A.cursor_next) A.cursor_next[threadIdx.x] = 0u;
+    if constexpr (MESH) {   // the top of the triangle trees (two 16-byte words per record)
+        typedef unsigned int Word4 __attribute__((ext_vector_type(4)));
+        Word4* dst = reinterpret_cast<Word4*>(reinterpret_cast<char*>(smem) + A.top_off);
+        const Word4* src = reinterpret_cast<const Word4*>(A.bvh_top);
+        for (int i = threadIdx.x; i < A.top_n * 2; i += kBlock) dst[i] = src[i];
+    }
     if constexpr (TAB_LDS) {
         for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
         for (int i = threadIdx.x; i < A.ni; i += kBlock) lds_i[i] = A.gi[i];
@@ -1610,32 +1626,55 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // (the two table pointers in registers for the walk: the build keeps loop invariants where they are used --
                     // good for the photon loop as a whole, but here that is a scalar load of the kernel argument, and a wait
                     // for it, in every iteration of the walk)
-                    // (the record after a hit is the next one in memory and is named before the test -- the compiler issues that
-                    // load after the test all the same, one load per iteration whatever the outcome: measured faster than
-                    // forcing it early, which spends a second load on every culled inner node)
                     const pvt::BvhNode* bvh = A.bvh;
                     const pvt::MeshTri* tris = A.tris;
                     asm volatile("" : "+s"(bvh), "+s"(tris));
-                    int end = bvh[i].skip;
-                    pvt::BvhNode b = bvh[i];   // 32 bytes: two 16-byte loads
+                    // The walk waits for its records more than it computes (a wave of the 20 480-face ball: 62 % of its cycles,
+                    // ~1 000 per box): the top levels of every tree -- where every ray passes -- are read from a copy in LDS
+                    // (pvt_bvh.h: stage_top).  A cursor is the index of a record in global memory, or kTopFlag | slot in
+                    // that copy; skip links are stored in the same form, the walk is over when the cursor equals the
+                    // tree's end.
+                    const pvt::BvhNode* const ltop = reinterpret_cast<const pvt::BvhNode*>(reinterpret_cast<const char*>(smem) + A.top_off);
+                    // (records in global memory through a buffer descriptor: the address of a record is its byte offset, one
+                    // shift, instead of a 64-bit multiply-add, and the loads do not count as LDS traffic to wait for)
+                    const __amdgpu_buffer_rsrc_t brec = __builtin_amdgcn_make_buffer_rsrc(const_cast<pvt::BvhNode*>(bvh), 0, -1, 0x00020000);
+                    auto record_at = [&](int index) __attribute__((always_inline)) {
+                        typedef unsigned int Word4 __attribute__((ext_vector_type(4)));
+                        struct Pair { Word4 a, b; } w;
+                        w.a = __builtin_amdgcn_raw_buffer_load_b128(brec, index << 5, 0, 0);
+                        w.b = __builtin_amdgcn_raw_buffer_load_b128(brec, (index << 5) + 16, 0, 0);
+                        return __builtin_bit_cast(pvt::BvhNode, w);
+                    };
+                    // (the root's record -- its box, the tree's end, where its copy is -- through the scalar cache: the node is the wave's)
+                    const __attribute__((address_space(4))) pvt::BvhNode* const rootp =
+                        (const __attribute__((address_space(4))) pvt::BvhNode*)(A.bvh + i);
+                    const float rlo[3] = {rootp->lo[0], rootp->lo[1], rootp->lo[2]}, rhi[3] = {rootp->hi[0], rootp->hi[1], rootp->hi[2]};
+                    const int end = rootp->skip, rleaf = rootp->leaf;
+                    pvt::BvhNode b;
                     // The boxes are tested in f32, relative to the mesh's centre (the node's parameter slots) and from where
                     // the ray ENTERS the root box -- every quantity then has the mesh's own size, the test's rounding displaces
                     // a plane by < 5e-7 of the mesh's diagonal, and the host pads every box by 4e-6 of it (pvt_bvh.h).
-                    float of[3], invf[3];
+                    float oi[3], invf[3];   // (a plane's distance is fma(plane, 1/d, -(o/d)): o/d once per walk)
                     {
                         double t_near = 0.0, t_far = INFINITY;
                         const double cc[3] = {gpar[0], gpar[1], gpar[2]};
 #pragma unroll
                         for (int a = 0; a < 3; a++) {
-                            const double ta = (((double)b.lo[a] + cc[a]) - oo[a]) * minv[a], tb = (((double)b.hi[a] + cc[a]) - oo[a]) * minv[a];
+                            const double ta = (((double)rlo[a] + cc[a]) - oo[a]) * minv[a], tb = (((double)rhi[a] + cc[a]) - oo[a]) * minv[a];
                             t_near = __builtin_fmax(t_near, __builtin_fmin(ta, tb));
                             t_far = __builtin_fmin(t_far, __builtin_fmax(ta, tb));
                         }
-                        if (t_far < t_near) end = i;   // the ray misses the mesh's box altogether
+                        if ((rleaf & 15) == 0 && rleaf != 0) {   // the root's copy in LDS
+                            i = pvt::kTopFlag | ((rleaf >> 4) - 1);
+                            b = ltop[i & ~pvt::kTopFlag];
+                        } else {
+                            b = record_at(i);
+                        }
+                        if (t_far < t_near) i = end;   // the ray misses the mesh's box altogether
 #pragma unroll
                         for (int a = 0; a < 3; a++) {
-                            of[a] = (float)((oo[a] - cc[a]) + dd[a] * t_near);
                             invf[a] = pvt_fabs(dd[a]) < 1e-20 ? 1e20f : (float)minv[a];   // (a component this small: the ray is parallel to the pair of planes)
+                            oi[a] = (float)((oo[a] - cc[a]) + dd[a] * t_near) * invf[a];
                         }
                     }
                     // The triangle tests are DEFERRED: a lane that reaches a leaf only notes it (four slots in registers) and
@@ -1647,45 +1686,56 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // order they are found in does not matter.)
                     // (A mesh of a few triangles -- a tree of a handful of nodes, leaves of up to eight triangles -- has no
                     // walk to speak of to keep going: its leaves are tested as they are met.  Wave-uniform: the node is.)
-                    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;
-                    const int qcap = end - i <= 15 ? 1 : 4;
+                    // (the notes live in LDS, one column per lane: in registers they were a shift register whose copies the
+                    // compiler carried through every path of the walk -- 14 moves per box)
+                    unsigned int* const mq = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(smem) + A.meshq_off) + threadIdx.x;
+                    int qn = 0;
+                    const int qcap = end - T.iu(node * NI + NI_MESH) <= 15 ? 1 : kMeshQ;
                     for (;;) {
                         // ---- walk: every lane goes on until its walk is over or its slots are full
                         for (;;) {
-                            const bool go = i < end && qn < qcap;
-                            if (__ballot(go) == 0ull || __popcll(__ballot(i < end && qn >= qcap)) >= PVT_MESH_FULL_LANES) break;
+                            const bool go = i != end && qn < qcap;
+                            if (__ballot(go) == 0ull || __popcll(__ballot(i != end && qn >= qcap)) >= PVT_MESH_FULL_LANES) break;
+#if PVT_STATS
+                            if (MESH) { st_g[0] += 1; st_g[1] += __popcll(__ballot(go)); }
+#endif
                             if (go) {
-                                // the successor after a HIT is the next record (depth-first order): fetched while this box
-                                // is tested (one record past the array's end exists: the host appends a sentinel)
-                                const pvt::BvhNode nxt = bvh[i + 1];
                                 float tmin = 0.0f, tmax = INFINITY;
 #pragma unroll
                                 for (int a = 0; a < 3; a++) {
-                                    const float ta = (b.lo[a] - of[a]) * invf[a], tb = (b.hi[a] - of[a]) * invf[a];
+                                    const float ta = __builtin_fmaf(b.lo[a], invf[a], -oi[a]), tb = __builtin_fmaf(b.hi[a], invf[a], -oi[a]);
                                     tmin = __builtin_fmaxf(tmin, __builtin_fminf(ta, tb));
                                     tmax = __builtin_fminf(tmax, __builtin_fmaxf(ta, tb));
                                 }
-                                if (tmax < tmin) {
-                                    i = b.skip;
-                                    if (i < end) b = bvh[i];
-                                } else {
+                                // the successor: after a miss and after a leaf the skip link; after a hit of an inner node the next
+                                // record (depth-first order) -- which for the last level of the copy in LDS is named in `leaf`
+                                int next = b.skip;
+                                if (!(tmax < tmin)) {
                                     if ((b.leaf & 15) != 0) {   // a leaf: its triangles later (the newest note first: any order will do)
-                                        q3 = q2; q2 = q1; q1 = q0; q0 = b.leaf;
+                                        mq[qn * kBlock] = (unsigned int)b.leaf;
                                         qn += 1;
+                                    } else {
+                                        next = b.leaf != 0 ? (b.leaf >> 4) : i + 1;
                                     }
-                                    i += 1;
-                                    b = nxt;
+                                }
+                                i = next;
+                                if (i != end) {
+                                    if (i & pvt::kTopFlag) b = ltop[i & ~pvt::kTopFlag];
+                                    else b = record_at(i);
                                 }
                             }
                         }
                         // ---- the noted leaves, every lane on one of its own at a time
                         while (__ballot(qn > 0) != 0ull) {
                             if (qn > 0) {
-                                const int leaf = q0;
-                                q0 = q1; q1 = q2; q2 = q3; qn -= 1;
+                                qn -= 1;
+                                const int leaf = (int)mq[qn * kBlock];
                                 const int tn = leaf & 15, tri_start = leaf >> 4;
                                 const pvt::MeshTri* tr = tris + tri_start;
                                 for (int k = 0; k < tn; k++, tr++) {
+#if PVT_STATS
+                                    if (MESH) { st_g[2] += 1; st_g[3] += __popcll(__ballot(true)); }
+#endif
                                     double va[3], vb[3], vc[3];
 #pragma unroll
                                     for (int a = 0; a < 3; a++) {
@@ -1726,7 +1776,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                                 }
                             }
                         }
-                        if (__ballot(i < end) == 0ull) break;
+                        if (__ballot(i != end) == 0ull) break;
                     }
                 } else if (gt == PVT_GEOM_BOX) {  // slab test (_kernel.pyx:245-276)
                 double tmin = -INFINITY, tmax = INFINITY;

@@ -3,13 +3,15 @@
 # kernel on one mesh scene of tools/gpu_mesh_stream.py (default ico5), each counter set in its own run with
 # --kernel-trace only.  Output: gpurun_out/mesh_pmc_<scene>.txt (sums over the trace-kernel dispatches of 12 bundles)
 scene=${1:-ico5}
+# (PVT_LIB selects the build; PMC_TAG names the output, default the scene)
+tag=${PMC_TAG:-$scene}
 export TMPDIR=/tmp PVT_STREAM_STEPS=12
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
 run() { name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/mesh_pmc_${scene}_$name -o pmc -- \
-      python $R/tools/gpu_mesh_stream.py $scene > $R/gpurun_out/mesh_pmc_${scene}_$name.log 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/mesh_pmc_${tag}_$name -o pmc -- \
+      python $R/tools/gpu_mesh_stream.py $scene > $R/gpurun_out/mesh_pmc_${tag}_$name.log 2>&1
 }
 # (the TA_* / TCP_* counter sets did not come back within ten minutes on this pool: run only on request)
 if [ "$2" = with-ta ]; then
@@ -17,9 +19,10 @@ run ta TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum
 fi
 run sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY
+run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS
 run tcc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 cd $R
-python3 - "$scene" <<'PY' | tee gpurun_out/mesh_pmc_$1.txt
+python3 - "$tag" <<'PY' | tee gpurun_out/mesh_pmc_$tag.txt
 import csv, glob, sys, collections
 scene = sys.argv[1]
 tot = collections.Counter(); n = 0
