@@ -33,9 +33,11 @@ import argparse
 import datetime
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -556,32 +558,15 @@ def main():
         finally:
             other.close()
 
-    sustained = attempt("sustained leg", sustained_leg) if args.sustained_s > 0 and not errors else None
-    strong = attempt("strong-scaling leg", lambda: strong_leg(sustained)) if args.total_photons > 0 and not errors else None
-    extra = {}
-    wanted = [c for c in args.extra_configs.split(",") if c and c != "none"] if args.config == "cfg2" else []
-    for name in wanted:
-        if errors:
-            break
-        got = attempt(f"config {name}", lambda: config_leg(name))
-        if got is not None:
-            extra[name] = got
-    scaling = None
-    sizes = ([int(k) for k in args.scene_sizes.split(",") if k and k != "none"]
-             if args.config == "cfg2" and args.extra_configs != "none" else [])   # ('--extra-configs none': the main config only)
-    if sizes and not errors:
-        scaling = {"what": "k x k tile arrays of the headline slab in one world (benchmarks/configs.py: tiles_lsc), device "
-                           "emission, same pipeline as the other configs; the reference intersects every node in every step "
-                           "(_kernel.pyx:666-680), this engine walks a node grid from 8 nodes on (DESIGN.md)",
-                   "photons_per_gpu_per_window": n * 10, "sizes": {}}
-        for k in sizes:
-            if errors:
-                break
-            got = attempt(f"scene size tiles{k}", lambda: size_leg(k))
-            if got is not None:
-                scaling["sizes"][f"tiles{k}"] = got
+    printed = threading.Lock()
 
-    if rank == 0:
+    def report(more_errors=()):
+        """Rank 0's ONE line, from whatever has been measured when it is called: at the end of the run, or -- from the
+        watcher thread below -- when the launcher takes the job down because another rank is gone."""
+        if not printed.acquire(blocking=False):
+            return
+        sustained, strong, extra, scaling = done["sustained"], done["strong"], done["extra"], done["scaling"]
+        failures = list(errors) + list(more_errors)
         achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9 if leg.array_input else 0.0
         traffic, instruction_side = load_pmc(args.config, value / world, cus)
         rates = [per_window / d for d in window_dts]
@@ -642,11 +627,65 @@ def main():
             out["configs"] = extra
         if scaling:
             out["scene_scaling"] = scaling
-        if errors:
-            out["error"] = "; ".join(errors)   # (everything above was measured before the failure)
+        if failures:
+            out["error"] = "; ".join(failures)   # (everything above was measured before the failure)
         if not args.no_cpu_baseline and world == 1 and leg.array_input:   # the CPU referee is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(leg.compiled, *leg.host_rays)
         print(json.dumps(out), flush=True)
+
+
+    def watch_for_a_lost_rank():
+        """torch.distributed.run ends the other ranks with SIGTERM as soon as one of them is gone -- possibly before rank 0
+        has found out for itself (a collective that times out) and printed.  The signal is noted through a wake-up pipe,
+        which works while the main thread sits inside a collective or a device synchronisation, and a thread prints the
+        line with what there is."""
+        if not (distributed and rank == 0):
+            return
+        r_fd, w_fd = os.pipe()
+        os.set_blocking(w_fd, False)
+        signal.signal(signal.SIGTERM, lambda signum, frame: None)   # (a Python-level handler: the byte is then written)
+        signal.set_wakeup_fd(w_fd, warn_on_full_buffer=False)
+
+        def waiter():
+            while True:
+                got = os.read(r_fd, 1)
+                if got and got[0] == signal.SIGTERM:
+                    report(["the launcher ended this rank (SIGTERM): another rank was lost during a leg after the timed region"])
+                    os._exit(1)
+
+        threading.Thread(target=waiter, daemon=True).start()
+
+    # what the legs after the timed region have produced so far (rank 0's line is built from it, see report())
+    done = {"sustained": None, "strong": None, "extra": {}, "scaling": None}
+    watch_for_a_lost_rank()
+    done["sustained"] = sustained = attempt("sustained leg", sustained_leg) if args.sustained_s > 0 and not errors else None
+    done["strong"] = attempt("strong-scaling leg", lambda: strong_leg(sustained)) if args.total_photons > 0 and not errors else None
+    extra = done["extra"]
+    wanted = [c for c in args.extra_configs.split(",") if c and c != "none"] if args.config == "cfg2" else []
+    for name in wanted:
+        if errors:
+            break
+        got = attempt(f"config {name}", lambda: config_leg(name))
+        if got is not None:
+            extra[name] = got
+    scaling = None
+    sizes = ([int(k) for k in args.scene_sizes.split(",") if k and k != "none"]
+             if args.config == "cfg2" and args.extra_configs != "none" else [])   # ('--extra-configs none': the main config only)
+    if sizes and not errors:
+        scaling = {"what": "k x k tile arrays of the headline slab in one world (benchmarks/configs.py: tiles_lsc), device "
+                           "emission, same pipeline as the other configs; the reference intersects every node in every step "
+                           "(_kernel.pyx:666-680), this engine walks a node grid from 8 nodes on (DESIGN.md)",
+                   "photons_per_gpu_per_window": n * 10, "sizes": {}}
+        done["scaling"] = scaling
+        for k in sizes:
+            if errors:
+                break
+            got = attempt(f"scene size tiles{k}", lambda: size_leg(k))
+            if got is not None:
+                scaling["sizes"][f"tiles{k}"] = got
+
+    if rank == 0:
+        report()
     leg.close()
     if distributed and not errors:
         dist.barrier()

@@ -1207,7 +1207,9 @@ LdsPlan plan_lds(const PvtScene* s, bool record) {
     if (lp.bins_in_lds) lds += bins_bytes;
     const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 1 : 0);
     const size_t xbytes = (size_t)kXSlots * xw * 8;
-    if (s->consolidate && lds + xbytes <= 40 * 1024 && lds + xbytes <= lds_limit) {
+    // (mesh scenes do without: measured, repacking a draining workgroup buys their launches nothing, and the 9 KB hold
+    // another level of the trees' top)
+    if (s->consolidate && s->meshq == 0 && lds + xbytes <= 40 * 1024 && lds + xbytes <= lds_limit) {
         lp.xslots = kXSlots;
         lds += xbytes;
     }
