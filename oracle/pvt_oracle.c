@@ -463,15 +463,28 @@ static int find_coating(const PvtSceneTables* S, int hit, const double* nl, cons
     }
     return -1;
 }
+/* Cosine-weighted direction about +z from two draws (material/utils.py:176-186, engine/emit.py:78): theta =
+ * asin(sqrt(p1)), phi = 2 pi p2, then sin / cos of both.  Portable mode evaluates the compositions directly, as
+ * sample_phase does: sin(asin s) = s, cos(asin s) = pvt_sqrt1m2(s), sin / cos(2 pi u) = pvt_sincos2pi(u). */
+static void lambert_direction(const MathSel* M, double p1, double p2, double* out) {
+    if (!M->mode) {
+        sphere_direction(M, asin(sqrt(p1)), 2.0 * M_PI * p2, out);
+        return;
+    }
+    const double st = pvt_sqrt(p1), ct = pvt_sqrt1m2(st);
+    double sp, cp;
+    pvt_sincos2pi(p2, &sp, &cp);
+    out[0] = st * cp;
+    out[1] = st * sp;
+    out[2] = ct;
+}
 /* EXTENSION: cosine-weighted direction about unit vector m (local frame),
  * Duff et al. orthonormal basis; for m = +z returns (sx, sy, sz) unchanged,
  * which is what the reference's lambertian() delegate yields (material/utils.py:176-186). */
 static void lambertian_about(const MathSel* M, const double* m, Rng* rng, double* out) {
     double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
-    double theta = m_asin(M, sqrt(p1));
-    double phi = 2.0 * M_PI * p2;
     double s[3];
-    sphere_direction(M, theta, phi, s);
+    lambert_direction(M, p1, p2, s);
     double sign = m[2] < 0.0 ? -1.0 : 1.0;
     double a = -1.0 / (sign + m[2]);
     double b = m[0] * m[1] * a;
@@ -868,7 +881,7 @@ static void emit_one(const PvtEmitterTables* E, const MathSel* M, uint64_t emit_
         case PVT_DIR_HG: sample_phase(M, PVT_PHASE_HG, prm, &rng, ld); break;
         case PVT_DIR_LAMBERTIAN: {
             double p1 = rng_uniform(&rng), p2 = rng_uniform(&rng);
-            sphere_direction(M, m_asin(M, sqrt(p1)), 2.0 * M_PI * p2, ld);
+            lambert_direction(M, p1, p2, ld);
             break;
         }
         default: break;

@@ -39,7 +39,10 @@ struct MeshTri {      // 104 bytes
 // Leaf size: the watertight triangle test costs several box tests, so large meshes get one
 // triangle per leaf (measured on MI355X: 20 480-face ball 3.2 ms vs 4.5 ms with 4 per leaf);
 // for a handful of faces the tree is not worth walking and leaves hold up to 8.
-constexpr int kSmallMesh = 32, kSmallLeaf = 8, kLargeLeaf = 1;
+#ifndef PVT_SMALL_LEAF
+#define PVT_SMALL_LEAF 8
+#endif
+constexpr int kSmallMesh = 32, kSmallLeaf = PVT_SMALL_LEAF, kLargeLeaf = 1;
 
 class BvhBuilder {
 public:

@@ -422,6 +422,16 @@ __device__ __forceinline__ V3 sphere_direction(double theta, double phi) {
     return V3{st * cp, st * sp, ct};
 }
 
+// Cosine-weighted direction about +z from two draws (material/utils.py:176-186: theta = asin(sqrt(p1)), phi = 2 pi p2,
+// then sin / cos of both): the compositions evaluated directly, as everywhere else in portable arithmetic --
+// sin(asin s) = s, cos(asin s) = pvt_sqrt1m2(s), sin / cos(2 pi u) = pvt_sincos2pi(u).
+__device__ __forceinline__ V3 lambert_direction(double p1, double p2) {
+    const double st = pvt_sqrt(p1), ct = sqrt1m2_normal(st);
+    double sp, cp;
+    pvt_sincos2pi(p2, &sp, &cp);
+    return V3{st * cp, st * sp, ct};
+}
+
 // phase functions (_kernel.pyx:455-476); draw order is part of the contract
 __device__ __forceinline__ V3 sample_phase(int type, double param, Rng& rng) {
     // the polar angle is sampled through its cosine (HG, isotropic) or its sine (cone); the other one is the
@@ -508,7 +518,7 @@ __device__ __forceinline__ void emit_one(const KArgs& A, unsigned long long gi, 
     else if (dt == PVT_DIR_HG) ld = sample_phase(PVT_PHASE_HG, prm, rng);
     else if (dt == PVT_DIR_LAMBERTIAN) {
         double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
-        ld = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
+        ld = lambert_direction(p1, p2);
     }
     const double* m = ed + E.l2w + li * 16;
     pos.x = m[0] * lp.x + m[1] * lp.y + m[2] * lp.z + m[3];
@@ -2224,7 +2234,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     if (!node_ident(node_bits(hit))) nloc = local_normal(local_point());
                     V3 mm{side * nloc.x, side * nloc.y, side * nloc.z};
                     double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
-                    V3 sd = sphere_direction(pvt_asin(pvt_sqrt(p1)), 2.0 * kPi * p2);
+                    V3 sd = lambert_direction(p1, p2);
                     double sign = mm.z < 0.0 ? -1.0 : 1.0;
                     double a = -1.0 / (sign + mm.z);
                     double b = mm.x * mm.y * a;

@@ -393,6 +393,32 @@ def test_bvh_walk_finds_exactly_the_crossings_of_the_brute_force_oracle():
     assert cpu["rec_distinct"][0] > 0.6 * n
 
 
+@pytest.mark.parametrize("top_bytes", ["0", "96", "224", "4064", "default"])
+def test_bvh_walk_is_the_same_whatever_part_of_the_tree_sits_in_lds(top_bytes, monkeypatch):
+    """The walk reads the top levels of a tree from a copy in LDS and the rest from global memory; cursors and skip links
+    name either (pvt_bvh.h: stage_top).  No copy at all (0), the root and its children (3 records = 96 bytes), three levels,
+    seven levels, and what the library picks: always the brute-force oracle's crossings, in a scene of TWO meshes of
+    different size (the copy is shared out between the trees) plus an analytic node."""
+    import pvtrace_amd as pv
+    if top_bytes != "default":
+        monkeypatch.setenv("PVT_MESH_TOP_BYTES", top_bytes)
+    scene, ball = _mesh_ball_scene(3)
+    small = pv.Node(name="small", parent=scene.root,
+                    geometry=pv.Mesh.icosphere(1, 0.3, material=pv.Material(refractive_index=1.3)))
+    small.location = (2.0, 0.3, 0.1)
+    compiled = compile_scene(scene)
+    n = 3000
+    rng = np.random.default_rng(31)
+    pos = rng.uniform(-2.6, 2.6, (n, 3)); pos[:, 2] = rng.uniform(-1.5, 1.5, n)
+    target = np.where(rng.random((n, 1)) < 0.5, np.array([[0.0, 0.0, 2.0]]), np.array([[2.0, 0.3, 0.1]])) + rng.normal(0, 0.25, (n, 3))
+    dirs = target - pos
+    dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    wl = np.full(n, 555.0)
+    gpu = _kernel.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 0, 1, 1)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 48, 0, 8, 1, math_mode=O.MATH_PORTABLE)
+    assert_bundles_identical(gpu, cpu, sums_rtol=1e-12, what=f"two meshes, copy of {top_bytes} bytes")
+
+
 def test_every_kernel_variant_at_once():
     """The template axes together: mesh geometry (MESH), 6000-point spectra that do not fit LDS
     (TAB_LDS=false), 150 recorders (wide seen mask), sampled event log (RECORD) and device-side
