@@ -5,7 +5,7 @@
 // the traversal is `i = hit ? i + 1 : skip[i]` with no per-lane stack in scratch or LDS.  A
 // photon needs EVERY forward crossing of a mesh (the container rule counts them,
 // _kernel.pyx:684-714), so front-to-back ordering buys nothing and a fixed order is free.
-// The tree is built with a binned surface-area heuristic.  Leaves hold one triangle (up to 8 for tiny meshes), pre-gathered (vertices + face normal +
+// The tree is built with a binned surface-area heuristic.  Leaves hold one triangle, pre-gathered (vertices + face normal +
 // face id) so a leaf is one contiguous run of 104-byte records.  Nodes are 32 bytes (f32 boxes
 // rounded outwards): culling is only a filter, the triangle test itself stays f64.
 //
@@ -36,13 +36,14 @@ struct MeshTri {      // 104 bytes
     long long face;   // index in the scene's pooled face table (tie-break key, diagnostics)
 };
 
-// Leaf size: the watertight triangle test costs several box tests, so large meshes get one
-// triangle per leaf (measured on MI355X: 20 480-face ball 3.2 ms vs 4.5 ms with 4 per leaf);
-// for a handful of faces the tree is not worth walking and leaves hold up to 8.
-#ifndef PVT_SMALL_LEAF
-#define PVT_SMALL_LEAF 8
+// Leaf size: the watertight triangle test costs several box tests (185 vector instructions against 40, and the boxes of
+// a small tree are read from LDS), so every leaf holds ONE triangle.  (Rounds 1-3 gave meshes of up to 32 faces leaves of
+// eight; with round 4's walk one triangle per leaf is 24 % faster on the 12-triangle slab and 52 % on the L-shaped prism:
+// profiles/r04_mesh_walk_series.txt.  The record format still allows up to 15.)
+#ifndef PVT_LEAF_TRIANGLES
+#define PVT_LEAF_TRIANGLES 1
 #endif
-constexpr int kSmallMesh = 32, kSmallLeaf = PVT_SMALL_LEAF, kLargeLeaf = 1;
+constexpr int kLeafTriangles = PVT_LEAF_TRIANGLES;
 
 class BvhBuilder {
 public:
@@ -78,7 +79,6 @@ public:
             if (centre) centre[a] = c_[a];
         }
         f0_ = f0;
-        leaf_ = count <= kSmallMesh ? kSmallLeaf : kLargeLeaf;
         const int root = (int)nodes_.size();
         build(0, count);
         return root;
@@ -218,7 +218,7 @@ private:
     double pad_ = 0.0;
     double c_[3] = {0.0, 0.0, 0.0};
     int f0_ = 0;
-    int leaf_ = kLargeLeaf;
+    int leaf_ = kLeafTriangles;
 };
 
 // ---- the top of the trees, for LDS ------------------------------------------------------------------------
