@@ -995,6 +995,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
     HIP_TRY(hipMemset(s->d_cursor, 0, 64 * kCursorSlots + 256));
     HIP_TRY(hipMalloc(&s->d_set_cursor, (size_t)kCursorSlots * kMaxSets * 4));
+    if (bvh_nodes.size() >= ((size_t)1 << 26) || bvh_tris.size() >= ((size_t)1 << 26))
+        return fail(PVT_ERR_INVALID, "meshes too large: the walk's cursors and leaf references hold 2^26 records / triangles");
     if (!bvh_nodes.empty()) {
         // a lane of a walk notes kMeshQ leaves before their triangles are tested -- one, in trees of a handful of records
         // (the kernel applies the same rule per tree)
