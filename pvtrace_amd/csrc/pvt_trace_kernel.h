@@ -25,7 +25,7 @@
 #define PVT_WAVE_SCALAR 1
 #endif
 #ifndef PVT_MESH_FULL_LANES
-#define PVT_MESH_FULL_LANES 1   // lanes with full leaf slots that end a walk phase of the mesh walk
+#define PVT_MESH_FULL_LANES 4   // lanes with full leaf slots that end a walk phase of the mesh walk (1 / 4 / 16 measured: within 3 %)
 #endif
 #ifndef PVT_LOG_STORES
 #define PVT_LOG_STORES 16   // bytes per store of an event record (8: from the value registers; 16: assembled vectors)
