@@ -538,6 +538,20 @@ def main():
         finally:
             other.close()
 
+    # ------------------------------------------------------------------ triangle meshes (extension): photons/s against the face count
+    def mesh_leg(sub):
+        name = f"mesh{sub}"
+        other = Leg(name, n)
+        try:
+            other.spin_up(min(args.spinup_s, 0.1), 2)
+            dts = sorted(other.window(100 + w * 10, 10) for w in range(3))
+            sus_steps = max(10, int(0.7 / (dts[1] / 10)))
+            dt = other.window(100_000, sus_steps)
+            return {"faces": 20 * 4 ** sub, "value": n * world * 10 / dts[1], "sustained": n * world * sus_steps / dt,
+                    "unit": "photons/s", "launch": other.dscene.launch_info()}
+        finally:
+            other.close()
+
     # ------------------------------------------------------------------ scene size: photons/s against the node count
     def size_leg(k):
         name = f"tiles{k}"
@@ -627,6 +641,8 @@ def main():
             out["configs"] = extra
         if scaling:
             out["scene_scaling"] = scaling
+        if done["meshes"]:
+            out["meshes"] = done["meshes"]
         if failures:
             out["error"] = "; ".join(failures)   # (everything above was measured before the failure)
         if not args.no_cpu_baseline and world == 1 and leg.array_input:   # the CPU referee is timed at N=1 only
@@ -656,7 +672,7 @@ def main():
         threading.Thread(target=waiter, daemon=True).start()
 
     # what the legs after the timed region have produced so far (rank 0's line is built from it, see report())
-    done = {"sustained": None, "strong": None, "extra": {}, "scaling": None}
+    done = {"sustained": None, "strong": None, "extra": {}, "scaling": None, "meshes": None}
     watch_for_a_lost_rank()
     done["sustained"] = sustained = attempt("sustained leg", sustained_leg) if args.sustained_s > 0 and not errors else None
     done["strong"] = attempt("strong-scaling leg", lambda: strong_leg(sustained)) if args.total_photons > 0 and not errors else None
@@ -683,6 +699,17 @@ def main():
             got = attempt(f"scene size tiles{k}", lambda: size_leg(k))
             if got is not None:
                 scaling["sizes"][f"tiles{k}"] = got
+
+    if sizes and not errors:   # (with the scene-size leg: '--extra-configs none' runs the main config only)
+        done["meshes"] = meshes = {"what": "triangle-mesh extension (no reference counterpart: its engine rejects meshes): the glass "
+                                           "ball of the reference's hello_world as an icosphere, device emission, same pipeline; "
+                                           "stack-free BVH walk with the top of the tree in LDS (DESIGN.md §4.5)", "sizes": {}}
+        for sub in (3, 5, 7):
+            if errors:
+                break
+            got = attempt(f"mesh scene mesh{sub}", lambda: mesh_leg(sub))
+            if got is not None:
+                meshes["sizes"][f"mesh{sub}"] = got
 
     if rank == 0:
         report()

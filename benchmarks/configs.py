@@ -12,6 +12,7 @@
   background, plain Fresnel surfaces, so the reference kernel runs it too) on a 5.5 cm pitch in cfg2's world,
   lit from above by one rectangular source that covers the array, 20-degree cone, 555 nm: k*k + 1 nodes.  The
   reference intersects every node in every step (pvtrace/engine/_kernel.pyx:666-680).
+* mesh<s>: the triangle-mesh extension on the reference's hello_world scene, the ball an icosphere of 20 * 4^s faces.
 """
 import functools
 
@@ -105,6 +106,30 @@ def tiles_lsc(k, recorders="centre"):
     return Scene(world)
 
 
+def mesh_ball(subdivisions):
+    """The reference's hello_world (examples/hello_world.py:8-32: a glass ball of radius 1 at (0, 0, 2) in a 10 cm air
+    sphere, pi/8 cone from the origin) with the ball as a TRIANGLE MESH -- an icosphere of 20 * 4^subdivisions faces --
+    and whole-surface recorders on it.  Meshes are an extension (the reference engine rejects them); this is the scene
+    the mesh walk's numbers are quoted on."""
+    from pvtrace_amd import Mesh
+    world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    ball = Node(name="ball-lens", parent=world,
+                geometry=Mesh.icosphere(subdivisions, 1.0, material=Material(refractive_index=1.5)))
+    ball.location = (0, 0, 2)
+    ball.recorders = [Recorder("ball-entering", event="entering"), Recorder("ball-escaping", event="escaping")]
+    Node(name="green-laser", parent=world, light=Light(direction=functools.partial(cone, np.pi / 8), name="green-laser"))
+    return Scene(world)
+
+
+def _mesh_config(subdivisions):
+    return dict(build=functools.partial(mesh_ball, subdivisions), emit_method="kT",
+                workload=f"triangle-mesh extension: hello_world's glass ball as an icosphere of {20 * 4 ** subdivisions} faces "
+                         f"(BVH walk), pi/8 cone @555 nm, 2 recorders, record_every=0")
+
+
+MESH_SIZES = (3, 5, 7)
+
+
 def _tiles_config(k):
     return dict(build=functools.partial(tiles_lsc, k), emit_method="kT",
                 workload=f"scene-size family: {k}x{k} array of cfg2's slab on a 5.5 cm pitch ({k * k + 1} nodes), "
@@ -127,3 +152,4 @@ CONFIGS = {
                           "1 cm^-1 isotropic scatterer, 5x5 cm rectangular source, 11 recorders, record_every=0"),
 }
 CONFIGS.update({f"tiles{k}": _tiles_config(k) for k in TILE_SIZES})
+CONFIGS.update({f"mesh{k}": _mesh_config(k) for k in MESH_SIZES})
