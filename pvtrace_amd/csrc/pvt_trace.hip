@@ -1658,34 +1658,57 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
     for (int k = 0; k < fc; k++) if (seen[k] != 1) return fail(PVT_ERR_INVALID, "face missing from the tree");
     // the copy of the top levels for LDS (pvt_bvh.h: stage_top), at several budgets: the walk through cursors must name the
     // same records, in the same order, with the same successors after a hit and after a miss as the plain tree
+    auto replay = [](const std::vector<pvt::BvhNode>& plain, const std::vector<pvt::BvhNode>& staged,
+                     const std::vector<pvt::BvhNode>& top, int root) -> const char* {
+        const int end = plain[root].skip;
+        std::vector<int> cursor_of((size_t)(end - root) + 1, -1);
+        cursor_of[(size_t)(end - root)] = end;
+        int c = root;
+        const int hint = staged[root].leaf;
+        if ((plain[root].leaf & 15) == 0 && hint != 0) {   // the tree has a copy: its root names the slot
+            if ((hint & 15) != 0) return "root does not name its copy";
+            c = pvt::kTopFlag | ((hint >> 4) - 1);
+        }
+        for (int i = root; i < end; i++) {   // a walk that hits every box visits the records in order
+            if (c == end) return "staged walk ends early";
+            if ((c & pvt::kTopFlag) ? (size_t)(c & ~pvt::kTopFlag) >= top.size() : (c < root || c >= end)) return "cursor out of range";
+            cursor_of[(size_t)(i - root)] = c;
+            const pvt::BvhNode& rec = pvt::at_cursor(staged, top, c);
+            for (int a = 0; a < 3; a++)
+                if (rec.lo[a] != plain[i].lo[a] || rec.hi[a] != plain[i].hi[a]) return "staged walk out of order";
+            if ((plain[i].leaf & 15) != 0 && rec.leaf != plain[i].leaf) return "staged leaf differs";
+            if ((plain[i].leaf & 15) == 0 && (rec.leaf & 15) != 0) return "staged inner record reads as a leaf";
+            c = pvt::next_cursor(rec, c, true);
+        }
+        if (c != end) return "staged walk does not end at the tree's end";
+        for (int i = root; i < end; i++) {   // ... and a miss leads where the plain skip link leads
+            const pvt::BvhNode& rec = pvt::at_cursor(staged, top, cursor_of[(size_t)(i - root)]);
+            if (pvt::next_cursor(rec, cursor_of[(size_t)(i - root)], false) != cursor_of[(size_t)(plain[i].skip - root)]) return "staged skip link differs";
+        }
+        return nullptr;
+    };
     for (size_t budget : {(size_t)3, (size_t)7, (size_t)64, (size_t)768, nodes.size()}) {
         std::vector<pvt::BvhNode> staged = nodes, top;
         pvt::stage_top(staged, std::vector<int>{0}, budget, top);
         if (top.size() > budget) return fail(PVT_ERR_INVALID, "copy of the top levels exceeds its budget");
-        const int end = (int)nodes.size();
-        std::vector<int> cursor_of(nodes.size() + 1, -1);
-        cursor_of[nodes.size()] = end;
-        int c = 0;
-        if (!top.empty()) {
-            if ((staged[0].leaf & 15) != 0 || staged[0].leaf == 0) return fail(PVT_ERR_INVALID, "root does not name its copy");
-            c = pvt::kTopFlag | ((staged[0].leaf >> 4) - 1);
-        }
-        for (int i = 0; i < end; i++) {   // a walk that hits every box visits the records in order
-            if (c == end) return fail(PVT_ERR_INVALID, "staged walk ends early");
-            if ((c & pvt::kTopFlag) ? (size_t)(c & ~pvt::kTopFlag) >= top.size() : (c <= 0 && i > 0) || c >= end)
-                return fail(PVT_ERR_INVALID, "cursor out of range");
-            cursor_of[i] = c;
-            const pvt::BvhNode& b = pvt::at_cursor(staged, top, c);
-            for (int a = 0; a < 3; a++)
-                if (b.lo[a] != nodes[i].lo[a] || b.hi[a] != nodes[i].hi[a]) return fail(PVT_ERR_INVALID, "staged walk out of order");
-            if ((nodes[i].leaf & 15) != 0 && b.leaf != nodes[i].leaf) return fail(PVT_ERR_INVALID, "staged leaf differs");
-            if ((nodes[i].leaf & 15) == 0 && (b.leaf & 15) != 0) return fail(PVT_ERR_INVALID, "staged inner record reads as a leaf");
-            c = pvt::next_cursor(b, c, true);
-        }
-        if (c != end) return fail(PVT_ERR_INVALID, "staged walk does not end at the tree's end");
-        for (int i = 0; i < end; i++) {   // ... and a miss leads where the plain skip link leads
-            const pvt::BvhNode& b = pvt::at_cursor(staged, top, cursor_of[i]);
-            if (pvt::next_cursor(b, cursor_of[i], false) != cursor_of[nodes[i].skip]) return fail(PVT_ERR_INVALID, "staged skip link differs");
+        if (const char* what = replay(nodes, staged, top, 0)) return fail(PVT_ERR_INVALID, what);
+    }
+    // ... and ALL the scene's meshes staged together, as scene creation does (the budget is shared out, slots run on from
+    // tree to tree): every tree still walks like its plain self
+    {
+        std::vector<pvt::BvhNode> all;
+        std::vector<pvt::MeshTri> all_tris;
+        std::vector<int> roots;
+        for (int n = 0; n < t->n_nodes; n++)
+            if (t->geom_type[n] == PVT_GEOM_MESH)
+                roots.push_back(pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, all, all_tris)
+                                    .add_mesh(t->mesh_face_start[n], t->mesh_face_count[n]));
+        for (size_t budget : {(size_t)0, (size_t)10, (size_t)100, (size_t)512, all.size()}) {
+            std::vector<pvt::BvhNode> staged = all, top;
+            pvt::stage_top(staged, roots, budget, top);
+            if (top.size() > budget) return fail(PVT_ERR_INVALID, "shared copy of the top levels exceeds its budget");
+            for (int r : roots)
+                if (const char* what = replay(all, staged, top, r)) return fail(PVT_ERR_INVALID, what);
         }
     }
     if (n_bvh_nodes) *n_bvh_nodes = (int32_t)nodes.size();

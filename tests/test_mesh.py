@@ -181,6 +181,23 @@ def test_host_built_bvh_is_a_proper_depth_first_tree():
         native.mesh_bvh_check(compiled, 2)                              # the analytic sphere
 
 
+def test_the_lds_copy_of_the_tree_tops_is_shared_out_between_meshes_of_different_size():
+    """pvt_mesh_bvh_check also stages ALL meshes of the scene together (pvt_bvh.h: stage_top) at five budgets -- none, a
+    handful of records, more than the small trees need, everything -- and replays every tree through its cursors: the
+    records of the plain tree in order, the same successor after a hit and after a miss."""
+    from pvtrace_amd.engine import native
+
+    world = Node(name="w", geometry=Mesh.icosphere(1, 20.0, material=Material(1.0)))
+    for k, (sub, radius) in enumerate([(4, 1.0), (0, 0.4), (2, 0.7), (1, 0.2)]):
+        n = Node(name=f"m{k}", parent=world, geometry=Mesh.icosphere(sub, radius, material=Material(1.5)))
+        n.location = (3.0 * k - 4.0, 0.5 * k, 0.0)
+    compiled = compile_scene(Scene(world))
+    faces = [80, 5120, 20, 320, 80]
+    for node, count in enumerate(faces):
+        nodes, leaves, depth = native.mesh_bvh_check(compiled, node)
+        assert leaves == count and nodes == 2 * count - 1
+
+
 def test_non_convex_mesh_holds_a_ray_that_crosses_it_three_times():
     """A ray that starts inside one arm of the L-prism and heads across the notch crosses the mesh's
     surface three times before the world's.  The reference's container rule -- the nearest node crossed
