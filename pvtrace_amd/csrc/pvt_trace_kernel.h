@@ -13,6 +13,9 @@
 #ifndef PVT_MESH_Q
 #define PVT_MESH_Q 8
 #endif
+#ifndef PVT_MESH_WAVES
+#define PVT_MESH_WAVES 4   // waves per SIMD the mesh variants are held to (registers: 512 / waves; LDS per workgroup: 160 KB / waves)
+#endif
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
@@ -2460,9 +2463,6 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 // registers: held to 128 they park about sixty values in scratch around the BVH walk (photon state the walk does not
 // touch), and the fourth wave is worth more than that costs -- the walk is a chain of dependent loads: +8 ... +19 % in
 // the pipelined stream, 3.1 -> 2.7 ms for a single 10^6-photon launch on the 327 680-face ball (five waves: worse).
-#ifndef PVT_MESH_WAVES
-#define PVT_MESH_WAVES 4
-#endif
 template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_MESH_WAVES, PVT_MESH_WAVES))) trace_kernel(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, MESH>(A);
