@@ -1010,7 +1010,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             const size_t other = (tally.bytes > hist.bytes ? tally.bytes : hist.bytes) + (size_t)s->meshq * kBlock * 4;
             const size_t per_wg = (size_t)39 * 1024 * 4 / PVT_MESH_WAVES;
             size_t room = tally.ok && hist.ok && other < per_wg ? per_wg - other : 0;
-            if (room > 24 * 1024) room = 24 * 1024;
+            if (room > 32 * 1024) room = 32 * 1024;
             if (const char* env = getenv("PVT_MESH_TOP_BYTES")) room = (size_t)atoll(env);   // (developer override; 0: no copy)
             std::vector<pvt::BvhNode> top;
             pvt::stage_top(bvh_nodes, bvh_roots, room / sizeof(pvt::BvhNode), top);
