@@ -130,6 +130,24 @@ def _mesh_config(subdivisions):
 MESH_SIZES = (3, 5, 7)
 
 
+def fine_spectra_lsc(points=8001):
+    """cfg2's slab with its two spectra tabulated on a fine grid (8001 points: 400-800 nm in 0.05 nm steps -- what a
+    measured spectrum straight from a spectrometer file looks like): 260 KB of tables, far beyond a workgroup's LDS."""
+    x = np.linspace(400.0, 800.0, points)
+    world = Node(name="World", geometry=Box((500.0, 500.0, 100.0), material=Material(refractive_index=1.0)))
+    slab = Node(name="LSC", parent=world, geometry=Box((5.0, 5.0, 1.0), material=Material(
+        refractive_index=1.5,
+        components=[Luminophore(coefficient=np.column_stack((x, lumogen_f_red_305.absorption(x) * 10.0)),
+                                emission=np.column_stack((x, lumogen_f_red_305.emission(x))),
+                                quantum_yield=1.0, name="Lumogen F Red 305"),
+                    Absorber(0.1, name="Background")])))
+    slab.recorders = face_recorders()
+    light = Node(name="Light", parent=world, light=Light(direction=functools.partial(cone, np.radians(20)), name="Light"))
+    light.location = (0.0, 0.0, 5.0)
+    light.rotate(np.radians(180), (1, 0, 0))
+    return Scene(world)
+
+
 def _tiles_config(k):
     return dict(build=functools.partial(tiles_lsc, k), emit_method="kT",
                 workload=f"scene-size family: {k}x{k} array of cfg2's slab on a 5.5 cm pitch ({k * k + 1} nodes), "
@@ -153,3 +171,5 @@ CONFIGS = {
 }
 CONFIGS.update({f"tiles{k}": _tiles_config(k) for k in TILE_SIZES})
 CONFIGS.update({f"mesh{k}": _mesh_config(k) for k in MESH_SIZES})
+CONFIGS["fine"] = dict(build=fine_spectra_lsc, emit_method="kT",
+                       workload="cfg2's slab with 8001-point spectra (tables beyond LDS), 20-degree cone @555 nm, 10 recorders")

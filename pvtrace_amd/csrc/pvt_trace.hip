@@ -92,6 +92,7 @@ struct PvtScene {
     Lay lay{};
     EmitOff eoff{};
     int nd = 0, ni = 0;
+    int nd_small = 0, ni_small = 0;   // ... of which everything but the spectra / their guide tables (the blobs' heads)
     int n_nodes = 0, root = 0, n_rec = 0, total_bins = 0, n_coat = 0, n_lights = 0;
     double* d_gd = nullptr;
     int* d_gi = nullptr;
@@ -142,7 +143,7 @@ struct PvtScene {
 };
 
 namespace {
-struct LdsPlan { size_t bytes; bool tab_lds; int bins_in_lds, xslots, tq_pos; bool ok; };
+struct LdsPlan { size_t bytes; bool tab_lds, small_lds; int bins_in_lds, xslots, tq_pos; bool ok; };
 LdsPlan plan_lds(const PvtScene* s, bool record);   // (defined with the launch code)
 }  // namespace
 
@@ -623,7 +624,21 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     lay.rec_d = lay.comp_d + CR * CD;
     lay.hist_d = lay.rec_d + R * RD;
     lay.coat_d = lay.hist_d + H * HD;
-    const int spec_d = lay.coat_d + K * KD;
+    // The small tables come first in the blob -- records, then critical angles, rotation classes, index classes and the
+    // node grid -- and the spectra last: when a scene's spectra are too large for LDS, a workgroup still stages everything
+    // before `spec_d` (KArgs::nd_lds; the guide tables are the tail of the int blob in the same way).
+    const int small_d = lay.coat_d + K * KD;
+    constexpr int kCritClasses = 16;
+    lay.n_cls = M;
+    lay.crit_d = M <= kCritClasses ? small_d : -1;
+    lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + M * M : -1;
+    lay.rot_d = small_d + (lay.crit_d >= 0 ? 2 * M * M : 0);
+    lay.ncls_d = lay.rot_d + Q * RT;
+    lay.by_node = by_node ? 1 : 0;
+    NodeGrid grid;
+    const bool has_grid = plan_node_grid(t, &grid);
+    lay.grid_d = has_grid ? lay.ncls_d + M * 2 : -1;
+    const int spec_d = lay.ncls_d + M * 2 + (has_grid ? 14 + (int)grid.masks.size() : 0);
     std::vector<double> c_abs_rcp(C), c_abs_w(C), c_ems_rcp_x(C), c_ems_rcp_c(C), c_ems_w(C);
     std::vector<int> c_abs_x(C), c_abs_y(C), c_ems_x(C), c_ems_c(C), c_abs_g(C), c_ems_gx(C), c_ems_gc(C);
     int spec_len = 0, guide_len = 0;
@@ -660,17 +675,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         }
     }
     const int spec_end = spec_d + spec_len;
-    constexpr int kCritClasses = 16;
-    lay.n_cls = M;
-    lay.crit_d = M <= kCritClasses ? spec_end : -1;
-    lay.ccrit_d = lay.crit_d >= 0 ? lay.crit_d + M * M : -1;
-    lay.rot_d = spec_end + (lay.crit_d >= 0 ? 2 * M * M : 0);
-    lay.ncls_d = lay.rot_d + Q * RT;
-    lay.by_node = by_node ? 1 : 0;
-    NodeGrid grid;
-    const bool has_grid = plan_node_grid(t, &grid);
-    lay.grid_d = has_grid ? lay.ncls_d + M * 2 : -1;
-    std::vector<double> gd((size_t)lay.ncls_d + (size_t)M * 2 + (has_grid ? 14 + grid.masks.size() : 0) + 1, 0.0);
+    std::vector<double> gd((size_t)spec_end + 1, 0.0);
     if (has_grid) {
         double* d = gd.data() + lay.grid_d;
         for (int a = 0; a < 3; a++) { d[a] = grid.lo[a]; d[3 + a] = grid.hi[a]; d[6 + a] = grid.cell[a]; d[9 + a] = 1.0 / grid.cell[a]; }
@@ -970,6 +975,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     s->lay = lay;
     s->nd = (int)gd.size();
     s->ni = (int)gi.size();
+    s->nd_small = spec_d;
+    s->ni_small = guide0;
     s->n_nodes = N;
     s->root = t->root_id;
     s->n_rec = R;
@@ -1095,6 +1102,7 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
     a.bvh = s->d_bvh; a.tris = s->d_tris;
     a.lay = s->lay; a.eoff = s->eoff;
     a.nd = s->nd; a.ni = s->ni;
+    a.nd_lds = 0; a.ni_lds = 0;
     a.n_nodes = s->n_nodes; a.root = s->root; a.n_rec = s->n_rec; a.total_bins = s->total_bins;
     a.n_coat = s->n_coat; a.n_lights = s->n_lights;
     a.n_rays = (unsigned int)p->n_rays;
@@ -1110,10 +1118,10 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
 #ifndef PVT_DEV_VARIANTS
 #define PVT_DEV_VARIANTS 0   // developer builds: only the analytic, array-input, <=64-recorder variants (fast compile)
 #endif
-template <bool RECORD, bool TAB_LDS, int SEENW>
+template <bool RECORD, int TAB_LDS, int SEENW>
 hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
     const bool mesh = a.bvh != nullptr;
-    if constexpr (TAB_LDS && (!PVT_DEV_VARIANTS || SEENW == 1) && PVT_DEV_VARIANTS != 2) {
+    if constexpr (TAB_LDS == 1 && (!PVT_DEV_VARIANTS || SEENW == 1) && PVT_DEV_VARIANTS != 2) {
         if (a.lay.grid_d >= 0 && !mesh && (!PVT_DEV_VARIANTS || !emit)) {   // many nodes: per-lane walk of the node grid
             if (emit && !PVT_DEV_VARIANTS) hipLaunchKernelGGL((trace_kernel_grid<RECORD, SEENW, !PVT_DEV_VARIANTS>), dim3(grid), dim3(kBlock), lds, st, a);
             else hipLaunchKernelGGL((trace_kernel_grid<RECORD, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
@@ -1121,21 +1129,24 @@ hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const
         }
     }
 #if PVT_DEV_VARIANTS == 2   // developer builds of the MESH variants only (tables in LDS, <= 64 recorders, array input)
-    if (emit || !mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
-    if constexpr (TAB_LDS && SEENW == 1) hipLaunchKernelGGL((trace_kernel<RECORD, true, 1, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
+    if (emit || !mesh || TAB_LDS != 1 || SEENW != 1) return hipErrorNotSupported;
+    if constexpr (TAB_LDS == 1 && SEENW == 1) hipLaunchKernelGGL((trace_kernel<RECORD, 1, 1, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
 #elif PVT_DEV_VARIANTS
-    if (emit || mesh || !TAB_LDS || SEENW != 1) return hipErrorNotSupported;
-    if constexpr (TAB_LDS && SEENW == 1) {
-        if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, true, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
-        else hipLaunchKernelGGL((trace_kernel_w4<false, true, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    if (emit || mesh || TAB_LDS != 1 || SEENW != 1) return hipErrorNotSupported;
+    if constexpr (TAB_LDS == 1 && SEENW == 1) {
+        if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, 1, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((trace_kernel_w4<false, 1, 1, false>), dim3(grid), dim3(kBlock), lds, st, a);
     }
 #else
+    // (mesh scenes stage all their tables or none: plan_lds never asks for the heads alone there)
+    constexpr int MESH_TAB = TAB_LDS == 2 ? 0 : TAB_LDS;
+    if (mesh && TAB_LDS == 2) return hipErrorNotSupported;
     if (emit) {
-        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, true, true>), dim3(grid), dim3(kBlock), lds, st, a);
+        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, MESH_TAB, SEENW, true, true>), dim3(grid), dim3(kBlock), lds, st, a);
         else if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((trace_kernel_w4<false, TAB_LDS, SEENW, true>), dim3(grid), dim3(kBlock), lds, st, a);
     } else {
-        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, TAB_LDS, SEENW, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
+        if (mesh) hipLaunchKernelGGL((trace_kernel<RECORD, MESH_TAB, SEENW, false, true>), dim3(grid), dim3(kBlock), lds, st, a);
         else if constexpr (RECORD) hipLaunchKernelGGL((trace_kernel_w4<true, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((trace_kernel_w4<false, TAB_LDS, SEENW, false>), dim3(grid), dim3(kBlock), lds, st, a);
     }
@@ -1143,7 +1154,7 @@ hipError_t launch_variant(bool emit, int grid, size_t lds, hipStream_t st, const
     return hipGetLastError();
 }
 
-template <bool RECORD, bool TAB_LDS>
+template <bool RECORD, int TAB_LDS>
 hipError_t launch_seen(int n_rec, bool emit, int grid, size_t lds, hipStream_t st, const KArgs& a) {
     if (n_rec <= 64) return launch_variant<RECORD, TAB_LDS, 1>(emit, grid, lds, st, a);
     return launch_variant<RECORD, TAB_LDS, 4>(emit, grid, lds, st, a);
@@ -1192,7 +1203,7 @@ int check_trace_args(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, 
 // they fit, then the drain-phase consolidation buffer (kXSlots photon states, also the seed pools) within 40 KB.
 // `s->meshq` and `s->top_n` (mesh scenes) are reserved first, so that what is decided here still fits with them.
 LdsPlan plan_lds(const PvtScene* s, bool record) {
-    LdsPlan lp{0, false, 0, 0, 0, true};
+    LdsPlan lp{0, false, false, 0, 0, 0, true};
     const size_t reserved = (size_t)s->meshq * kBlock * 4 + (size_t)s->top_n * sizeof(pvt::BvhNode);
     const size_t acc_bytes = (size_t)s->n_rec * (8 * 8 + 8) + (size_t)((s->n_rec + 1) & ~1) * 4 + CTL_WORDS * 4;
     const size_t tab_bytes = (size_t)s->nd * 8 + (size_t)((s->ni + 1) & ~1) * 4;
@@ -1204,7 +1215,11 @@ LdsPlan plan_lds(const PvtScene* s, bool record) {
     const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((lp.tq_pos ? 7 : 4) * 8 + 4);
     if (acc_bytes + tq_bytes > lds_limit) { lp.ok = false; return lp; }
     lp.tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget;
-    size_t lds = acc_bytes + tq_bytes + (lp.tab_lds ? tab_bytes : 0);
+    // spectra too large for LDS: everything else -- node, component and recorder records, class tables -- still is staged
+    // (the blobs' heads; the spectra and their guide tables are read from global memory)
+    const size_t small_bytes = (size_t)s->nd_small * 8 + (size_t)((s->ni_small + 1) & ~1) * 4;
+    lp.small_lds = !lp.tab_lds && s->meshq == 0 && acc_bytes + tq_bytes + small_bytes <= 40 * 1024 && acc_bytes + tq_bytes + small_bytes <= budget;
+    size_t lds = acc_bytes + tq_bytes + (lp.tab_lds ? tab_bytes : lp.small_lds ? small_bytes : 0);
     lp.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
     if (lp.bins_in_lds) lds += bins_bytes;
     const size_t xw = 14 + (s->n_rec <= 64 ? 1 : 4) + (record ? 1 : 0);
@@ -1289,6 +1304,7 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     a.bins_in_lds = lp.bins_in_lds;
     a.xslots = lp.xslots;
     const bool tab_lds = lp.tab_lds;
+    if (lp.small_lds) { a.nd_lds = s->nd_small; a.ni_lds = s->ni_small; }
     size_t lds = lp.bytes;
     a.meshq_off = -1;
     a.top_off = 0; a.top_n = 0; a.bvh_top = nullptr;
@@ -1369,11 +1385,13 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     }
     hipError_t e;
     if (record) {
-        e = tab_lds ? launch_seen<true, true>(s->n_rec, emit, (int)grid, lds, st, a)
-                    : launch_seen<true, false>(s->n_rec, emit, (int)grid, lds, st, a);
+        e = tab_lds ? launch_seen<true, 1>(s->n_rec, emit, (int)grid, lds, st, a)
+            : lp.small_lds ? launch_seen<true, 2>(s->n_rec, emit, (int)grid, lds, st, a)
+                           : launch_seen<true, 0>(s->n_rec, emit, (int)grid, lds, st, a);
     } else {
-        e = tab_lds ? launch_seen<false, true>(s->n_rec, emit, (int)grid, lds, st, a)
-                    : launch_seen<false, false>(s->n_rec, emit, (int)grid, lds, st, a);
+        e = tab_lds ? launch_seen<false, 1>(s->n_rec, emit, (int)grid, lds, st, a)
+            : lp.small_lds ? launch_seen<false, 2>(s->n_rec, emit, (int)grid, lds, st, a)
+                           : launch_seen<false, 0>(s->n_rec, emit, (int)grid, lds, st, a);
     }
     if (e != hipSuccess) return fail(PVT_ERR_HIP, std::string("trace_kernel launch: ") + hipGetErrorString(e));
     if (!n_sets) carry.phase = (carry.phase + 1) % 3;

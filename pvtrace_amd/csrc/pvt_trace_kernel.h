@@ -137,6 +137,8 @@ struct KArgs {
     Lay lay;
     EmitOff eoff;
     int nd, ni;         // blob lengths
+    int nd_lds, ni_lds; // (variants whose tables do not fit LDS) heads of the blobs that are staged all the same: everything
+                        // but the spectra and their guide tables (0: nothing)
     int n_nodes, root, n_rec, total_bins, n_coat, n_lights;
     // rays in (null -> device emission)
     const double* pos;
@@ -282,7 +284,9 @@ __device__ __forceinline__ double rcp_normal(double x) {
 }
 
 // ------------------------------------------------------------ table access
-// TAB_LDS: divergent reads come from the LDS copy; uniform reads always come
+// TAB_LDS (0 / 1 / 2): divergent reads come from global memory / from the LDS copy of the blobs / records and class
+// tables from LDS (the heads of the blobs, KArgs::nd_lds) and the spectra with their guide tables -- too large to
+// stage -- from global memory; uniform reads always come
 // from the global blob so the compiler can use scalar loads.
 // Read-only scene blobs viewed through the CONSTANT address space: a load whose
 // address is wave-uniform then becomes an s_load through the scalar cache (SGPR result,
@@ -291,18 +295,21 @@ __device__ __forceinline__ double rcp_normal(double x) {
 typedef const __attribute__((address_space(4))) double* CDoubles;
 typedef const __attribute__((address_space(4))) int* CInts;
 
-template <bool TAB_LDS>
+template <int TAB_LDS>
 struct Tables {
     CDoubles gd;
     CInts gi;
-    const double* ld;  // LDS copies (== global blobs when !TAB_LDS)
+    const double* ld;  // LDS copies (TAB_LDS != 0)
     const int* li;
     const double* __restrict__ hd;
     const int* __restrict__ hi;
     __device__ __forceinline__ double du(int i) const { return gd[i]; }  // uniform index
     __device__ __forceinline__ int iu(int i) const { return gi[i]; }
-    __device__ __forceinline__ double dv(int i) const { return TAB_LDS ? ld[i] : hd[i]; }  // per-lane index
-    __device__ __forceinline__ int iv(int i) const { return TAB_LDS ? li[i] : hi[i]; }
+    // per-lane index: records and class tables (dv / iv), spectra and their guide tables (sd / si)
+    __device__ __forceinline__ double dv(int i) const { return TAB_LDS != 0 ? ld[i] : hd[i]; }
+    __device__ __forceinline__ int iv(int i) const { return TAB_LDS != 0 ? li[i] : hi[i]; }
+    __device__ __forceinline__ double sd(int i) const { return TAB_LDS == 1 ? ld[i] : hd[i]; }
+    __device__ __forceinline__ int si(int i) const { return TAB_LDS == 1 ? li[i] : hi[i]; }
 };
 
 struct V3 {
@@ -340,11 +347,11 @@ constexpr double kRcpCcm = 1.0 / kCcm;   // correctly rounded by the compiler
 // of w (both checked by the host), so the reference's index is found by arithmetic — no table
 // walk, no dependent LDS reads — and validated against the (computed) neighbours.  `yw` likewise for
 // the ordinates (the inverse-CDF lookup returns wavelengths of an evenly spaced grid).
-template <bool TAB_LDS>
+template <int TAB_LDS>
 __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, double x, int xs, int ys, int n,
                                                  int guide, double scale, int hist, double rcp,
                                                  double w = __builtin_nan(""), double yw = __builtin_nan("")) {
-    auto end = [&](int i) { return T.dv(i); };
+    auto end = [&](int i) { return T.sd(i); };
     if (n == 1) return end(ys);
     // a table on a proven even grid (w, yw) is stored as its first value: the last one is computed, same bits
     const bool even = !hist && w == w;
@@ -362,15 +369,15 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
             if (x < xlo) { i -= 1; xhi = xlo; xlo = x0 + (double)i * w; }
             else if (!(x < xhi)) { i += 1; xlo = xhi; xhi = x0 + (double)(i + 1) * w; }
         }
-        const double ylo = T.dv(ys + i), yhi = T.dv(ys + i + 1);
+        const double ylo = T.sd(ys + i), yhi = T.sd(ys + i + 1);
         return ylo + div_known((yhi - ylo) * (x - xlo), xhi - xlo, rcp);
     }
     int b = (int)((x - x0) * scale);
     b = b < 0 ? 0 : (b > n - 2 ? n - 2 : b);
-    int lo = T.iv(guide + b), hi = T.iv(guide + b + 1) + 1;
+    int lo = T.si(guide + b), hi = T.si(guide + b + 1) + 1;
     if (hi > n - 1) hi = n - 1;
     // the abscissae travel with the indices, so nothing is re-read after the search
-    double xlo = T.dv(xs + lo), xhi = T.dv(xs + hi);
+    double xlo = T.sd(xs + lo), xhi = T.sd(xs + hi);
     if (hist) {
         // histogram-sampled table (extension; Python Distribution's hist branch): the value of
         // the first abscissa >= x, i.e. ys[#{xs_i < x}] — same bracket, strict comparison
@@ -378,9 +385,9 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
         if (!(x <= xhi)) hi = n - 1;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (T.dv(xs + mid) < x) lo = mid; else hi = mid;
+            if (T.sd(xs + mid) < x) lo = mid; else hi = mid;
         }
-        return T.dv(ys + hi);
+        return T.sd(ys + hi);
     }
     if (__ballot(!(xlo <= x) || !(x < xhi)) != 0ull) {   // (rounding put some lane's x in a neighbouring bucket: rare)
         if (!(xlo <= x)) { lo = 0; xlo = x0; }
@@ -388,7 +395,7 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
     }
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        const double xm = T.dv(xs + mid);
+        const double xm = T.sd(xs + mid);
         if (xm <= x) { lo = mid; xlo = xm; } else { hi = mid; xhi = xm; }
     }
     double ylo, yhi;
@@ -396,7 +403,7 @@ __device__ __forceinline__ double interp_clamped(const Tables<TAB_LDS>& T, doubl
         const double y0 = end(ys);
         ylo = y0 + (double)lo * yw; yhi = y0 + (double)hi * yw;
     } else {
-        ylo = T.dv(ys + lo); yhi = T.dv(ys + hi);
+        ylo = T.sd(ys + lo); yhi = T.sd(ys + hi);
     }
     if (xhi == xlo) return ylo;
     // evenly spaced abscissae (every interval has the same bits, checked by the host): the
@@ -726,7 +733,7 @@ struct Seen {
 // MESH: the scene has triangle-mesh nodes.  The BVH walk costs ~35 VGPRs, so scenes made of
 // analytic shapes run the variant compiled without it (one more wave per SIMD).
 // GRID: scenes of many nodes -- every lane finds the nodes its ray can cross through a uniform grid (see the node loop).
-template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH, bool GRID = false>
+template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH, bool GRID = false>
 __device__ __forceinline__ void trace_body(const KArgs& A) {
     extern __shared__ double smem[];
 #if PVT_TIMELINE
@@ -752,8 +759,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 
     // ---- stage tables + zero accumulators --------------------------------
     double* lds_d = smem;
-    int nd_lds = TAB_LDS ? A.nd : 0;
-    int ni_lds = TAB_LDS ? ((A.ni + 1) & ~1) : 0;  // keep 8-byte alignment after the ints
+    const int nd_lds = TAB_LDS == 1 ? A.nd : TAB_LDS == 2 ? A.nd_lds : 0;
+    const int ni_stage = TAB_LDS == 1 ? A.ni : TAB_LDS == 2 ? A.ni_lds : 0;
+    const int ni_lds = (ni_stage + 1) & ~1;  // keep 8-byte alignment after the ints
     int* lds_i = reinterpret_cast<int*>(lds_d + nd_lds);
     double* acc_sums = reinterpret_cast<double*>(lds_i + ni_lds);
     // crossings are 64-bit: a trapped photon crosses surfaces up to `maxsteps` times, and a persistent
@@ -779,9 +787,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         const Word4* src = reinterpret_cast<const Word4*>(A.bvh_top);
         for (int i = threadIdx.x; i < A.top_n * 2; i += kBlock) dst[i] = src[i];
     }
-    if constexpr (TAB_LDS) {
-        for (int i = threadIdx.x; i < A.nd; i += kBlock) lds_d[i] = A.gd[i];
-        for (int i = threadIdx.x; i < A.ni; i += kBlock) lds_i[i] = A.gi[i];
+    if constexpr (TAB_LDS != 0) {
+        for (int i = threadIdx.x; i < nd_lds; i += kBlock) lds_d[i] = A.gd[i];
+        for (int i = threadIdx.x; i < ni_stage; i += kBlock) lds_i[i] = A.gi[i];
     }
     for (int i = threadIdx.x; i < A.n_rec * 8; i += kBlock) acc_sums[i] = 0.0;
     for (int i = threadIdx.x; i < A.n_rec; i += kBlock) { acc_cross[i] = 0ull; acc_distinct[i] = 0u; }
@@ -792,7 +800,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     tl_t[1] = wall_clock64();
 #endif
 
-    Tables<TAB_LDS> T{(CDoubles)A.gd, (CInts)A.gi, TAB_LDS ? lds_d : A.gd, TAB_LDS ? lds_i : A.gi, A.gd, A.gi};
+    Tables<TAB_LDS> T{(CDoubles)A.gd, (CInts)A.gi, TAB_LDS != 0 ? lds_d : A.gd, TAB_LDS != 0 ? lds_i : A.gi, A.gd, A.gi};
 
     // a node's flag word, read by the lane (see ND_BITS)
     auto node_bits = [&](int node) -> unsigned long long { return pvt_d2u(T.dv(node * ND + ND_BITS)); };
@@ -2463,11 +2471,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 // registers: held to 128 they park about sixty values in scratch around the BVH walk (photon state the walk does not
 // touch), and the fourth wave is worth more than that costs -- the walk is a chain of dependent loads: +8 ... +19 % in
 // the pipelined stream, 3.1 -> 2.7 ms for a single 10^6-photon launch on the 327 680-face ball (five waves: worse).
-template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT, bool MESH>
+template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_MESH_WAVES, PVT_MESH_WAVES))) trace_kernel(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, MESH>(A);
 }
-template <bool RECORD, bool TAB_LDS, int SEENW, bool EMIT>
+template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_w4(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, false>(A);
 }
@@ -2476,7 +2484,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
 #endif
 template <bool RECORD, int SEENW, bool EMIT>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_GRID_WAVES, PVT_GRID_WAVES))) trace_kernel_grid(KArgs A) {
-    trace_body<RECORD, true, SEENW, EMIT, false, true>(A);
+    trace_body<RECORD, 1, SEENW, EMIT, false, true>(A);
 }
 
 }  // namespace

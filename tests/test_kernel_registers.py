@@ -27,7 +27,9 @@ def test_register_budgets_of_the_built_kernels(tmp_path):
     analytic = {n: m for n, m in kernels.items() if "trace_kernel_w4" in n}
     mesh = {n: m for n, m in kernels.items() if "12trace_kernelILb" in n}
     grid = {n: m for n, m in kernels.items() if "trace_kernel_grid" in n}
-    assert len(analytic) == 16 and len(mesh) == 16          # {tally, history} x {LDS, global tables} x {64, 256 recorders} x {rays, emitter}
+    # {tally, history} x {tables in LDS, in global memory[, records in LDS and spectra in global memory: analytic scenes only]}
+    # x {64, 256 recorders} x {rays, emitter}
+    assert len(analytic) == 24 and len(mesh) == 16
     assert len(grid) == 8                                    # many-node scenes (tables in LDS): {tally, history} x {64, 256 recorders} x {rays, emitter}
     for name, m in grid.items():
         # four waves per SIMD; the walk of the node grid keeps nearest / second-nearest crossing, the cells' bookkeeping and
@@ -43,7 +45,7 @@ def test_register_budgets_of_the_built_kernels(tmp_path):
         assert m["vgpr_count"] <= 128 and m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
     for name, m in mesh.items():
         assert m["vgpr_count"] <= 128, (name, m)             # held to four waves; what does not fit is parked in scratch
-    headline = [m for n, m in analytic.items() if "w4ILb0ELb1ELi1ELb0E" in n]      # tally, tables in LDS, <= 64 recorders, rays in
+    headline = [m for n, m in analytic.items() if "w4ILb0ELi1ELi1ELb0E" in n]      # tally, tables in LDS, <= 64 recorders, rays in
     assert len(headline) == 1 and headline[0]["sgpr_spill_count"] <= 60, headline
     for name, m in kernels.items():
         if "trace_kernel" not in name:                       # emit / unpack / pack / self-test kernels

@@ -1,7 +1,7 @@
 """Developer tool: static instruction counts per source-line bucket of pvt_trace.hip for one kernel variant."""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernelILb0ELb1ELi1ELb0"
+variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernel_w4ILb0ELi1ELi1ELb0"
 tmp = tempfile.mkdtemp(prefix="isal_")
 src = os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace.hip")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-g", "-std=c++17", "-ffp-contract=off",

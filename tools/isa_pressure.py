@@ -2,7 +2,7 @@
 (a cheap pointer at the register-pressure peak)."""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernelILb0ELb1ELi1ELb0ELb0"
+variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernel_w4ILb0ELi1ELi1ELb0E"
 floor = int(sys.argv[2]) if len(sys.argv) > 2 else 112
 tmp = tempfile.mkdtemp(prefix="isap_")
 src = os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace.hip")

@@ -3,7 +3,7 @@ pvt_trace_kernel.h (+ inlined pvt_math.h attributed to the kernel line that call
 inlined-at chain approximated by 'last kernel-header line seen').  usage: isa_sections.py [src_root]"""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = sys.argv[1] if len(sys.argv) > 1 else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-variant = "trace_kernel_w4ILb0ELb1ELi1ELb0E"
+variant = "trace_kernel_w4ILb0ELi1ELi1ELb0E"
 tmp = tempfile.mkdtemp(prefix="isas_")
 src = os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace.hip")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-g", "-std=c++17", "-ffp-contract=off",

@@ -2,7 +2,7 @@
 histogram + register usage for one kernel variant (default: the bench variant)."""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernel_w4ILb0ELb1ELi1ELb0E"
+variant = sys.argv[1] if len(sys.argv) > 1 else "trace_kernel_w4ILb0ELi1ELi1ELb0E"
 tmp = tempfile.mkdtemp(prefix="isa_")
 src = os.path.join(ROOT, "pvtrace_amd", "csrc", "pvt_trace.hip")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
