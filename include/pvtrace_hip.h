@@ -363,7 +363,8 @@ int pvt_scene_launch_info(PvtScene* scene, int32_t* grid, int32_t* block, int32_
 
 /* Host-only check of the triangle BVH the library builds for mesh node `node` (no GPU needed):
  * every face appears in exactly one leaf, lies inside the boxes of its leaf and of all its
- * ancestors, and the skip links describe a proper depth-first layout; and the copy of the tree's top
+ * ancestors, the children of a record are a pair on one 64-byte line, a left child's skip link is its
+ * sibling and a right child's its parent's; and the copy of the tree's top
  * levels that the trace kernel reads from LDS (cursors and links that name either array), made at five
  * sizes, walks the same records in the same order with the same successors after a hit and after a miss.
  * Returns PVT_OK and the node / leaf counts and the tree depth, or PVT_ERR_INVALID with pvt_last_error(). */

@@ -1,13 +1,17 @@
 // Host-side construction of the triangle BVH the trace kernel walks for PVT_GEOM_MESH nodes.
 //
-// Layout is made for a per-lane, stack-free walk on the GPU: nodes are stored in depth-first
-// order and every node carries a `skip` link (index of the first node after its subtree), so
-// the traversal is `i = hit ? i + 1 : skip[i]` with no per-lane stack in scratch or LDS.  A
-// photon needs EVERY forward crossing of a mesh (the container rule counts them,
+// Layout is made for a per-lane, stack-free walk on the GPU: every record carries two links -- `skip`, the
+// record to go to when its box is missed or its subtree is done, and `link`, its first child (inner records) or
+// its triangle (leaves) -- so the traversal is `i = hit && inner ? link[i] : skip[i]` with no per-lane stack in
+// scratch or LDS.  The two children of a record are stored NEXT TO EACH OTHER, as a 64-byte-aligned pair: the
+// walk visits both whenever it hits their parent (the left one's skip link is the right one), so the cache line
+// fetched for the left child serves the right one as well.  (Until round 4 the records were in depth-first order
+// with the left child implied at i + 1: one and a half lines per parent instead of one, and the right child always a
+// fresh request to L2.)  A photon needs EVERY forward crossing of a mesh (the container rule counts them,
 // _kernel.pyx:684-714), so front-to-back ordering buys nothing and a fixed order is free.
-// The tree is built with a binned surface-area heuristic.  Leaves hold one triangle, pre-gathered (vertices + face normal +
-// face id) so a leaf is one contiguous run of 104-byte records.  Nodes are 32 bytes (f32 boxes
-// rounded outwards): culling is only a filter, the triangle test itself stays f64.
+// The tree is built with a binned surface-area heuristic.  Leaves hold one triangle, pre-gathered (vertices + face
+// normal + face id) in a 104-byte record.  Records are 32 bytes (f32 boxes rounded outwards): culling is only a
+// filter, the triangle test itself stays f64.
 //
 // The boxes are stored RELATIVE TO THE CENTRE of the mesh's bounding box and padded by 4e-6 of its diagonal:
 // the kernel tests them in f32 against a ray re-originated at its entry into the root box, so every
@@ -25,11 +29,14 @@
 
 namespace pvt {
 
-struct alignas(16) BvhNode {      // 32 bytes: two nodes per 64-byte line, half the traffic of f64 boxes
+struct alignas(16) BvhNode {      // 32 bytes: a pair of siblings per 64-byte line, half the traffic of f64 boxes
     float lo[3], hi[3];   // box relative to the mesh's centre, padded, rounded OUTWARDS to f32: still conservative
-    int skip;             // next node when this subtree is culled or finished
-    int leaf;             // leaves: (first triangle record << 4) | triangle count (1..8); inner: 0
+    int skip;             // where to go when this subtree is culled or finished (a cursor, see kTopFlag)
+    int link;             // leaves: kLeafFlag | triangle record; inner records: the first child (a cursor), its sibling follows it
 };
+constexpr int kLeafFlag = (int)0x80000000;   // (a leaf's link is negative)
+constexpr int kTopFlag = 1 << 30;            // a cursor with this bit names a slot of the copy in LDS (stage_top), else a record in global memory
+constexpr int kIndexMask = kTopFlag - 1;
 struct MeshTri {      // 104 bytes
     double v[9];      // three vertices, node-local frame
     double n[3];      // outward unit face normal
@@ -39,11 +46,7 @@ struct MeshTri {      // 104 bytes
 // Leaf size: the watertight triangle test costs several box tests (185 vector instructions against 40, and the boxes of
 // a small tree are read from LDS), so every leaf holds ONE triangle.  (Rounds 1-3 gave meshes of up to 32 faces leaves of
 // eight; with round 4's walk one triangle per leaf is 24 % faster on the 12-triangle slab and 52 % on the L-shaped prism:
-// profiles/r04_mesh_walk_series.txt.  The record format still allows up to 15.)
-#ifndef PVT_LEAF_TRIANGLES
-#define PVT_LEAF_TRIANGLES 1
-#endif
-constexpr int kLeafTriangles = PVT_LEAF_TRIANGLES;
+// profiles/r04_mesh_walk_series.txt.)
 
 class BvhBuilder {
 public:
@@ -79,8 +82,14 @@ public:
             if (centre) centre[a] = c_[a];
         }
         f0_ = f0;
+        // the root at an even index with an unused record after it, so that every pair of siblings shares a 64-byte line
+        if (nodes_.size() & 1) nodes_.push_back(unused());
         const int root = (int)nodes_.size();
-        build(0, count);
+        nodes_.push_back(BvhNode{});
+        nodes_.push_back(unused());
+        build(root, 0, count);
+        link_skips(root, (int)nodes_.size());   // the tree's end: one past its last record
+        nodes_[root + 1].skip = (int)nodes_.size();
         return root;
     }
 
@@ -97,28 +106,38 @@ private:
                 }
         }
     }
-    void build(int begin, int end) {
-        const int me = (int)nodes_.size();
-        nodes_.push_back(BvhNode{});
+    static BvhNode unused() {   // (never walked; an empty box and links that end a walk, should one ever get here)
+        BvhNode b{};
+        for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+        b.link = kLeafFlag;
+        return b;
+    }
+    // skip links, from the top: the left child's is its sibling, the right child's is its parent's
+    void link_skips(int me, int skip) {
+        nodes_[me].skip = skip;
+        if (nodes_[me].link >= 0) {
+            const int c = nodes_[me].link;
+            link_skips(c, c + 1);
+            link_skips(c + 1, skip);
+        }
+    }
+    void build(int me, int begin, int end) {
         double lo[3], hi[3];
         bounds(begin, end, lo, hi);
         for (int a = 0; a < 3; a++) {
             nodes_[me].lo[a] = std::nextafter((float)(lo[a] - pad_ - c_[a]), -INFINITY);   // (float) rounds to nearest:
             nodes_[me].hi[a] = std::nextafter((float)(hi[a] + pad_ - c_[a]), INFINITY);    // one more step outwards
         }
-        if (end - begin <= leaf_) {
-            nodes_[me].leaf = ((int)tris_.size() << 4) | (end - begin);
-            std::sort(order_.begin() + begin, order_.begin() + end);   // face order inside a leaf
-            for (int k = begin; k < end; k++) {
-                const int face = order_[k];
-                const int32_t* idx = f_ + 3 * (size_t)face;
-                MeshTri t{};
-                for (int c = 0; c < 3; c++)
-                    for (int a = 0; a < 3; a++) t.v[3 * c + a] = v_[3 * (size_t)idx[c] + a];
-                for (int a = 0; a < 3; a++) t.n[a] = n_[3 * (size_t)face + a];
-                t.face = face;
-                tris_.push_back(t);
-            }
+        if (end - begin <= 1) {
+            nodes_[me].link = kLeafFlag | (int)tris_.size();
+            const int face = order_[begin];
+            const int32_t* idx = f_ + 3 * (size_t)face;
+            MeshTri t{};
+            for (int c = 0; c < 3; c++)
+                for (int a = 0; a < 3; a++) t.v[3 * c + a] = v_[3 * (size_t)idx[c] + a];
+            for (int a = 0; a < 3; a++) t.n[a] = n_[3 * (size_t)face + a];
+            t.face = face;
+            tris_.push_back(t);
         } else {
             // Binned surface-area heuristic: for each axis the centroids fall into kBins bins; the split plane
             // between two bins that minimises  area(left) * n_left + area(right) * n_right  wins (the expected
@@ -201,11 +220,13 @@ private:
                                      return ca < cb || (ca == cb && a < b);
                                  });
             }
-            nodes_[me].leaf = 0;
-            build(begin, mid);
-            build(mid, end);
+            const int c = (int)nodes_.size();   // the children, side by side
+            nodes_.push_back(BvhNode{});
+            nodes_.push_back(BvhNode{});
+            nodes_[me].link = c;
+            build(c, begin, mid);
+            build(c + 1, mid, end);
         }
-        nodes_[me].skip = (int)nodes_.size();
     }
 
     const double* v_;
@@ -218,41 +239,36 @@ private:
     double pad_ = 0.0;
     double c_[3] = {0.0, 0.0, 0.0};
     int f0_ = 0;
-    int leaf_ = kLeafTriangles;
 };
 
 // ---- the top of the trees, for LDS ------------------------------------------------------------------------
 // The kernel's walk waits for its records far longer than it computes with them, and every ray passes the top
 // levels of a tree.  `stage_top` picks, for every tree, the levels that fit a budget of records (small trees
-// whole, the rest sharing what is left), copies them -- in depth-first order, so the successor after a hit is
-// still the next record -- to `top`, the image a workgroup loads into LDS, and re-writes the links:
-//   * a cursor / link is a record's index in `nodes`, or kTopFlag | slot in `top`; the tree's end stays what it was
-//     (the root's old skip link: the walk is over when the cursor equals it);
-//   * `skip` of every record, in both arrays, names its target in that form (a skip link leads to a sibling or to
-//     an ancestor's sibling -- never deeper than its source -- so links INTO the copy come from everywhere, links
-//     out of it only from its last level);
-//   * an inner record on the copy's last level names its first child -- record i + 1 of `nodes` -- in `leaf`
-//     as (i + 1) << 4 (count bits zero: still not a leaf); other inner records of the copy keep 0: next slot;
-//   * the root's record in `nodes` (never walked when a copy exists) names its slot in `leaf` as (slot + 1) << 4.
+// whole, the rest sharing what is left), copies them -- in the order they have in `nodes`, so siblings stay side by
+// side -- to `top`, the image a workgroup loads into LDS, and re-writes the links of BOTH arrays as cursors: a
+// record's index in `nodes`, or kTopFlag | slot in `top` when the record has a copy.  The tree's end stays what it
+// was (the root's skip link: the walk is over when the cursor equals it).  A skip link leads to a sibling or to an
+// ancestor's sibling -- never deeper than its source -- so links INTO the copy come from everywhere, links out of
+// it only from the child links of its last level.  The root's record in `nodes` is never walked when a copy exists,
+// but it is where the kernel learns of it: its child link then names slot + 1 of the root's own copy.
 // Trees without a copy (no budget, or a single leaf) are left as they were.  Results never depend on any of this.
-constexpr int kTopFlag = 1 << 30;
-
 inline void stage_top(std::vector<BvhNode>& nodes, const std::vector<int>& roots, size_t budget, std::vector<BvhNode>& top) {
     top.clear();
     struct Tree { int root, end; std::vector<int> depth; std::vector<size_t> per_level; };
     std::vector<Tree> trees;
     for (int r : roots) {
-        Tree t{r, nodes[r].skip, {}, {}};
-        if ((nodes[r].leaf & 15) != 0) continue;   // a single leaf
-        t.depth.resize(t.end - r);
-        std::vector<int> open_end;
-        for (int i = r; i < t.end; i++) {
-            while (!open_end.empty() && open_end.back() <= i) open_end.pop_back();
-            const size_t d = open_end.size();
-            t.depth[i - r] = (int)d;
+        if (nodes[r].link < 0) continue;   // a single leaf
+        Tree t{r, nodes[r].skip, std::vector<int>((size_t)(nodes[r].skip - r), -1), {}};
+        std::vector<int> todo{r};
+        t.depth[0] = 0;
+        while (!todo.empty()) {
+            const int i = todo.back();
+            todo.pop_back();
+            const size_t d = (size_t)t.depth[i - r];
             if (t.per_level.size() <= d) t.per_level.resize(d + 1, 0);
             t.per_level[d] += 1;
-            if ((nodes[i].leaf & 15) == 0) open_end.push_back(nodes[i].skip);
+            if (nodes[i].link >= 0)
+                for (int c = nodes[i].link; c < nodes[i].link + 2; c++) { t.depth[c - r] = (int)d + 1; todo.push_back(c); }
         }
         trees.push_back(std::move(t));
     }
@@ -279,33 +295,30 @@ inline void stage_top(std::vector<BvhNode>& nodes, const std::vector<int>& roots
         const Tree& t = trees[k];
         const int L = last_level[k];
         if (L < 0) continue;
-        const int base = (int)top.size();
-        std::vector<int> slot(t.end - t.root, -1);
-        int next = base;
+        std::vector<int> slot((size_t)(t.end - t.root), -1);
+        int next = (int)top.size();
         for (int i = t.root; i < t.end; i++)
-            if (t.depth[i - t.root] <= L) slot[i - t.root] = next++;
+            if (t.depth[i - t.root] >= 0 && t.depth[i - t.root] <= L) slot[i - t.root] = next++;
+        auto cursor = [&](int target) { return target == t.end || slot[target - t.root] < 0 ? target : (kTopFlag | slot[target - t.root]); };
         for (int i = t.root; i < t.end; i++) {
-            const int target = nodes[i].skip;
-            const int link = target == t.end ? t.end : (slot[target - t.root] >= 0 ? (kTopFlag | slot[target - t.root]) : target);
-            nodes[i].skip = link;
-            if (slot[i - t.root] >= 0) {
-                BvhNode b = nodes[i];
-                if ((b.leaf & 15) == 0 && t.depth[i - t.root] == L) b.leaf = (i + 1) << 4;
-                top.push_back(b);
-            }
+            if (t.depth[i - t.root] < 0) continue;   // (the unused record after the root)
+            nodes[i].skip = cursor(nodes[i].skip);
+            if (nodes[i].link >= 0) nodes[i].link = cursor(nodes[i].link);
+            if (slot[i - t.root] >= 0) top.push_back(nodes[i]);
         }
-        nodes[t.root].leaf = (base + 1) << 4;
     }
 }
 
 // What the kernel's walk does with a cursor, restated for the host-side check of `stage_top` (pvt_mesh_bvh_check):
 // the record a cursor names, and the cursor after it for a hit / a miss.
 inline const BvhNode& at_cursor(const std::vector<BvhNode>& nodes, const std::vector<BvhNode>& top, int cursor) {
-    return (cursor & kTopFlag) ? top[cursor & ~kTopFlag] : nodes[cursor];
+    return (cursor & kTopFlag) ? top[cursor & kIndexMask] : nodes[cursor];
 }
-inline int next_cursor(const BvhNode& b, int cursor, bool hit) {
-    if (!hit || (b.leaf & 15) != 0) return b.skip;
-    return b.leaf != 0 ? (b.leaf >> 4) : cursor + 1;
+inline int next_cursor(const BvhNode& b, bool hit) { return hit && b.link >= 0 ? b.link : b.skip; }
+// where a walk of the tree rooted at record `root` starts: the root's copy when there is one (see stage_top)
+inline int first_cursor(const std::vector<BvhNode>& nodes, int root) {
+    const int link = nodes[root].link;
+    return link >= 0 && (link & kTopFlag) ? (kTopFlag | ((link & kIndexMask) - 1)) : root;
 }
 
 }  // namespace pvt

@@ -1009,7 +1009,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         // (the kernel applies the same rule per tree)
         s->meshq = 1;
         for (int r : bvh_roots)
-            if (bvh_nodes[r].skip - r > 15) s->meshq = kMeshQ;
+            if (bvh_nodes[r].skip - r > 16) s->meshq = kMeshQ;   // (15 records and the unused one after the root)
         // The top levels of the trees go to LDS (pvt_bvh.h: stage_top), as many records as leave four workgroups per CU
         // -- the mesh variants' four waves per SIMD -- their LDS in either kind of launch (tallies / histories).
         {
@@ -1636,72 +1636,75 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
     std::vector<pvt::MeshTri> tris;
     double centre[3];
     const int root = pvt::BvhBuilder(t->mesh_vertices, t->mesh_faces, t->mesh_normals, nodes, tris).add_mesh(f0, fc, centre);
-    if (root != 0 || nodes.empty() || nodes[0].skip != (int)nodes.size()) return fail(PVT_ERR_INVALID, "root skip link");
+    if (root != 0 || nodes.size() < 2 || nodes[0].skip != (int)nodes.size()) return fail(PVT_ERR_INVALID, "root skip link");
     std::vector<int> seen(fc, 0);
-    int leaves = 0, max_depth = 0;
-    // walk the depth-first layout with an explicit ancestor stack (end index of each open subtree)
-    std::vector<int> open_end, open_id;
-    for (int i = 0; i < (int)nodes.size(); i++) {
-        while (!open_end.empty() && open_end.back() <= i) { open_end.pop_back(); open_id.pop_back(); }
-        const pvt::BvhNode& b = nodes[i];
-        if (b.skip <= i || b.skip > (int)nodes.size()) return fail(PVT_ERR_INVALID, "skip link does not move forward");
-        if (!open_end.empty() && b.skip > open_end.back()) return fail(PVT_ERR_INVALID, "subtree leaves its parent");
+    int leaves = 0, records = 0, max_depth = 0;
+    // from the root down (an explicit stack of {record, parent, depth, the skip link it must carry})
+    struct Open { int id, parent, depth, skip; };
+    std::vector<Open> todo{{0, -1, 1, (int)nodes.size()}};
+    std::vector<char> visited(nodes.size(), 0);
+    while (!todo.empty()) {
+        const Open o = todo.back();
+        todo.pop_back();
+        if (o.id < 0 || o.id >= (int)nodes.size() || visited[o.id]++) return fail(PVT_ERR_INVALID, "child link out of range or shared");
+        const pvt::BvhNode& b = nodes[o.id];
+        records += 1;
+        max_depth = std::max(max_depth, o.depth);
+        if (b.skip != o.skip) return fail(PVT_ERR_INVALID, "skip link: a left child's is its sibling, a right child's its parent's");
         for (int a = 0; a < 3; a++) {
             if (!(b.lo[a] <= b.hi[a])) return fail(PVT_ERR_INVALID, "empty box");
-            if (!open_id.empty() && (b.lo[a] < nodes[open_id.back()].lo[a] || b.hi[a] > nodes[open_id.back()].hi[a]))
+            if (o.parent >= 0 && (b.lo[a] < nodes[o.parent].lo[a] || b.hi[a] > nodes[o.parent].hi[a]))
                 return fail(PVT_ERR_INVALID, "child box not inside its parent");
         }
-        max_depth = std::max(max_depth, (int)open_end.size() + 1);
-        if ((b.leaf & 15) > 0) {
-            if (b.skip != i + 1) return fail(PVT_ERR_INVALID, "leaf with a subtree");
+        if (b.link < 0) {
             leaves += 1;
-            for (int k = 0; k < (b.leaf & 15); k++) {
-                const pvt::MeshTri& tr = tris[(b.leaf >> 4) + k];
-                const long long local = tr.face - f0;
-                if (local < 0 || local >= fc || seen[local]++) return fail(PVT_ERR_INVALID, "face missing or duplicated");
-                for (int c = 0; c < 3; c++)
-                    for (int a = 0; a < 3; a++) {
-                        if (tr.v[3 * c + a] != t->mesh_vertices[3 * (size_t)t->mesh_faces[3 * (size_t)tr.face + c] + a])
-                            return fail(PVT_ERR_INVALID, "gathered vertex differs from the table");
-                        if (tr.v[3 * c + a] - centre[a] < b.lo[a] || tr.v[3 * c + a] - centre[a] > b.hi[a])
-                            return fail(PVT_ERR_INVALID, "triangle outside its leaf box");
-                    }
-            }
+            const int tri = b.link & pvt::kIndexMask;
+            if (tri >= (int)tris.size()) return fail(PVT_ERR_INVALID, "triangle record out of range");
+            const pvt::MeshTri& tr = tris[tri];
+            const long long local = tr.face - f0;
+            if (local < 0 || local >= fc || seen[local]++) return fail(PVT_ERR_INVALID, "face missing or duplicated");
+            for (int c = 0; c < 3; c++)
+                for (int a = 0; a < 3; a++) {
+                    if (tr.v[3 * c + a] != t->mesh_vertices[3 * (size_t)t->mesh_faces[3 * (size_t)tr.face + c] + a])
+                        return fail(PVT_ERR_INVALID, "gathered vertex differs from the table");
+                    if (tr.v[3 * c + a] - centre[a] < b.lo[a] || tr.v[3 * c + a] - centre[a] > b.hi[a])
+                        return fail(PVT_ERR_INVALID, "triangle outside its leaf box");
+                }
         } else {
-            if (b.skip == i + 1) return fail(PVT_ERR_INVALID, "inner node without children");
-            open_end.push_back(b.skip);
-            open_id.push_back(i);
+            const int c = b.link;
+            if (c <= o.id || (c & 1) != 0) return fail(PVT_ERR_INVALID, "children not a pair on one 64-byte line after their parent");
+            todo.push_back({c + 1, o.id, o.depth + 1, o.skip});
+            todo.push_back({c, o.id, o.depth + 1, c + 1});
         }
     }
     for (int k = 0; k < fc; k++) if (seen[k] != 1) return fail(PVT_ERR_INVALID, "face missing from the tree");
-    // the copy of the top levels for LDS (pvt_bvh.h: stage_top), at several budgets: the walk through cursors must name the
-    // same records, in the same order, with the same successors after a hit and after a miss as the plain tree
+    if (records + 1 != (int)nodes.size() || visited[1]) return fail(PVT_ERR_INVALID, "records outside the tree");   // (one unused record follows the root)
+    // the copy of the top levels for LDS (pvt_bvh.h: stage_top), at several budgets: a walk through the cursors that hits
+    // every box must name the records the plain walk names, in its order, and a miss must lead where the plain skip link leads
     auto replay = [](const std::vector<pvt::BvhNode>& plain, const std::vector<pvt::BvhNode>& staged,
                      const std::vector<pvt::BvhNode>& top, int root) -> const char* {
         const int end = plain[root].skip;
         std::vector<int> cursor_of((size_t)(end - root) + 1, -1);
         cursor_of[(size_t)(end - root)] = end;
-        int c = root;
-        const int hint = staged[root].leaf;
-        if ((plain[root].leaf & 15) == 0 && hint != 0) {   // the tree has a copy: its root names the slot
-            if ((hint & 15) != 0) return "root does not name its copy";
-            c = pvt::kTopFlag | ((hint >> 4) - 1);
-        }
-        for (int i = root; i < end; i++) {   // a walk that hits every box visits the records in order
+        std::vector<int> order;
+        int c = pvt::first_cursor(staged, root);
+        for (int i = root; i != end; i = pvt::next_cursor(plain[i], true)) {
             if (c == end) return "staged walk ends early";
-            if ((c & pvt::kTopFlag) ? (size_t)(c & ~pvt::kTopFlag) >= top.size() : (c < root || c >= end)) return "cursor out of range";
+            if ((c & pvt::kTopFlag) ? (size_t)(c & pvt::kIndexMask) >= top.size() : (c < root || c >= end)) return "cursor out of range";
+            if (cursor_of[(size_t)(i - root)] >= 0) return "plain walk visits a record twice";
             cursor_of[(size_t)(i - root)] = c;
+            order.push_back(i);
             const pvt::BvhNode& rec = pvt::at_cursor(staged, top, c);
             for (int a = 0; a < 3; a++)
                 if (rec.lo[a] != plain[i].lo[a] || rec.hi[a] != plain[i].hi[a]) return "staged walk out of order";
-            if ((plain[i].leaf & 15) != 0 && rec.leaf != plain[i].leaf) return "staged leaf differs";
-            if ((plain[i].leaf & 15) == 0 && (rec.leaf & 15) != 0) return "staged inner record reads as a leaf";
-            c = pvt::next_cursor(rec, c, true);
+            if ((plain[i].link < 0) != (rec.link < 0) || (plain[i].link < 0 && rec.link != plain[i].link)) return "staged leaf differs";
+            c = pvt::next_cursor(rec, true);
+            if (order.size() > (size_t)(end - root)) return "plain walk does not end";
         }
         if (c != end) return "staged walk does not end at the tree's end";
-        for (int i = root; i < end; i++) {   // ... and a miss leads where the plain skip link leads
+        for (int i : order) {
             const pvt::BvhNode& rec = pvt::at_cursor(staged, top, cursor_of[(size_t)(i - root)]);
-            if (pvt::next_cursor(rec, cursor_of[(size_t)(i - root)], false) != cursor_of[(size_t)(plain[i].skip - root)]) return "staged skip link differs";
+            if (pvt::next_cursor(rec, false) != cursor_of[(size_t)(plain[i].skip - root)]) return "staged skip link differs";
         }
         return nullptr;
     };
@@ -1729,7 +1732,7 @@ int pvt_mesh_bvh_check(const PvtSceneTables* t, int32_t node, int32_t* n_bvh_nod
                 if (const char* what = replay(all, staged, top, r)) return fail(PVT_ERR_INVALID, what);
         }
     }
-    if (n_bvh_nodes) *n_bvh_nodes = (int32_t)nodes.size();
+    if (n_bvh_nodes) *n_bvh_nodes = (int32_t)records;
     if (n_leaves) *n_leaves = leaves;
     if (depth_out) *depth_out = max_depth;
     return PVT_OK;

@@ -1670,7 +1670,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     const __attribute__((address_space(4))) pvt::BvhNode* const rootp =
                         (const __attribute__((address_space(4))) pvt::BvhNode*)(A.bvh + i);
                     const float rlo[3] = {rootp->lo[0], rootp->lo[1], rootp->lo[2]}, rhi[3] = {rootp->hi[0], rootp->hi[1], rootp->hi[2]};
-                    const int end = rootp->skip, rleaf = rootp->leaf;
+                    const int end = rootp->skip, rlink = rootp->link;
+                    const int n_records = end - i;   // (before the cursor moves to the copy)
                     pvt::BvhNode b;
                     // The boxes are tested in f32, relative to the mesh's centre (the node's parameter slots) and from where
                     // the ray ENTERS the root box -- every quantity then has the mesh's own size, the test's rounding displaces
@@ -1685,9 +1686,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             t_near = __builtin_fmax(t_near, __builtin_fmin(ta, tb));
                             t_far = __builtin_fmin(t_far, __builtin_fmax(ta, tb));
                         }
-                        if ((rleaf & 15) == 0 && rleaf != 0) {   // the root's copy in LDS
-                            i = pvt::kTopFlag | ((rleaf >> 4) - 1);
-                            b = ltop[i & ~pvt::kTopFlag];
+                        if (rlink >= 0 && (rlink & pvt::kTopFlag) != 0) {   // the tree has a copy in LDS: the root's slot precedes its children's
+                            i = rlink - 1;
+                            b = ltop[i & pvt::kIndexMask];
                         } else {
                             b = record_at(i);
                         }
@@ -1711,7 +1712,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                     // compiler carried through every path of the walk -- 14 moves per box)
                     unsigned int* const mq = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(smem) + A.meshq_off) + threadIdx.x;
                     int qn = 0;
-                    const int qcap = end - T.iu(node * NI + NI_MESH) <= 15 ? 1 : kMeshQ;
+                    const int qcap = n_records <= 16 ? 1 : kMeshQ;
                     for (;;) {
                         // ---- walk: every lane goes on until its walk is over or its slots are full
                         for (;;) {
@@ -1728,20 +1729,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                                     tmin = __builtin_fmaxf(tmin, __builtin_fminf(ta, tb));
                                     tmax = __builtin_fminf(tmax, __builtin_fmaxf(ta, tb));
                                 }
-                                // the successor: after a miss and after a leaf the skip link; after a hit of an inner node the next
-                                // record (depth-first order) -- which for the last level of the copy in LDS is named in `leaf`
+                                // the successor: after a miss and after a leaf the skip link, after a hit of an inner record its first
+                                // child (whose own skip link is its sibling, in the same 64-byte line)
                                 int next = b.skip;
                                 if (!(tmax < tmin)) {
-                                    if ((b.leaf & 15) != 0) {   // a leaf: its triangles later (the newest note first: any order will do)
-                                        mq[qn * kBlock] = (unsigned int)b.leaf;
+                                    if (b.link < 0) {   // a leaf: its triangle later (the newest note first: any order will do)
+                                        mq[qn * kBlock] = (unsigned int)b.link;
                                         qn += 1;
                                     } else {
-                                        next = b.leaf != 0 ? (b.leaf >> 4) : i + 1;
+                                        next = b.link;
                                     }
                                 }
                                 i = next;
                                 if (i != end) {
-                                    if (i & pvt::kTopFlag) b = ltop[i & ~pvt::kTopFlag];
+                                    if (i & pvt::kTopFlag) b = ltop[i & pvt::kIndexMask];
                                     else b = record_at(i);
                                 }
                             }
@@ -1751,7 +1752,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             if (qn > 0) {
                                 qn -= 1;
                                 const int leaf = (int)mq[qn * kBlock];
-                                const int tn = leaf & 15, tri_start = leaf >> 4;
+                                constexpr int tn = 1;   // (one triangle per leaf: pvt_bvh.h)
+                                const int tri_start = leaf & pvt::kIndexMask;
                                 const pvt::MeshTri* tr = tris + tri_start;
                                 for (int k = 0; k < tn; k++, tr++) {
 #if PVT_STATS
