@@ -1214,11 +1214,14 @@ LdsPlan plan_lds(const PvtScene* s, bool record) {
     lp.tq_pos = s->hist_reads_position ? 1 : 0;
     const size_t tq_bytes = (size_t)kWaves * kTallyQ * ((lp.tq_pos ? 7 : 4) * 8 + 4);
     if (acc_bytes + tq_bytes > lds_limit) { lp.ok = false; return lp; }
-    lp.tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget;
+    // (PVT_TABLES: developer / test switch -- "global": no tables in LDS, "heads": never the spectra)
+    const char* force = getenv("PVT_TABLES");
+    lp.tab_lds = acc_bytes + tq_bytes + tab_bytes <= budget && !force;
     // spectra too large for LDS: everything else -- node, component and recorder records, class tables -- still is staged
     // (the blobs' heads; the spectra and their guide tables are read from global memory)
     const size_t small_bytes = (size_t)s->nd_small * 8 + (size_t)((s->ni_small + 1) & ~1) * 4;
-    lp.small_lds = !lp.tab_lds && s->meshq == 0 && acc_bytes + tq_bytes + small_bytes <= 40 * 1024 && acc_bytes + tq_bytes + small_bytes <= budget;
+    lp.small_lds = !lp.tab_lds && s->meshq == 0 && acc_bytes + tq_bytes + small_bytes <= 40 * 1024 && acc_bytes + tq_bytes + small_bytes <= budget &&
+                   !(force && force[0] == 'g');
     size_t lds = acc_bytes + tq_bytes + (lp.tab_lds ? tab_bytes : lp.small_lds ? small_bytes : 0);
     lp.bins_in_lds = (lds + bins_bytes <= budget) ? 1 : 0;
     if (lp.bins_in_lds) lds += bins_bytes;

@@ -311,8 +311,16 @@ def test_histograms_too_large_for_lds_fall_back_to_global_atomics():
     assert cpu["rec_bins"].sum() == cpu["rec_distinct"][0] > 0
 
 
-def test_spectra_too_large_for_lds_are_read_from_hbm():
+@pytest.mark.parametrize("tables", ["as the library places them", "heads", "global"])
+def test_spectra_too_large_for_lds_are_read_from_hbm(tables, monkeypatch):
+    """Three placements of the scene tables (kernel template TAB_LDS): everything in LDS; records and class tables in LDS
+    with the spectra and their guide tables in global memory (what the library picks here); everything in global memory
+    (what is left when not even the records fit) -- the last two also forced on the headline-sized scene."""
     from pvtrace_amd import Absorber, Box, Light, Luminophore, Material, Node, Scene, Sphere
+    if tables != "as the library places them":
+        monkeypatch.setenv("PVT_TABLES", tables)
+        gpu, cpu = gpu_and_oracle(scenes.lsc_equivalent(), 2000, (1, 48, 1000, 0))
+        assert_bundles_identical(gpu, cpu, sums_rtol=1e-12)
     from pvtrace_amd.material import gaussian
     x = np.linspace(300.0, 1000.0, 6000)        # 4 pooled tables x 6000 doubles = 192 KB > LDS
     world = Node(name="world", geometry=Sphere(10.0, material=Material(1.0)))
