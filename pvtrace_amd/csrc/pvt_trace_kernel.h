@@ -1612,7 +1612,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 } else if (MESH && gt == PVT_GEOM_MESH) {
                     // EXTENSION (no reference counterpart, see include/pvtrace_hip.h): every
                     // forward crossing of the node's triangles, found by a stack-free walk of
-                    // the depth-first BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
+                    // the BVH (pvt_bvh.h).  Crossings of one mesh are ordered by
                     // (t, face) so the result does not depend on the walk order.
                     const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
                     const double ax = pvt_fabs(d.x), ay = pvt_fabs(d.y), az = pvt_fabs(d.z);
