@@ -19,11 +19,13 @@ with an RCCL all-reduce inside the timed region.
 
 Rank 0 prints ONE JSON line; see the task contract for the fields.  `value` is the
 MEDIAN of `1 + --repeats` independent, identically fenced windows of --steps steps
-(`repeats` holds min / max / the first window).  `roofline` is for the trace kernel:
+(`repeats` holds min / max / the first window).  `roofline` is for the trace kernel.
+Its operative bound is FP64 VALU issue (`bound`, `frac` = VALU busy while the launches
+overlap); the HBM figure the metric asks for sits beside it in `roofline.hbm`:
 achieved = 56 algorithmic bytes/photon x photons per launch / mean launch duration
-(HIP events on the launch stream).  This path is NOT HBM-bound (DESIGN.md
-§Roofline): the fraction is reported because the metric asks for it, next to the
-instruction-side numbers that actually bound it.  `configs` holds the same
+(HIP events on the launch stream) against 8 TB/s, with the PMC-measured traffic.
+`roofline.steps_per_photon` and `roofline.lane_utilisation` are counted by the kernel
+itself during the timed windows (pvt_scene_counters), not read from a profile.  `configs` holds the same
 measurement for BASELINE configs[3] (nested_cylinders) and configs[4] (coated slab +
 scatterer) at 10^7 photons per GPU, pipelined, device-side emission.
 `cpu_baseline` times the CPU referee (a port of the reference kernel, proven
@@ -172,12 +174,33 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def load_pmc(name, value_per_gpu, cus):
-    """Instruction-side numbers of a config from the last committed PMC passes of this same command
-    (tools/gpu_pmc.sh -> profiles/pmc_summary[_cfgN].json), scaled by the measured rate."""
+def live_counters(counters, photons):
+    """What the kernel counted itself during the timed windows (pvt_scene_counters: two scalar adds per wave and trip of
+    the photon loop, always on): trips per photon, the reference's loop count per photon, lanes holding a live photon."""
+    if not counters or not counters.get("wave_iterations") or photons <= 0:
+        return None
+    return {
+        "measured_in_this_run": True,
+        "photons": photons,
+        "steps_per_photon": counters["steps"] / photons,                        # = `count` of _kernel.pyx:655 per photon
+        "lane_steps_per_photon": counters["lane_steps"] / photons,              # ... of which run (the rest: fused exits)
+        "fused_exits_per_photon": counters["fused_exits"] / photons,
+        "wave_iterations_per_photon": counters["wave_iterations"] / photons,
+        "lane_utilisation": counters["lane_utilisation"],                       # live lanes / 64 when a wave steps
+    }
+
+
+def load_pmc(name, value_per_gpu, cus, live=None):
+    """Instruction-side numbers of a config.  Two kinds, labelled as such: what the kernel counts itself in THIS run
+    (`in_kernel`: trips of the photon loop, live lanes per trip) and what only hardware counters can tell (vector
+    instructions issued: the last committed PMC passes of this same command, tools/gpu_pmc.sh ->
+    profiles/pmc_summary[_cfgN].json).  The two are tied together where possible: the PMC pass recorded the vector
+    instructions PER TRIP of a wave; multiplied by the trips per photon counted in this run that is the instruction
+    count per photon of THIS run's kernel as far as its control flow goes (a change that adds trips shows up; one that
+    adds instructions inside a trip needs a new PMC pass)."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json" if name == "cfg2" else f"pmc_summary_{name}.json")
     if not os.path.exists(path):
-        return None, None
+        return None, ({"measured_in_this_run": False, "in_kernel": live} if live else None)
     try:
         summary = json.load(open(path))
         derived = summary.get("derived", {})
@@ -186,6 +209,7 @@ def load_pmc(name, value_per_gpu, cus):
             # it samples, so they cannot be taken in the timed run); only the photon rate they are scaled by is measured here
             "measured_in_this_run": False,
             "source": os.path.relpath(path, ROOT) + " (" + str(summary.get("stage", "")) + ")",
+            "in_kernel": live,
             "valu_wave_instructions_per_photon": derived.get("valu_wave_instructions_per_photon"),
             "valu_lane_utilisation": derived.get("valu_lane_utilisation"),
             "wait_fraction_of_wave_cycles": derived.get("wait_any_fraction_of_wave_cycles"),
@@ -194,6 +218,12 @@ def load_pmc(name, value_per_gpu, cus):
             "valu_busy_measured_single_launch": derived.get("valu_busy_measured"),
         }
         per_photon = derived.get("valu_wave_instructions_per_photon")
+        per_trip = derived.get("valu_wave_instructions_per_wave_iteration")
+        if per_trip and live:
+            per_photon = per_trip * live["wave_iterations_per_photon"]
+            side["valu_wave_instructions_per_wave_iteration_pmc"] = per_trip
+            side["valu_wave_instructions_per_photon"] = per_photon
+            side["valu_wave_instructions_per_photon_is"] = "PMC instructions per trip x trips per photon counted in this run"
         if per_photon:
             # the operative ceiling: VALU issue.  Nominal: one wave64 FP64 instruction per SIMD every 4
             # cycles at 2.4 GHz.  ACHIEVABLE on this part with the kernel's four waves per SIMD: a pure
@@ -216,7 +246,7 @@ def load_pmc(name, value_per_gpu, cus):
                 side["wave_slot_occupancy_measured_under_overlap"] = c["wave_slot_occupancy"]
         return summary.get("hbm_bytes_per_launch"), side
     except Exception:
-        return None, None
+        return None, ({"measured_in_this_run": False, "in_kernel": live} if live else None)
 
 
 def main():
@@ -395,6 +425,7 @@ def main():
     # ------------------------------------------------------------------ main loop (the contract's K steps)
     leg = Leg(args.config, n)
     leg.spin_up(args.spinup_s, args.warmup)
+    leg.dscene.counters(reset=True)   # the kernel's own step counters, over the timed windows (read after the last one)
     first_dt = leg.window(args.warmup, args.steps, timed_events=True)
     kernel_ms = leg.pipe.kernel_ms()
     mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
@@ -405,6 +436,7 @@ def main():
     for _ in range(max(0, args.repeats)):
         window_dts.append(leg.window(next_step, args.steps))
         next_step += args.steps
+    in_kernel = live_counters(leg.dscene.counters(), n * args.steps * len(window_dts))   # (this rank's photons)
     ordered = sorted(window_dts)
     median_dt = ordered[(len(ordered) - 1) // 2]   # median (the slower of the two middle ones for an even count)
     per_window = n * world * args.steps
@@ -512,9 +544,11 @@ def main():
         try:
             other.spin_up(min(args.spinup_s, 0.1), 2)
             dts, kms = [], []
+            other.dscene.counters(reset=True)
             for w in range(5):
                 dts.append(other.window(100 + w * bundles, bundles, timed_events=True))
                 kms += other.pipe.kernel_ms()
+            live = live_counters(other.dscene.counters(), n * bundles * 5)
             frac = other.fractions(n * world * bundles)
             dts.sort()
             photons = n * world * bundles
@@ -524,7 +558,7 @@ def main():
                 sus_steps = max(bundles, int(args.config_sustained_s / (dts[len(dts) // 2] / bundles)))
                 dt = other.window(100_000, sus_steps)
                 sus = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt, "value": n * world * sus_steps / dt}
-            _, side = load_pmc(name, v / world, cus)
+            _, side = load_pmc(name, v / world, cus, live)
             return {
                 "workload": CONFIGS[name]["workload"], "photons_per_gpu": n * bundles, "bundles": bundles,
                 "emission": "device (sampled by the wave that claims a chunk of rays, in the trace kernel)", "bundles_in_flight": args.streams,
@@ -544,11 +578,13 @@ def main():
         other = Leg(name, n)
         try:
             other.spin_up(min(args.spinup_s, 0.1), 2)
+            other.dscene.counters(reset=True)
             dts = sorted(other.window(100 + w * 10, 10) for w in range(3))
+            live = live_counters(other.dscene.counters(), n * 10 * 3)
             sus_steps = max(10, int(0.7 / (dts[1] / 10)))
             dt = other.window(100_000, sus_steps)
             return {"faces": 20 * 4 ** sub, "value": n * world * 10 / dts[1], "sustained": n * world * sus_steps / dt,
-                    "unit": "photons/s", "launch": other.dscene.launch_info()}
+                    "unit": "photons/s", "launch": other.dscene.launch_info(), "in_kernel": live}
         finally:
             other.close()
 
@@ -558,16 +594,19 @@ def main():
         other = Leg(name, n)
         try:
             other.spin_up(min(args.spinup_s, 0.1), 2)
+            other.dscene.counters(reset=True)
             dts = sorted(other.window(100 + w * 10, 10) for w in range(3))
+            live = live_counters(other.dscene.counters(), n * 10 * 3)
             v = n * world * 10 / dts[1]
             sus_steps = max(10, int(1.0 / (dts[1] / 10)))
             dt = other.window(100_000, sus_steps)
-            _, side = load_pmc(name, v / world, cus)
+            _, side = load_pmc(name, v / world, cus, live)
             return {
                 "nodes": k * k + 1, "value": v, "sustained": n * world * sus_steps / dt, "unit": "photons/s",
                 "launch": other.dscene.launch_info(), "node_grid": native.node_grid_plan(other.compiled) is not None,
                 "valu_wave_instructions_per_photon": (side or {}).get("valu_wave_instructions_per_photon"),
                 "valu_lane_utilisation": (side or {}).get("valu_lane_utilisation"),
+                "in_kernel": live,
             }
         finally:
             other.close()
@@ -582,8 +621,15 @@ def main():
         sustained, strong, extra, scaling = done["sustained"], done["strong"], done["extra"], done["scaling"]
         failures = list(errors) + list(more_errors)
         achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9 if leg.array_input else 0.0
-        traffic, instruction_side = load_pmc(args.config, value / world, cus)
+        traffic, instruction_side = load_pmc(args.config, value / world, cus, in_kernel)
         rates = [per_window / d for d in window_dts]
+        side = instruction_side or {}
+        busy = side.get("valu_busy_under_overlap") or side.get("valu_issue_frac")
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": traffic,
+               "achieved_at_step_rate": (ALGORITHMIC_BYTES_PER_PHOTON if leg.array_input else 0) * per_window / world / median_dt / 1e9,
+               "note": "the figure the metric asks for: 56 algorithmic B/photon x photons per launch / mean launch duration; "
+                       "not the binding resource"}
         out = {
             "metric": "photons/sec on 5x5x1 cm Lumogen-F-Red LSC",
             "value": value,
@@ -614,19 +660,28 @@ def main():
             "rccl_ranks": rccl_ranks,
             "host": {"usable_cores": usable_cores(), "cores_of_rank0": cores_pinned},
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # The operative ceiling of this kernel is FP64 VALU issue (one wave64 instruction per SIMD every four
+                # cycles); HBM, which the metric names, is kept beside it (`hbm`, same fields as before).
+                "bound": "fp64-valu-issue" if busy else "hbm",
+                "achieved": side.get("valu_issue_rate_per_s") if busy else achieved,
+                "peak": side.get("valu_issue_peak_per_s") if busy else HBM_PEAK_GBS,
+                "unit": "wave64 VALU instructions/s" if busy else "GB/s",
+                "frac": busy if busy else achieved / HBM_PEAK_GBS,
+                "frac_is": ("VALU busy with the launches overlapping: vector instructions per photon (PMC per trip x trips "
+                            "counted in this run) x photons/s x 4 cycles / (SIMDs x shader clock measured under overlap)")
+                           if busy else "hbm",
+                "traffic": traffic,
+                "hbm": hbm,
+                "steps_per_photon": in_kernel["steps_per_photon"] if in_kernel else None,
+                "lane_utilisation": in_kernel["lane_utilisation"] if in_kernel else None,
                 "kernel": "trace_kernel_w4<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=%d> (pvt_trace_kernel.h trace_body, MESH=0)"
                           % (0 if leg.array_input else 1),
                 "kernel_ms_mean": mean_kernel_ms,
                 "instruction_side": instruction_side,
                 "kernel_photons_per_s": n / (mean_kernel_ms * 1e-3),
-                "achieved_at_step_rate": (ALGORITHMIC_BYTES_PER_PHOTON if leg.array_input else 0) * per_window / world
-                                         / median_dt / 1e9,
-                "note": "not HBM-bound: 56 algorithmic B/photon; the loop is FP64-VALU/latency/"
-                        "divergence-bound (DESIGN.md). kernel_ms_mean is per launch (HIP events on the "
-                        "launch's own stream, first window); with several bundles in flight launches overlap, so "
-                        "ms_per_step < kernel_ms_mean",
+                "note": "`value` is a STREAM of overlapping bundles; ONE launch of this size alone runs at kernel_photons_per_s "
+                        "(its drain tail is latency-bound). kernel_ms_mean is per launch (HIP events on the launch's own "
+                        "stream, first window); with several bundles in flight launches overlap, so ms_per_step < kernel_ms_mean",
             },
             "launch": launch,
             "tallies": fractions,

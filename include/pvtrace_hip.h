@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 10
+#define PVT_ABI_VERSION 11
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -39,7 +39,10 @@ enum {
 enum { PVT_GEOM_BOX = 0, PVT_GEOM_SPHERE = 1, PVT_GEOM_CYLINDER = 2, PVT_GEOM_MESH = 3 };
 enum { PVT_SURF_FRESNEL = 0, PVT_SURF_NULL = 1 };
 enum { PVT_COMP_ABSORBER = 0, PVT_COMP_SCATTERER = 1, PVT_COMP_LUMINOPHORE = 2, PVT_COMP_REACTOR = 3 };
-enum { PVT_PHASE_ISOTROPIC = 0, PVT_PHASE_HG = 1, PVT_PHASE_CONE = 2 };
+enum { PVT_PHASE_ISOTROPIC = 0, PVT_PHASE_HG = 1, PVT_PHASE_CONE = 2,
+       /* EXTENSION (the reference engine rejects it, compiler.py:300-310; its Python path and its scene-spec parser have it,
+        * material/utils.py:176-186, cli/parse.py:166-167): cosine-weighted about +z, theta = asin(sqrt(p1)), phi = 2 pi p2 */
+       PVT_PHASE_LAMBERTIAN = 3 };
 enum { PVT_EMIT_KT = 0, PVT_EMIT_REDSHIFT = 1, PVT_EMIT_FULL = 2 };
 /* recorder selectors (engine/recorder.py:45-53) */
 enum {
@@ -357,6 +360,16 @@ int pvt_emit_device(PvtScene* scene, const PvtTraceParams* params, double* posit
  * 1/x, x/y and sqrt(x) sequences of the kernel (operands in their normal ranges).  Lets the tests prove the bit-reproducibility premise of
  * csrc/pvt_math.h on gfx950. */
 int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, int device);
+
+/* Step counters of the scene since its creation (or the last reset), summed over every launch on every stream --
+ * always on, two scalar adds per wave and trip of the photon loop:
+ *   out[0] wave-iterations (trips in which a wave stepped its lanes)      out[1] lane-steps (live lanes summed over them)
+ *   out[2] photons finished one step early by the fused exit             out[3] waves retired
+ * out[1] + out[2] is the reference's loop count (`count`, _kernel.pyx:655) summed over the photons traced so far --
+ * exactly, when no photon is parked between launches (PVT_FLAG_CARRY_OUT) at the time of the call; out[1] / (64 out[0])
+ * is the fraction of lanes that held a live photon when a wave stepped.  The caller synchronises the streams it
+ * launched on first (the copy only orders after the null stream); `reset` != 0 clears the counters afterwards. */
+int pvt_scene_counters(PvtScene* scene, uint64_t* out, int reset);
 
 /* Launch geometry actually used by the last trace on this scene (diagnostics). */
 int pvt_scene_launch_info(PvtScene* scene, int32_t* grid, int32_t* block, int32_t* lds_bytes);

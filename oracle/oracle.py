@@ -66,6 +66,10 @@ def lib():
                                            C.c_void_p, C.c_void_p, C.c_int]
         L.pvt_oracle_mesh_hits.restype = C.c_int
         L.pvt_oracle_uniforms.argtypes = [C.c_uint64, C.c_void_p, C.c_int]
+        L.pvt_oracle_surface.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pvt_oracle_last_steps.restype = C.c_long
+        L.pvt_oracle_phase.argtypes = [C.c_int, C.c_double, C.c_uint64, C.c_int, C.c_void_p]
         L.pvt_oracle_fresnel_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.pvt_oracle_specular_reflect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -136,6 +140,11 @@ def trace_bundle(compiled, positions, directions, wavelengths, seed, maxsteps, m
     return finish_outputs(compiled, out, n_recorded, rows)
 
 
+def last_steps():
+    """Trips of the photon loop (`count`, _kernel.pyx:655) summed over the rays of this thread's last trace_bundle."""
+    return int(lib().pvt_oracle_last_steps())
+
+
 def emit(emitter, n_rays, emit_seed, ray_offset=0, math_mode=MATH_PORTABLE):
     """Per-ray-stream emission, mirror of the device emitter -> (pos, dir, wl)."""
     L = lib()
@@ -183,6 +192,25 @@ def specular_reflect(d, normal):
     d = np.ascontiguousarray(d, dtype=np.float64); nm = np.ascontiguousarray(normal, dtype=np.float64)
     out = np.zeros(3)
     lib().pvt_oracle_specular_reflect(d.ctypes.data, nm.ctypes.data, out.ctypes.data)
+    return out
+
+
+def surface(geom_type, params, point, direction, n1, n2, math_mode=MATH_LIBM):
+    """The Fresnel surface branch at `point` of an untransformed shape -> (outward normal, reflectivity, reflected
+    direction, refracted direction -- NaN beyond the critical angle)."""
+    prm = np.zeros(4); prm[:len(params)] = params
+    p = np.ascontiguousarray(point, dtype=np.float64); d = np.ascontiguousarray(direction, dtype=np.float64)
+    nrm, refl, trans = np.zeros(3), np.zeros(3), np.zeros(3)
+    r = C.c_double(0.0)
+    lib().pvt_oracle_surface(int(geom_type), prm.ctypes.data, p.ctypes.data, d.ctypes.data, float(n1), float(n2),
+                             int(math_mode), nrm.ctypes.data, C.addressof(r), refl.ctypes.data, trans.ctypes.data)
+    return nrm, r.value, refl, trans
+
+
+def phase(phase_type, param, seed, math_mode=MATH_LIBM):
+    """Direction a component's phase function samples from the stream of `seed` (its draws: uniforms(seed, 2))."""
+    out = np.zeros(3)
+    lib().pvt_oracle_phase(int(phase_type), float(param), int(seed), int(math_mode), out.ctypes.data)
     return out
 
 

@@ -354,6 +354,13 @@ static void sample_phase(const MathSel* M, int type, double param, Rng* rng, dou
         sin_t = sqrt(g1) * m_sin(M, param);
         turn = g2;
         by_cosine = 0;
+    } else if (type == PVT_PHASE_LAMBERTIAN) {
+        /* EXTENSION (the reference kernel has no such tag): material/utils.py:176-186 -- theta = asin(sqrt(p1)),
+         * phi = 2 pi p2, the draws in that order */
+        double p1 = rng_uniform(rng), p2 = rng_uniform(rng);
+        sin_t = sqrt(p1);
+        turn = p2;
+        by_cosine = 0;
     } else {
         double g1 = rng_uniform(rng), g2 = rng_uniform(rng);
         turn = g1;
@@ -370,6 +377,17 @@ static void sample_phase(const MathSel* M, int type, double param, Rng* rng, dou
     out[0] = sin_t * cp;
     out[1] = sin_t * sp;
     out[2] = cos_t;
+}
+
+/* Incidence geometry of a surface event (_kernel.pyx:846-852): the normal flipped along the ray, the clamped cosine,
+ * the angle.  One function for the trace loop and for the unit hook the golden tests drive (pvt_oracle_surface). */
+static double incidence(const MathSel* M, const double* nrm, const double* dir, double* nf, double* ddot_out) {
+    nf[0] = nrm[0]; nf[1] = nrm[1]; nf[2] = nrm[2];
+    if (dot3(nf, dir) < 0.0) { nf[0] = -nf[0]; nf[1] = -nf[1]; nf[2] = -nf[2]; }
+    double ddot = dot3(nf, dir);
+    if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
+    *ddot_out = ddot;
+    return m_acos(M, ddot);
 }
 
 /* ---- recorders (_kernel.pyx:482-556) ------------------------------------ */
@@ -493,10 +511,15 @@ static void lambertian_about(const MathSel* M, const double* m, Rng* rng, double
     for (int i = 0; i < 3; i++) out[i] = s[0] * t1[i] + s[1] * t2[i] + s[2] * m[i];
 }
 
+/* trips of the photon loop (`count`, _kernel.pyx:655) summed over the rays of the last pvt_oracle_trace of this thread:
+ * what the device's step counters (pvt_scene_counters) must add up to */
+static _Thread_local long g_last_steps = 0;
+long pvt_oracle_last_steps(void) { return g_last_steps; }
+
 /* ---- one photon (_kernel.pyx:603-897) ----------------------------------- */
 static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLog* L, int max_events,
                      long base, Acc* A, double* pos, double* dir, double wl, uint64_t seed,
-                     int maxsteps, int emit_method) {
+                     int maxsteps, int emit_method, long* steps) {
     Rng rng;
     int count = 0, nevents = 0, source = -1;
     double travelled = 0.0, duration = 0.0;
@@ -693,11 +716,8 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
         xform_point(S->world_to_local + hit * 16, pos, lp);
         local_normal(S, hit, tri0, lp, nl);
         xform_vector(S->local_to_world + hit * 16, nl, nrm);
-        nf[0] = nrm[0]; nf[1] = nrm[1]; nf[2] = nrm[2];
-        if (dot3(nf, dir) < 0.0) { nf[0] = -nf[0]; nf[1] = -nf[1]; nf[2] = -nf[2]; }
-        double ddot = dot3(nf, dir);
-        if (ddot > 1.0) ddot = 1.0; else if (ddot < -1.0) ddot = -1.0;
-        double angle = m_acos(M, ddot);
+        double ddot;
+        double angle = incidence(M, nrm, dir, nf, &ddot);
 
         double r = 0.0, n1 = 0.0, n2 = 0.0;
         int fres = S->surface_type[hit] == PVT_SURF_FRESNEL;
@@ -744,6 +764,7 @@ static int trace_one(const PvtSceneTables* S, const MathSel* M, const PvtEventLo
             continue;
         }
     }
+    *steps += count;   /* trips of the photon's loop (_kernel.pyx:655) */
     return nevents;
 }
 
@@ -786,7 +807,8 @@ int pvt_oracle_trace(const PvtSceneTables* S, const PvtRays* rays, const PvtTrac
     int64_t* a_bins = calloc((size_t)nthr * nbins, sizeof(int64_t));
     if (!a_dist || !a_cross || !a_sums || !a_bins) return PVT_ERR_INVALID;
 
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nthr)
+    long steps_total = 0;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthr) reduction(+ : steps_total)
     for (long i = 0; i < n; i++) {
         int tid = 0;
 #ifdef _OPENMP
@@ -799,7 +821,7 @@ int pvt_oracle_trace(const PvtSceneTables* S, const PvtRays* rays, const PvtTrac
         double pos[3] = {rays->position[i * 3], rays->position[i * 3 + 1], rays->position[i * 3 + 2]};
         double dir[3] = {rays->direction[i * 3], rays->direction[i * 3 + 1], rays->direction[i * 3 + 2]};
         int nev = trace_one(S, &M, L, P->max_events, base, &A, pos, dir, rays->wavelength[i],
-                            P->seed + P->ray_offset + (uint64_t)i, P->maxsteps, P->emit_method);
+                            P->seed + P->ray_offset + (uint64_t)i, P->maxsteps, P->emit_method, &steps_total);
         if (base >= 0) L->counts[i / rec_every] = nev;
     }
 
@@ -821,6 +843,7 @@ int pvt_oracle_trace(const PvtSceneTables* S, const PvtRays* rays, const PvtTrac
         out->rec_bins[b] += s;
     }
     free(a_dist); free(a_cross); free(a_sums); free(a_bins);
+    g_last_steps = steps_total;
     return PVT_OK;
 }
 
@@ -978,6 +1001,27 @@ int pvt_oracle_mesh_hits(const double* vertices, const int32_t* faces, int n_fac
         count += 1;
     }
     return count;
+}
+/* The Fresnel surface branch on an untransformed shape, piece by piece as trace_one runs it (:846-895): outward normal at
+ * `p`, incidence, reflectivity, and BOTH continuations (the loop takes one of them by a draw).  What the reference's
+ * FresnelSurfaceDelegate answers for the same ray (material/surface.py:102-177; tests/golden/surface.npz). */
+void pvt_oracle_surface(int geom_type, const double* params, const double* p, const double* dir, double n1, double n2,
+                        int math_mode, double* normal, double* reflectivity, double* reflected, double* transmitted) {
+    MathSel Ms = {math_mode};
+    double nf[3], ddot;
+    pvt_oracle_normal(geom_type, params, p, normal);
+    const double angle = incidence(&Ms, normal, dir, nf, &ddot);
+    *reflectivity = fresnel_reflectivity(&Ms, angle, ddot, n1, n2);
+    specular_reflect(dir, normal, reflected);
+    fresnel_refract(dir, nf, n1, n2, transmitted);
+}
+/* One draw of a component's phase function from the stream of `seed` (the draws it consumes are
+ * pvt_oracle_uniforms(seed, .)[0..1]) */
+void pvt_oracle_phase(int type, double param, uint64_t seed, int math_mode, double* out) {
+    MathSel Ms = {math_mode};
+    Rng r;
+    rng_seed(&r, seed);
+    sample_phase(&Ms, type, param, &r, out);
 }
 void pvt_oracle_uniforms(uint64_t seed, double* out, int n) {
     Rng r;

@@ -104,6 +104,7 @@ struct PvtScene {
     int top_n = 0;                      // ... records of it
     int meshq = 0;                      // leaves a lane of a mesh walk notes in LDS before their triangles are tested (1 or kMeshQ)
     unsigned int* d_set_cursor = nullptr;   // kCursorSlots x kMaxSets cursors: launches with tally sets
+    unsigned long long* d_counters = nullptr;   // step counters: 64 rows x 4 words (KArgs::counters, pvt_scene_counters)
     unsigned int* d_cursor = nullptr;   // kCursorSlots cursors (64 B apart), one per stream: launches on
                                         // different streams may overlap, each needs its own
     std::mutex slot_mutex;              // launches on one stream are ordered and may share a cursor;
@@ -817,6 +818,15 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         int* q = gi.data() + lay.comp_i + rc * CI;
         q[CI_TYPE] = t->comp_type[c];
         q[CI_PHASE] = t->comp_phase_type[c];
+        if (t->comp_phase_type[c] == PVT_PHASE_LAMBERTIAN) {
+            // The Lambertian phase function, theta = asin(sqrt(p1)), IS the cone's theta = asin(sqrt(p1) sin(theta_max)) at
+            // theta_max = pi/2 -- same two draws in the same order -- provided sin(pi/2) is the double 1.0 in the
+            // kernel's arithmetic (x * 1.0 is exact); checked here with the very function the kernel calls.
+            const double half_pi = 1.5707963267948966;
+            if (pvt_sin(half_pi) != 1.0) return fail(PVT_ERR_INVALID, "pvt_sin(pi/2) != 1: the Lambertian phase function cannot be lowered to a cone");
+            d[CD_PHASE] = half_pi;
+            q[CI_PHASE] = PVT_PHASE_CONE;
+        }
         q[CI_ABS_X] = c_abs_x[c];   // absolute offsets into the double blob
         q[CI_ABS_Y] = c_abs_y[c];
         q[CI_ABS_N] = t->comp_abs_n[c];
@@ -1002,6 +1012,8 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
     HIP_TRY(hipMemset(s->d_cursor, 0, 64 * kCursorSlots + 256));
     HIP_TRY(hipMalloc(&s->d_set_cursor, (size_t)kCursorSlots * kMaxSets * 4));
+    HIP_TRY(hipMalloc(&s->d_counters, 64 * 4 * 8));
+    HIP_TRY(hipMemset(s->d_counters, 0, 64 * 4 * 8));
     if (bvh_nodes.size() >= ((size_t)1 << 26) || bvh_tris.size() >= ((size_t)1 << 26))
         return fail(PVT_ERR_INVALID, "meshes too large: the walk's cursors and leaf references hold 2^26 records / triangles");
     if (!bvh_nodes.empty()) {
@@ -1083,6 +1095,7 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_ei) (void)hipFree(s->d_ei);
     if (s->d_cursor) (void)hipFree(s->d_cursor);
     if (s->d_set_cursor) (void)hipFree(s->d_set_cursor);
+    if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->d_bvh_top) (void)hipFree(s->d_bvh_top);
     if (s->d_tris) (void)hipFree(s->d_tris);
@@ -1107,6 +1120,7 @@ KArgs base_args(const PvtScene* s, const PvtTraceParams* p) {
     a.n_coat = s->n_coat; a.n_lights = s->n_lights;
     a.n_rays = (unsigned int)p->n_rays;
     a.cursor = s->d_cursor;
+    a.counters = s->d_counters;
     a.seed = p->seed + p->ray_offset;
     a.emit_seed = p->emit_seed;
     a.ray_offset = p->ray_offset;
@@ -1618,6 +1632,18 @@ int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, i
     HIP_TRY(hipMemcpy(y_host, dy, (size_t)n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(dx);
     (void)hipFree(dy);
+    return PVT_OK;
+}
+
+int pvt_scene_counters(PvtScene* s, uint64_t* out, int reset) {
+    if (!s || !out) return fail(PVT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    unsigned long long rows[64 * 4];
+    HIP_TRY(hipMemcpy(rows, s->d_counters, sizeof rows, hipMemcpyDeviceToHost));   // (orders after the launches on the null stream only)
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    for (int r = 0; r < 64; r++)
+        for (int k = 0; k < 4; k++) out[k] += rows[r * 4 + k];
+    if (reset) HIP_TRY(hipMemset(s->d_counters, 0, sizeof rows));
     return PVT_OK;
 }
 

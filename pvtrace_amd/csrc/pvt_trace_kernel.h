@@ -19,6 +19,9 @@
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
+#ifndef PVT_COUNTERS
+#define PVT_COUNTERS 1   // (0: a developer build without the always-on step counters, to price them: tools/gpu_ab.sh)
+#endif
 // Developer-only: every wave writes wall-clock stamps (start, tables staged, first step, cursor dry, end) and its
 // iteration count to KArgs::timeline (tools/gpu_wave_timeline.py)
 #ifndef PVT_TIMELINE
@@ -61,7 +64,7 @@ constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a 
                                      // workgroups' LDS fit a CU, so a fresh workgroup of the next launch can
                                      // start while draining ones still hold theirs (+6 % on pipelined bundles)
 // workgroup control words in LDS
-enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_WORDS = 16 };
+enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_FUSED = 14, CTL_WORDS = 16 };   // (CTL_FUSED: see KArgs::counters)
 constexpr double kEps = 2.220446049250313e-13;       // _kernel.pyx:29
 constexpr double kAlphaZero = 1e-8;                  // :32
 constexpr double kCcm = 2.99792458e10;               // :33
@@ -201,6 +204,14 @@ struct KArgs {
     // from `bvh_top` to byte offset `top_off`; cursors with pvt::kTopFlag set index that copy
     int top_off, top_n;
     const pvt::BvhNode* bvh_top;
+    // Step counters of the scene, always on (pvt_scene_counters): 64 rows (blockIdx & 63) of four u64 words
+    //   [0] wave-iterations: trips of the photon loop in which a wave stepped its lanes
+    //   [1] lane-steps: live lanes summed over those trips = the reference's loop count `_kernel.pyx:655` summed over the
+    //       photons, except for [2]
+    //   [2] fused exits: photons finished one step early by the fused exit (their last, empty step is not run)
+    //   [3] waves retired
+    // Per wave two scalar adds per iteration and three atomics when it retires; null = off.
+    unsigned long long* counters;
 };
 constexpr int kMeshQ = PVT_MESH_Q;    // leaves a lane notes before its triangles are tested
 constexpr int kCarryBase = 14;     // u64 words of a parked photon before its seen-mask
@@ -904,6 +915,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     double wl = 0.0, travelled = 0.0, duration = 0.0;
     Rng rng{0, 0, 0, 0};
     int count = 0, source = -1, nev = 0;
+    unsigned int n_iters = 0u, n_lane_steps = 0u;   // wave-uniform (KArgs::counters)
     int rec_slot = -1;   // recorded rays: index among them (row block rec_slot * max_events), else -1
     Seen<SEENW> seen;
 #pragma unroll
@@ -1285,6 +1297,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
 #endif
 
+#if PVT_COUNTERS
+        n_iters += 1u;
+        n_lane_steps += (unsigned int)__popcll(__ballot(alive));
+#endif
 #if PVT_TIMELINE
         if (tl_iters == 0) tl_t[2] = wall_clock64();
         if ((ws & WS_EXHAUSTED) && tl_t[3] == 0) tl_t[3] = wall_clock64();
@@ -2298,7 +2314,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 const int gp = hit * ND + ND_PARAMS;
                 const double h = 0.5 * (pvt_fabs(nrm.x) * T.dv(gp) + pvt_fabs(nrm.y) * T.dv(gp + 1) + pvt_fabs(nrm.z) * T.dv(gp + 2));
                 const double g = h - dot3(nrm, lp), dn = dot3(nrm, dir);
-                if (dn > 0.0 && g <= (0.5 * kEps) * dn) terminal = true;
+                if (dn > 0.0 && g <= (0.5 * kEps) * dn) {
+                    terminal = true;
+#if PVT_COUNTERS
+                    atomicAdd(reinterpret_cast<unsigned int*>(ctl) + CTL_FUSED, 1u);
+#endif
+                }
             }
         }
 
@@ -2432,10 +2453,27 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     if (A.timeline && lane == 0) {
         unsigned long long* o = A.timeline + ((unsigned long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8;
         o[0] = tl_t[0]; o[1] = tl_t[1]; o[2] = tl_t[2]; o[3] = tl_t[3]; o[4] = wall_clock64(); o[5] = tl_iters;
-        o[6] = __builtin_readcyclecounter() - tl_c0; o[7] = 1;
+        // (word 7: valid | the wave ended as the last of its workgroup << 1 | HW_ID register << 32: wave slot, SIMD, CU, SE)
+        o[6] = __builtin_readcyclecounter() - tl_c0;
+        o[7] = 1ull | ((ws & WS_SOLO) ? 2ull : 0ull) | ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32);
     }
 #endif
     tally_flush();   // the first crossings still parked
+    unsigned long long* ctr;   // this workgroup's row of the step counters (null: off)
+    {
+        const __attribute__((address_space(4))) KArgs* ak =
+            (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ak));
+        ctr = ak->counters;
+        if (ctr) {
+            ctr += (blockIdx.x & 63u) * 4u;
+            if (lane == 0) {
+                atomicAdd(ctr, (unsigned long long)n_iters);
+                atomicAdd(ctr + 1, (unsigned long long)n_lane_steps);
+                atomicAdd(ctr + 3, 1ull);
+            }
+        }
+    }
     // ---- flush workgroup accumulators: done by the LAST wave to leave -------
     // (no closing barrier: retiring waves must never be counted by the drain-phase
     // rendezvous barriers of the waves still running)
@@ -2445,6 +2483,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     order = __builtin_amdgcn_readfirstlane(order);
     if (order != kWaves - 1) return;
     __threadfence_block();
+    if (ctr && lane == 0) {
+        const unsigned int fused = reinterpret_cast<unsigned int*>(ctl)[CTL_FUSED];
+        if (fused) atomicAdd(ctr + 2, (unsigned long long)fused);
+    }
     unsigned long long* const out_distinct = reinterpret_cast<unsigned long long*>(A.rec_distinct) + (long long)set * A.set_stride_i;
     unsigned long long* const out_crossings = reinterpret_cast<unsigned long long*>(A.rec_crossings) + (long long)set * A.set_stride_i;
     unsigned long long* const out_bins = reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i;
@@ -2477,8 +2519,11 @@ template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_MESH_WAVES, PVT_MESH_WAVES))) trace_kernel(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, MESH>(A);
 }
+#ifndef PVT_W4_WAVES
+#define PVT_W4_WAVES 4   // (developer builds: other occupancies of the analytic variants)
+#endif
 template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_w4(KArgs A) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_W4_WAVES, PVT_W4_WAVES))) trace_kernel_w4(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, false>(A);
 }
 #ifndef PVT_GRID_WAVES

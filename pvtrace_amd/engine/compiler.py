@@ -47,6 +47,7 @@ GEOM_BOX, GEOM_SPHERE, GEOM_CYLINDER, GEOM_MESH = 0, 1, 2, 3
 SURF_FRESNEL, SURF_NULL = 0, 1
 COMP_ABSORBER, COMP_SCATTERER, COMP_LUMINOPHORE, COMP_REACTOR = 0, 1, 2, 3
 PHASE_ISOTROPIC, PHASE_HENYEY_GREENSTEIN, PHASE_CONE = 0, 1, 2
+PHASE_LAMBERTIAN = 3   # extension: the reference compiler rejects it (compiler.py:300-310); cli/parse.py:166-167 builds it
 EMIT_KT, EMIT_REDSHIFT, EMIT_FULL = 0, 1, 2
 EMIT_METHODS = {"kT": EMIT_KT, "redshift": EMIT_REDSHIFT, "full": EMIT_FULL}
 
@@ -71,6 +72,8 @@ def _phase_of(node, component):
         return PHASE_HENYEY_GREENSTEIN, float(phase.g)
     if isinstance(phase, Cone):
         return PHASE_CONE, float(phase.theta_max)
+    if phase is M.lambertian:   # (reference material/utils.py:176-186; what `phase-function: {lambertian:}` parses to)
+        return PHASE_LAMBERTIAN, 0.0
     # functools.partial spellings of the same built-ins (not recognised by the
     # reference compiler, which raises for them)
     if isinstance(phase, functools.partial) and not phase.keywords:

@@ -253,6 +253,7 @@ def declare_signatures(lib, names):
              C.POINTER(C.c_int32)], C.c_int),
         "pvt_scene_launch_info": (
             [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
+        "pvt_scene_counters": ([vp, C.POINTER(C.c_uint64), C.c_int], C.c_int),
         "pvt_node_grid_plan": (
             [C.POINTER(PvtSceneTables), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
              C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_int64], C.c_int),
@@ -271,10 +272,11 @@ ABI_SYMBOLS = (
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
     "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
     "pvt_scene_carry_pending", "pvt_last_multi_reduce", "pvt_node_grid_plan", "pvt_scene_carry_discard", "pvt_scene_trim",
+    "pvt_scene_counters",
 )
 
 _lib = None
-ABI_VERSION = 10  # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 11  # include/pvtrace_hip.h PVT_ABI_VERSION
 FLAG_NO_LOG_PREFILL = 1   # PvtTraceParams.flags
 FLAG_CARRY_OUT = 2        # park the photons still alive at the end of the launch for the next launch on the stream
 
@@ -443,6 +445,19 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+    def counters(self, reset=False):
+        """The scene's always-on step counters since creation / the last reset (pvt_scene_counters): wave-iterations,
+        lane-steps, fused exits, waves retired, and what follows from them.  `lane_steps + fused_exits` is the
+        reference's loop count (_kernel.pyx:655) summed over the photons traced.  Synchronises the device first."""
+        import torch
+
+        torch.cuda.synchronize(self.device)
+        out = (C.c_uint64 * 4)()
+        check(self.lib.pvt_scene_counters(self.handle, out, 1 if reset else 0), "pvt_scene_counters")
+        it, ls, fused, waves = (int(v) for v in out)
+        return {"wave_iterations": it, "lane_steps": ls, "fused_exits": fused, "waves": waves,
+                "steps": ls + fused, "lane_utilisation": ls / (64.0 * it) if it else 0.0}
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -37,8 +37,10 @@ class SpecError(ValueError):
     """The scene specification is malformed."""
 
 
-def load(source):
-    """`source`: path of a YAML file, a YAML string containing a newline, or a dict."""
+def load(source, base=None):
+    """`source`: path of a YAML file, a YAML string containing a newline, or a dict.  `base`: the directory relative
+    `file:` entries are resolved against (default: the YAML file's own directory, else the working directory)."""
+    given = base
     base = os.getcwd()
     if isinstance(source, dict):
         spec = source
@@ -51,7 +53,7 @@ def load(source):
                 spec = yaml.safe_load(fp)
         else:
             spec = yaml.safe_load(source)
-    return _Builder(spec, base).scene()
+    return _Builder(spec, given if given is not None else base).scene()
 
 
 parse = load  # the reference's name for it (pvtrace/cli/parse.py:72)

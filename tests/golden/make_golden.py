@@ -13,8 +13,9 @@ lie and only numeric inputs/outputs are saved.
   tallies_lsc_1e6.npz).
 * The reference's pure-Python leaf modules that import without third-party
   packages (data spectra, Distribution, Fresnel/phase helpers, Transformable,
-  Sphere, Cylinder) give known answers for spectra.npz, optics.npz,
-  geometry.npz and transforms.npz.  The package __init__ is bypassed with a
+  Sphere, Cylinder, FresnelSurfaceDelegate, engine/recorder.py) give known
+  answers for spectra.npz, optics.npz, geometry.npz, transforms.npz, phase.npz,
+  surface.npz and recorder_ids.json.  The package __init__ is bypassed with a
   namespace stub (it would pull anytree/trimesh/meshcat, absent here; no
   stand-ins for those are written).
 """
@@ -225,9 +226,129 @@ def make_hist_spectra():
          lookup=np.asarray(d.lookup(q)), query_p=p, sample=np.asarray(d.sample(p)))
 
 
+def make_phase():
+    """Directions of the reference's phase functions (material/utils.py:104-186) for given draws: numpy's global
+    generator is replaced, for the duration of a call, by one that hands out the first draws of our per-ray stream
+    (oracle.uniforms(seed, .)), so the same draws can be given to the restatement."""
+    from oracle import oracle as O
+
+    mu = ref_module("pvtrace.material.utils")
+    seeds = np.arange(1, 201, dtype=np.int64)
+    cases = [("isotropic", 0, 0.0, lambda: mu.isotropic()), ("hg", 1, 0.6, lambda: mu.henyey_greenstein(0.6)),
+             ("hg_back", 1, -0.35, lambda: mu.henyey_greenstein(-0.35)), ("cone", 2, 0.4, lambda: mu.cone(0.4)),
+             ("lambertian", 3, 0.0, lambda: mu.lambertian())]
+    out = {"seeds": seeds, "draws": np.array([O.uniforms(int(sd), 2) for sd in seeds])}
+    real = np.random.uniform
+    for name, tag, param, fn in cases:
+        dirs = []
+        for sd in seeds:
+            feed = list(O.uniforms(int(sd), 2))
+
+            def fake(low=0.0, high=1.0, size=None):
+                assert (low, high) == (0.0, 1.0) or (low, high) == (0, 1)
+                if size is None:
+                    return feed.pop(0)
+                return np.array([feed.pop(0) for _ in range(int(size))])
+
+            np.random.uniform = fake
+            try:
+                dirs.append(np.asarray(fn(), dtype=float))
+            finally:
+                np.random.uniform = real
+        out[f"{name}_tag"] = np.int64(tag)
+        out[f"{name}_param"] = np.float64(param)
+        out[f"{name}_dir"] = np.array(dirs)
+    save("phase.npz", **out)
+
+
+def make_surface():
+    """The reference's FresnelSurfaceDelegate (material/surface.py:102-177) asked about rays meeting a reference Sphere
+    and a reference Cylinder: reflectivity, reflected and transmitted direction.  Ray / node arguments are plain
+    namespaces with the attributes the delegate reads (ray.position, ray.direction, node.geometry.material
+    .refractive_index); the geometry IS the reference's."""
+    surf = ref_module("pvtrace.material.surface")
+    sph = ref_module("pvtrace.geometry.sphere")
+    cyl = ref_module("pvtrace.geometry.cylinder")
+    delegate = surf.FresnelSurfaceDelegate()
+    rng = np.random.default_rng(21)
+
+    def node(n):
+        return types.SimpleNamespace(geometry=types.SimpleNamespace(material=types.SimpleNamespace(refractive_index=n)))
+
+    shapes = {"sphere": (sph.Sphere(1.7), 1, [1.7]), "cyl": (cyl.Cylinder(2.5, 0.9), 2, [2.5, 0.9])}
+    out = {}
+    for name, (geometry, gtype, params) in shapes.items():
+        n = 300
+        pts = []
+        while len(pts) < n:   # points ON the surface: first intersection of random rays
+            o = rng.uniform(-3, 3, 3); d = rng.normal(size=3); d /= np.linalg.norm(d)
+            hit = geometry.intersections(tuple(o), tuple(d))
+            if hit:
+                pts.append(hit[0])
+        pts = np.array(pts, dtype=float)
+        dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+        pairs = np.array([(1.0, 1.5), (1.5, 1.0), (1.33, 1.0), (1.0, 1.0), (1.49, 1.7)])[rng.integers(0, 5, n)]
+        refl_r, refl_d, trans_d, normals = [], [], [], []
+        for p_, d_, (n1, n2) in zip(pts, dirs, pairs):
+            ray = types.SimpleNamespace(position=tuple(p_), direction=tuple(d_))
+            args = (None, ray, geometry, node(n1), node(n2))
+            r = delegate.reflectivity(*args)
+            refl_r.append(r)
+            refl_d.append(delegate.reflected_direction(*args))
+            with np.errstate(invalid="ignore"):
+                trans_d.append(delegate.transmitted_direction(*args) if r < 1.0 else (np.nan,) * 3)
+            normals.append(geometry.normal(tuple(p_)))
+        out.update({f"{name}_type": np.int64(gtype), f"{name}_params": np.array(params), f"{name}_points": pts,
+                    f"{name}_directions": dirs, f"{name}_indices": pairs, f"{name}_normals": np.array(normals, dtype=float),
+                    f"{name}_reflectivity": np.array(refl_r), f"{name}_reflected": np.array(refl_d, dtype=float),
+                    f"{name}_transmitted": np.array(trans_d, dtype=float)})
+    save("surface.npz", **out)
+
+
+def make_recorder_ids():
+    """The reference's recorder vocabulary (engine/recorder.py:33-55: PROPERTIES, EVENTS) and what its constructors
+    refuse, as JSON."""
+    import json
+
+    ref_module("pvtrace.data.lumogen_f_red_305")   # (makes sure the top-level namespace stub exists)
+    if "pvtrace.engine" not in sys.modules:   # the engine package's __init__ imports its compiler, which needs anytree:
+        pkg = types.ModuleType("pvtrace.engine")   # bypassed like the top-level __init__ (recorder.py imports nothing)
+        pkg.__path__ = [os.path.join(REF, "engine")]
+        sys.modules["pvtrace.engine"] = pkg
+    rec = ref_module("pvtrace.engine.recorder")
+
+    def refuses(fn):
+        try:
+            fn()
+        except ValueError as exc:
+            return str(exc)
+        return None
+
+    doc = {
+        "PROPERTIES": dict(rec.PROPERTIES), "EVENTS": dict(rec.EVENTS),
+        "refused": {
+            "histogram_unknown_property": refuses(lambda: rec.Histogram("colour", 0, 1, 4)),
+            "histogram_empty_range": refuses(lambda: rec.Histogram("x", 1, 1, 4)),
+            "histogram_no_bins": refuses(lambda: rec.Histogram("x", 0, 1, 0)),
+            "recorder_unknown_event": refuses(lambda: rec.Recorder("r", event="vanished")),
+            "recorder_bad_histogram": refuses(lambda: rec.Recorder("r", histograms=[3])),
+        },
+        "defaults": {"event": rec.Recorder("r").event, "atol": rec.Recorder("r").atol, "facet": rec.Recorder("r").facet},
+    }
+    path = os.path.join(HERE, "recorder_ids.json")
+    with open(path, "w") as fp:
+        json.dump(doc, fp, indent=1, sort_keys=True)
+    print("recorder_ids.json")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated in the build container")
+    if len(sys.argv) > 1 and sys.argv[1] == "--units":   # only the small unit fixtures added in round 5
+        make_phase()
+        make_surface()
+        make_recorder_ids()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
         make_config_tallies(only=sys.argv[2:])
         sys.exit(0)
@@ -235,6 +356,9 @@ if __name__ == "__main__":
     make_optics()
     make_geometry()
     make_transforms()
+    make_phase()
+    make_surface()
+    make_recorder_ids()
     make_traces()
     make_lsc_tallies()
     make_config_tallies()

@@ -416,6 +416,39 @@ def l_prism(recorders=True):
     return Scene(world)
 
 
+def lambertian_fog():
+    """A slab whose two scatterers use the Lambertian and a cone phase function (extension: the reference engine rejects
+    `lambertian` as a custom phase function, compiler.py:300-310; its scene-spec parser builds it, cli/parse.py:166-167)."""
+    world = Node(name="world", geometry=Box((30.0, 30.0, 30.0), material=Material(refractive_index=1.0)))
+    fog = Node(name="fog", parent=world, geometry=Box((6.0, 6.0, 2.0), material=Material(refractive_index=1.3, components=[
+        Scatterer(coefficient=0.8, quantum_yield=0.97, phase_function=lambertian, name="lambert"),
+        Scatterer(coefficient=0.3, quantum_yield=0.9, phase_function=Cone(0.6), name="cone"),
+        Absorber(coefficient=0.05, name="loss"),
+    ])))
+    fog.rotate(0.3, (1.0, 0.0, 0.0))
+    fog.recorders = face_recorders("fog-", hist=False)
+    light = Node(name="light", parent=world, light=Light(direction=functools.partial(cone, 0.3), name="light"))
+    light.location = (0.0, 0.0, 4.0)
+    light.rotate(np.pi, (1, 0, 0))
+    world.recorders = [Recorder("exit", event="exit", histograms=[Histogram("angle", 0, np.pi / 2, 9)])]
+    return Scene(world)
+
+
+def reference_spec_scene(name="tests/data/pvtrace-scene-spec.yml"):
+    """One of the reference's own scene-spec files (parsed dicts: tests/golden/spec_dicts.json, made by
+    tests/golden/make_spec_fixtures.py), built by the product's front-end.  The default is the reference's parser fixture:
+    a sphere and a cylinder holding isotropic / Lambertian / cone / Henyey-Greenstein scatterers, an STL cube, eight
+    lights with every mask."""
+    import json
+    import os
+
+    from pvtrace_amd import spec
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gold, "spec_dicts.json")) as fp:
+        return spec.load(json.load(fp)[name], base=os.path.join(gold, "spec_data"))
+
+
 REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
     "hello_world": hello_world,
     "lsc_equivalent": lsc_equivalent,
@@ -434,6 +467,8 @@ EXTENSION_SCENES = {   # need an extension: coatings, hist spectra, meshes
     "hist_lamp": hist_lamp,
     "mesh_lsc": mesh_lsc,
     "mesh_gem": mesh_gem,
+    "lambertian_fog": lambertian_fog,
+    "reference_spec": reference_spec_scene,
 }
 ALL_SCENES = dict(REFERENCE_SCENES, **EXTENSION_SCENES)
 

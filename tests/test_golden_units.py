@@ -173,3 +173,100 @@ def test_histogram_sampled_distribution_golden():
         assert O.step_lookup(q, g["x"], g["cdf"]) == l
     for p, s in zip(g["query_p"], g["sample"]):
         assert O.step_lookup(p, g["cdf"], g["x"]) == s, p
+
+
+# ---- round 5: more of the path pinned by the reference's own modules (no stand-ins) ----------------------
+PHASE_CASES = ["isotropic", "hg", "hg_back", "cone", "lambertian"]
+
+
+@pytest.mark.parametrize("case", PHASE_CASES)
+def test_phase_functions_against_the_reference_functions(case):
+    """tests/golden/phase.npz: the reference's material/utils.py phase functions, fed the first two draws of our per-ray
+    stream.  The oracle's sample_phase (what the trace loop calls) must give the same direction from the same stream --
+    libm mode to rounding, portable mode (the GPU's arithmetic) to a few ulp -- and so must the product's own Python
+    functions.  `lambertian` is the extension tag PVT_PHASE_LAMBERTIAN: no reference KERNEL counterpart, but this
+    reference function."""
+    import pvtrace_amd.material as M
+
+    g = load("phase.npz")
+    tag, param = int(g[f"{case}_tag"]), float(g[f"{case}_param"])
+    mine = {"isotropic": M.isotropic, "hg": lambda: M.henyey_greenstein(param), "hg_back": lambda: M.henyey_greenstein(param),
+            "cone": lambda: M.cone(param), "lambertian": M.lambertian}[case]
+    real = np.random.uniform
+    for seed, draws, want in zip(g["seeds"], g["draws"], g[f"{case}_dir"]):
+        assert np.array_equal(O.uniforms(int(seed), 2), draws)
+        assert np.allclose(O.phase(tag, param, int(seed), O.MATH_LIBM), want, rtol=0, atol=2e-15), (case, seed)
+        assert np.allclose(O.phase(tag, param, int(seed), O.MATH_PORTABLE), want, rtol=0, atol=1e-14), (case, seed)
+        feed = list(draws)
+
+        def fake(low=0.0, high=1.0, size=None):
+            return feed.pop(0) if size is None else np.array([feed.pop(0) for _ in range(int(size))])
+
+        np.random.uniform = fake
+        try:
+            got = np.asarray(mine(), dtype=float)
+        finally:
+            np.random.uniform = real
+        assert np.allclose(got, want, rtol=0, atol=2e-15), (case, seed)
+    if case == "lambertian":
+        assert np.all(g["lambertian_dir"][:, 2] >= 0.0)   # never below the surface (material/utils.py:180)
+
+
+def test_lambertian_phase_is_the_cone_of_half_angle_pi_over_two():
+    """What the host packer relies on when it lowers PVT_PHASE_LAMBERTIAN to the kernel's cone branch (pvt_trace.hip):
+    sin(pi/2) is the double 1.0 in the kernel's arithmetic, so the two tags sample identical bits."""
+    assert O.math("sin", np.array([1.5707963267948966]), math_mode=O.MATH_PORTABLE)[0] == 1.0
+    for seed in range(1, 60):
+        for mode in (O.MATH_PORTABLE, O.MATH_LIBM):
+            assert np.array_equal(O.phase(3, 0.0, seed, mode), O.phase(2, 1.5707963267948966, seed, mode))
+
+
+@pytest.mark.parametrize("shape", ["sphere", "cyl"])
+def test_surface_branch_against_the_reference_fresnel_delegate(shape):
+    """tests/golden/surface.npz: the reference's FresnelSurfaceDelegate (material/surface.py:102-177) on the reference's
+    own Sphere / Cylinder.  The oracle's surface branch -- normal, flipped normal, clamped cosine, angle, reflectivity,
+    specular and Snell directions, the functions trace_one runs in that order -- answers the same."""
+    g = load("surface.npz")
+    gtype, prm = int(g[f"{shape}_type"]), list(g[f"{shape}_params"])
+    tir = 0
+    for p, d, (n1, n2), nrm, r, refl, trans in zip(g[f"{shape}_points"], g[f"{shape}_directions"], g[f"{shape}_indices"],
+                                                   g[f"{shape}_normals"], g[f"{shape}_reflectivity"],
+                                                   g[f"{shape}_reflected"], g[f"{shape}_transmitted"]):
+        for mode in (O.MATH_LIBM, O.MATH_PORTABLE):
+            o_n, o_r, o_refl, o_trans = O.surface(gtype, prm, p, d, n1, n2, mode)
+            assert np.allclose(o_n, nrm, rtol=0, atol=1e-9)       # (the point is on the surface to ~1e-15)
+            assert o_r == pytest.approx(r, rel=1e-9, abs=1e-12)
+            assert np.allclose(o_refl, refl, rtol=0, atol=1e-9)
+            if r < 1.0:
+                assert np.allclose(o_trans, trans, rtol=0, atol=1e-9)
+        tir += r == 1.0
+    assert 0 < tir < len(g[f"{shape}_points"])   # both sides of the critical angle are in the sample
+
+
+def test_recorder_vocabulary_is_the_references():
+    """tests/golden/recorder_ids.json: PROPERTIES / EVENTS of the reference's engine/recorder.py:33-55, the messages
+    of what its constructors refuse, its defaults -- against the product's module and the ids of the C ABI."""
+    import json
+    import re
+
+    from pvtrace_amd.engine import recorder as R
+
+    with open(os.path.join(GOLD, "recorder_ids.json")) as fp:
+        doc = json.load(fp)
+    assert R.PROPERTIES == doc["PROPERTIES"] and R.EVENTS == doc["EVENTS"]
+    header = open(os.path.join(os.path.dirname(GOLD), "..", "include", "pvtrace_hip.h")).read()
+    abi = {k.lower(): int(v) for k, v in re.findall(r"PVT_REC_(\w+) = (\d+)", header)}
+    assert abi == doc["EVENTS"]
+    refused = {
+        "histogram_unknown_property": lambda: R.Histogram("colour", 0, 1, 4),
+        "histogram_empty_range": lambda: R.Histogram("x", 1, 1, 4),
+        "histogram_no_bins": lambda: R.Histogram("x", 0, 1, 0),
+        "recorder_unknown_event": lambda: R.Recorder("r", event="vanished"),
+        "recorder_bad_histogram": lambda: R.Recorder("r", histograms=[3]),
+    }
+    for key, fn in refused.items():
+        with pytest.raises(ValueError) as err:
+            fn()
+        assert str(err.value) == doc["refused"][key], key
+    r = R.Recorder("r")
+    assert (r.event, r.atol, r.facet) == (doc["defaults"]["event"], doc["defaults"]["atol"], doc["defaults"]["facet"])

@@ -145,3 +145,33 @@ def test_spec_scene_traces_on_the_engine():
     assert recs["edge-escape"].rays == recs["lsc-east"].rays    # same facet, explicit vs shorthand
     edges, values = recs["edge-escape"].histogram(0)
     assert values.sum() == recs["edge-escape"].rays
+
+
+def test_every_scene_spec_the_reference_holds_loads_and_lowers():
+    """tests/golden/spec_dicts.json = yaml.safe_load of the reference's seven spec files (examples/*.yml,
+    tests/data/*.yml; tests/golden/make_spec_fixtures.py), with the CSV spectrum and the STL cube they point at.  Each
+    must build, lower to tables and survive a few hundred photons on the referee.  The parser fixture
+    (tests/data/pvtrace-scene-spec.yml; reference tests/test_cli.py) is the one with every mask, every phase function
+    -- `lambertian` among them, cli/parse.py:166-167 -- and a mesh."""
+    import json
+    import os
+
+    from oracle import oracle as O
+    from pvtrace_amd.engine.compiler import PHASE_LAMBERTIAN
+    from pvtrace_amd.engine.emit import emit_bundle
+    from tests.util import GOLD
+
+    with open(os.path.join(GOLD, "spec_dicts.json")) as fp:
+        docs = json.load(fp)
+    assert len(docs) == 7
+    for name, doc in docs.items():
+        scene = spec.load(doc, base=os.path.join(GOLD, "spec_data"))
+        compiled = compile_scene(scene)
+        assert len(scene.light_nodes) >= 1, name
+        pos, dirs, wl, _ = emit_bundle(scene, 300, seed=4)
+        out = O.trace_bundle(compiled, pos, dirs, wl, 9, 1000, 64, 0, 1, 1, math_mode=O.MATH_PORTABLE)
+        assert out["counts"].min() >= 2, name
+    big = compile_scene(spec.load(docs["tests/data/pvtrace-scene-spec.yml"], base=os.path.join(GOLD, "spec_data")))
+    assert sorted(set(big.comp_phase_type.tolist())) == [0, 1, 2, PHASE_LAMBERTIAN]
+    assert big.node_names == ["world", "ball", "rod", "xyz-cube"] and big.geom_type.tolist() == [0, 1, 2, 3]
+    assert len(big.scene.light_nodes) == 8

@@ -11,7 +11,7 @@ while at + 32 <= len(data):
     magic, launch, grid, n = struct.unpack_from("<4Q", data, at); at += 32
     assert magic == 0xABCD
     w = np.frombuffer(data, dtype=np.uint64, count=grid * 4 * 8, offset=at).reshape(grid * 4, 8).astype(np.int64); at += grid * 4 * 8 * 8
-    w = w[w[:, 7] == 1]
+    w = w[(w[:, 7] & 1) == 1]
     if len(w) == 0:
         continue
     allw.append(w)
@@ -21,7 +21,18 @@ while at + 32 <= len(data):
         pct = lambda x: " ".join(f"{v:7.1f}" for v in np.percentile(us(x), [0, 5, 50, 95, 100]))
         mhz = w[:, 6].sum() / ((w[:, 4] - w[:, 0]).sum() / 100.0)
         print(f"launch {launch} grid {grid} n {n}: waves {len(w)} iterations/wave {w[:,5].mean():.1f}; shader clock {mhz:.0f} MHz; "
-              f"first step us [min p5 p50 p95 max] {pct(w[:,2])}; end {pct(w[:,4])}")
+              f"first step us [min p5 p50 p95 max] {pct(w[:,2])}; cursor dry {pct(w[w[:,3] > 0][:,3])}; end {pct(w[:,4])}")
+        # where the waves that end last ran: the HW_ID register (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+        hw = (w[:, 7] >> 32) & 0xffffffff
+        simd, cu, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7
+        late = us(w[:, 4]) > 0.5 * us(w[:, 4]).max()
+        key = (se[late] * 16 + cu[late]) * 4 + simd[late]
+        uniq, cnt = np.unique(key, return_counts=True)
+        print(f"   waves ending in the last half of the launch: {late.sum()} on {len(uniq)} distinct SIMDs (max {cnt.max() if len(cnt) else 0} on one), "
+              f"{len(np.unique(key // 4))} distinct CUs; SIMD histogram of ALL waves {np.bincount(simd, minlength=4)}, of the late ones {np.bincount(simd[late], minlength=4)}")
+        end_us = us(w[:, 4])
+        for q in (50, 90, 99, 99.9, 100):
+            print(f"   end percentile {q}: {np.percentile(end_us, q):.1f} us")
 w = np.concatenate(allw)
 start, end, iters, cyc = w[:, 0], w[:, 4], w[:, 5], w[:, 6]
 life_us = (end - start) / 100.0

@@ -38,7 +38,7 @@ c = dict(sums)
 read_b = c["FETCH_SIZE"] * 1024 * 2
 write_b = c["WRITE_SIZE"] * 1024
 out = {
-    "round": 4, "stage": stage, "mode": mode, "config": cfg,
+    "round": 5, "stage": stage, "mode": mode, "config": cfg,
     "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --gpus 1 --steps 6 --warmup 1 "
                "--no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2 --extra-configs none --config " + cfg
                + (" --streams 1" if mode.startswith("serial") else "") + " (one counter set per run; tools/gpu_pmc.sh " + mode.split("_")[0] + " " + cfg + "); "
@@ -67,6 +67,21 @@ out = {
         "vmem_instructions_per_wave": c.get("SQ_INSTS_VMEM", 0) / c["SQ_WAVES"],
     },
 }
+# the bench line printed under the sq1 pass carries what the kernel counted itself (trips of the photon loop per photon);
+# with it the vector instructions PER TRIP of a wave, which bench.py scales by the trips it counts in its own run
+for cand in ("sq1", "sq2", "sq3"):
+    line = os.path.join(ROOT, "gpurun_out", f"pmc_{mode}_{cand}.json")
+    try:
+        doc = json.loads(open(line).read().strip().splitlines()[-1])
+        ik = (doc["roofline"]["instruction_side"] or {}).get("in_kernel")   # (--config <cfg>: the main leg IS that config)
+        if ik:
+            out["in_kernel_of_the_pmc_run"] = ik
+            out["derived"]["wave_iterations_per_photon"] = ik["wave_iterations_per_photon"]
+            out["derived"]["valu_wave_instructions_per_wave_iteration"] = (
+                out["derived"]["valu_wave_instructions_per_photon"] / ik["wave_iterations_per_photon"])
+            break
+    except (OSError, ValueError, KeyError, IndexError, TypeError):
+        continue
 live = {"pipelined": "pmc_summary.json"}.get(mode, f"pmc_summary_{cfg}.json" if mode == f"pipelined_{cfg}" else None)
 for name in ((f"{tag}_pmc_summary.json", live) if live else (f"{tag}_pmc_summary.json",)):
     with open(os.path.join(ROOT, "profiles", name), "w") as fp:
