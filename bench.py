@@ -370,16 +370,20 @@ def main():
             # before the closing fence.  --streams 1 gives the strictly serial schedule.
             self.pipe = BundlePipeline(self.dscene, depth=args.streams, distributed=distributed, reduce=args.reduce)
             self.pipe.wait_for_inputs()
+            self.submit_s, self.submit_n = 0.0, 0   # host time spent enqueueing bundles (Python + the C ABI call)
 
         def step(self, k, timed, tail=False, m=None, offset=None, seed=None, closing=False):
             m = self.n if m is None else m
             rays = self.ray_sets[k % len(self.ray_sets)]
             if rays is not None and m != self.n:
                 rays = tuple(t[:m] for t in rays)
+            t_sub = time.perf_counter()
             self.pipe.submit(rays, m, seed=12345 + k * world * self.n if seed is None else seed,
                              ray_offset=rank * self.n if offset is None else offset, emit_seed=4242 + k * world * self.n,
                              maxsteps=1000, max_events=128, emit_method=self.method, timed=timed, tail=tail,
                              closing=closing)
+            self.submit_s += time.perf_counter() - t_sub
+            self.submit_n += 1
 
         def window(self, first_step, steps, timed_events=False):
             """One independent window of `steps` steps, fenced on both sides -> seconds (max over ranks)."""
@@ -441,6 +445,14 @@ def main():
     median_dt = ordered[(len(ordered) - 1) // 2]   # median (the slower of the two middle ones for an even count)
     per_window = n * world * args.steps
     value = per_window / median_dt
+    # what a step costs the HOST of each rank (Python + ctypes + the enqueue): N ranks share the box's cores, and a step
+    # of the stream is ~0.3 ms of GPU time, so this is the budget a multi-rank run lives on
+    submit_us = [leg.submit_s / max(leg.submit_n, 1) * 1e6]
+    if distributed:
+        t_sub = torch.zeros(world, dtype=torch.float64, device=dev)
+        t_sub[rank] = submit_us[0]
+        dist.all_reduce(t_sub, op=dist.ReduceOp.SUM)
+        submit_us = [float(v) for v in t_sub.tolist()]
 
     errors = []
     if os.environ.get("PVT_BENCH_DIE_AFTER_MAIN") == str(rank):   # (tests: a rank lost after the timed region)
@@ -505,6 +517,7 @@ def main():
             tallied = int(st["rec_distinct"][names.index("entering")] + st["rec_distinct"][names.index("reflected")])
         strong = {"scaling": "strong", "total_photons": args.total_photons, "seconds": dt,
                   "value": args.total_photons / dt, "photons_tallied": tallied}
+        job_ints = {k: np.asarray(st[k]).astype(np.int64) for k in ("rec_distinct", "rec_crossings", "rec_bins")}
         if distributed and "strong" in rank_seconds:
             strong["seconds_per_rank"] = rank_seconds["strong"]
         if sustained is not None:
@@ -530,6 +543,12 @@ def main():
                 solo.wait_for_inputs()
                 for _ in range(2):   # (the first pass pays for the new pipeline's streams and buffers)
                     alone = job(solo, 0, args.total_photons, lambda: (solo.synchronize(), torch.cuda.synchronize(dev)))
+                # the same job traced by ONE rank: its integer tallies must be the N-rank job's, bit for bit (the
+                # reference's analogue: output independent of the thread count, tests/test_engine.py:169-176)
+                one = solo.totals_host()
+                strong["integer_tallies_equal_single_rank"] = bool(all(
+                    np.array_equal(np.asarray(one[k]).astype(np.int64), job_ints[k]) for k in job_ints))
+                strong["rec_distinct"] = [int(v) for v in job_ints["rec_distinct"]]
                 solo.close()
             fence(leg.pipe)
             if rank == 0:
@@ -658,7 +677,8 @@ def main():
                 "value_is": f"median of {len(window_dts)} fenced windows of {args.steps} steps",
             },
             "rccl_ranks": rccl_ranks,
-            "host": {"usable_cores": usable_cores(), "cores_of_rank0": cores_pinned},
+            "host": {"usable_cores": usable_cores(), "cores_of_rank0": cores_pinned,
+                     "submit_us_per_step_per_rank": submit_us, "gpu_us_per_step": median_dt / args.steps * 1e6},
             "roofline": {
                 # The operative ceiling of this kernel is FP64 VALU issue (one wave64 instruction per SIMD every four
                 # cycles); HBM, which the metric names, is kept beside it (`hbm`, same fields as before).

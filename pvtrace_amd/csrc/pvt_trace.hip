@@ -195,11 +195,20 @@ static double cosine_threshold(double crit) {
 //     sphere (radius >= 1e-5 of the extent, checked here) is crossed twice or not at all -- never once.
 // Returns false (no grid: the plain node loop serves the scene) for scenes it cannot vouch for: few nodes, meshes,
 // non-rigid or inconsistent poses, degenerate shapes.
+// Negative controls of the grid tests (tests/test_gpu_grid.py, tests/test_node_grid.py) are environment switches read
+// when a scene is created, and they produce WRONG physics on purpose: whoever has one set gets told, loudly, every time.
+bool dev_switch(const char* name) {
+    if (!getenv(name)) return false;
+    fprintf(stderr, "[pvtrace_hip] WARNING: %s is set -- the node grid of this scene is built WRONG on purpose (a test's negative "
+                    "control); unset it for real work\n", name);
+    return true;
+}
+
 struct NodeGrid {
     int n[3] = {1, 1, 1};
     double lo[3], hi[3], cell[3], guard = 0.0;
     int words = 1;
-    bool odd = false, any_rotated = false;
+    bool odd = false;
     std::vector<unsigned long long> masks;
 };
 static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
@@ -244,13 +253,6 @@ static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
             extent = std::fmax(extent, std::fabs(c) + hw);
         }
         if (!(back <= 1e-9 * (1.0 + extent))) return false;
-        if (n != root) {   // rotated: the 3x3 block of world->local is not the identity, bit for bit
-            const double one = 1.0, zero = 0.0;
-            for (int r = 0; r < 3; r++)
-                for (int c = 0; c < 3; c++)
-                    if (std::memcmp(&w[r * 4 + c], r == c ? &one : &zero, 8) != 0 || std::memcmp(&l[r * 4 + c], r == c ? &one : &zero, 8) != 0)
-                        g->any_rotated = true;
-        }
     }
     if (!(extent > 0.0) || !std::isfinite(extent)) return false;
     const double m = 1e-6 * extent;
@@ -262,7 +264,7 @@ static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
     }
     // (negative controls of tests/test_gpu_grid.py: file the boxes a centimetre too small / leave the walk as soon as
     // any two crossings are known -- results must then differ from the referee's)
-    const double grow = getenv("PVT_GRID_DEV_SHRINK") ? -1.0 : 2.0 * m;
+    const double grow = dev_switch("PVT_GRID_DEV_SHRINK") ? -1.0 : 2.0 * m;
     for (int a = 0; a < 3; a++) { g->lo[a] = INFINITY; g->hi[a] = -INFINITY; }
     for (int n = 0; n < N; n++) {
         if (n == root) continue;
@@ -391,7 +393,8 @@ static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
     constexpr int kMaxCells = 512;   // 8 KB of masks in LDS at two words per cell
     {   // start: about one cell per node, as cubic as the extent allows
         double target = std::fmin((double)kMaxCells, std::fmax(8.0, 1.0 * (N - 1)));
-        if (const char* env = getenv("PVT_GRID_CELLS")) target = std::fmin(4096.0, std::fmax(1.0, atof(env)));
+        // (developer sweep; never more cells than the mask table's share of LDS holds)
+        if (const char* env = getenv("PVT_GRID_CELLS")) target = std::fmin((double)kMaxCells, std::fmax(1.0, atof(env)));
         double side = std::cbrt(vol / target);
         for (int pass = 0; pass < 200; pass++) {
             long long cells = 1;
@@ -399,7 +402,7 @@ static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
                 g->n[a] = (int)std::fmin(64.0, std::fmax(1.0, std::floor(ext[a] / side + 0.5)));
                 cells *= g->n[a];
             }
-            if ((double)cells <= target * 1.25) break;
+            if ((double)cells <= target * 1.25 && cells <= kMaxCells) break;
             side *= 1.05;
         }
     }
@@ -421,7 +424,7 @@ static bool plan_node_grid(const PvtSceneTables* t, NodeGrid* g) {
             }
     }
     g->words = W;
-    g->guard = getenv("PVT_GRID_DEV_GUARD") ? -1e30 : m;
+    g->guard = dev_switch("PVT_GRID_DEV_GUARD") ? -1e30 : m;
     file_nodes(g->n, g->cell, g->masks);
     return true;
 }
@@ -682,8 +685,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         for (int a = 0; a < 3; a++) { d[a] = grid.lo[a]; d[3 + a] = grid.hi[a]; d[6 + a] = grid.cell[a]; d[9 + a] = 1.0 / grid.cell[a]; }
         d[12] = grid.guard;
         const unsigned long long bits = (unsigned long long)grid.n[0] | ((unsigned long long)grid.n[1] << 8) | ((unsigned long long)grid.n[2] << 16) |
-                                        ((unsigned long long)grid.words << 24) | ((unsigned long long)(grid.odd ? 1 : 0) << 28) |
-                                        ((unsigned long long)(grid.any_rotated ? 1 : 0) << 29);
+                                        ((unsigned long long)grid.words << 24) | ((unsigned long long)(grid.odd ? 1 : 0) << 28);
         std::memcpy(&d[13], &bits, 8);
         std::memcpy(&d[14], grid.masks.data(), grid.masks.size() * 8);
     }
@@ -1030,10 +1032,20 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
             const size_t per_wg = (size_t)39 * 1024 * 4 / PVT_MESH_WAVES;
             size_t room = tally.ok && hist.ok && other < per_wg ? per_wg - other : 0;
             if (room > 32 * 1024) room = 32 * 1024;
-            if (const char* env = getenv("PVT_MESH_TOP_BYTES")) room = (size_t)atoll(env);   // (developer override; 0: no copy)
+            if (const char* env = getenv("PVT_MESH_TOP_BYTES")) {   // (developer override, never past the room computed above; 0: no copy)
+                const size_t asked = (size_t)atoll(env);
+                room = asked < room ? asked : room;
+            }
             std::vector<pvt::BvhNode> top;
             pvt::stage_top(bvh_nodes, bvh_roots, room / sizeof(pvt::BvhNode), top);
             s->top_n = (int)top.size();
+            // what was planned without the copy must still hold with it (plan_lds reserves the copy first): same table
+            // placement, everything inside the LDS of a workgroup
+            const LdsPlan tally2 = plan_lds(s, false), hist2 = plan_lds(s, true);
+            const size_t with_top = (size_t)s->meshq * kBlock * 4 + (size_t)s->top_n * sizeof(pvt::BvhNode);
+            if (tally2.ok != tally.ok || hist2.ok != hist.ok || tally2.tab_lds != tally.tab_lds || hist2.tab_lds != hist.tab_lds ||
+                tally2.bytes + with_top > s->lds_limit || hist2.bytes + with_top > s->lds_limit)
+                return fail(PVT_ERR_INVALID, "internal: the LDS plan of a mesh scene changed when the copy of its trees' top levels was added");
             if (s->top_n > 0) {
                 HIP_TRY(hipMalloc(&s->d_bvh_top, top.size() * sizeof(pvt::BvhNode)));
                 HIP_TRY(hipMemcpy(s->d_bvh_top, top.data(), top.size() * sizeof(pvt::BvhNode), hipMemcpyHostToDevice));

@@ -64,7 +64,7 @@ constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a 
                                      // workgroups' LDS fit a CU, so a fresh workgroup of the next launch can
                                      // start while draining ones still hold theirs (+6 % on pipelined bundles)
 // workgroup control words in LDS
-enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_FUSED = 14, CTL_WORDS = 16 };   // (CTL_FUSED: see KArgs::counters)
+enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_COUNT = 16, CTL_WORDS = 24 };   // (CTL_COUNT: three u64 sums, see KArgs::counters)
 constexpr double kEps = 2.220446049250313e-13;       // _kernel.pyx:29
 constexpr double kAlphaZero = 1e-8;                  // :32
 constexpr double kCcm = 2.99792458e10;               // :33
@@ -210,7 +210,9 @@ struct KArgs {
     //       photons, except for [2]
     //   [2] fused exits: photons finished one step early by the fused exit (their last, empty step is not run)
     //   [3] waves retired
-    // Per wave two scalar adds per iteration and three atomics when it retires; null = off.
+    // Kept per LANE in three vector registers (the loop is short of scalar ones): one add per trip, one when a photon
+    // ends (its own step count `count` is what is added), one in the fused exit; summed in LDS when a wave retires, four
+    // atomics per workgroup.  null = off.
     unsigned long long* counters;
 };
 constexpr int kMeshQ = PVT_MESH_Q;    // leaves a lane notes before its triangles are tested
@@ -915,7 +917,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     double wl = 0.0, travelled = 0.0, duration = 0.0;
     Rng rng{0, 0, 0, 0};
     int count = 0, source = -1, nev = 0;
-    unsigned int n_iters = 0u, n_lane_steps = 0u;   // wave-uniform (KArgs::counters)
+    unsigned int c_iters = 0u, c_steps = 0u, c_fused = 0u;   // this lane's share of the step counters (KArgs::counters)
     int rec_slot = -1;   // recorded rays: index among them (row block rec_slot * max_events), else -1
     Seen<SEENW> seen;
 #pragma unroll
@@ -1298,8 +1300,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
 #endif
 
 #if PVT_COUNTERS
-        n_iters += 1u;
-        n_lane_steps += (unsigned int)__popcll(__ballot(alive));
+        c_iters += 1u;
 #endif
 #if PVT_TIMELINE
         if (tl_iters == 0) tl_t[2] = wall_clock64();
@@ -2317,7 +2318,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (dn > 0.0 && g <= (0.5 * kEps) * dn) {
                     terminal = true;
 #if PVT_COUNTERS
-                    atomicAdd(reinterpret_cast<unsigned int*>(ctl) + CTL_FUSED, 1u);
+                    c_fused += 1u;
 #endif
                 }
             }
@@ -2433,6 +2434,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             if constexpr (RECORD) {
                 if (rec_slot >= 0) A.log_counts[rec_slot] = nev;
             }
+#if PVT_COUNTERS
+            c_steps += (unsigned int)count;   // the trips this photon took, in whichever launches and lanes
+#endif
             alive = false;
         }
     }
@@ -2459,20 +2463,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     }
 #endif
     tally_flush();   // the first crossings still parked
-    unsigned long long* ctr;   // this workgroup's row of the step counters (null: off)
-    {
-        const __attribute__((address_space(4))) KArgs* ak =
-            (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ak));
-        ctr = ak->counters;
-        if (ctr) {
-            ctr += (blockIdx.x & 63u) * 4u;
-            if (lane == 0) {
-                atomicAdd(ctr, (unsigned long long)n_iters);
-                atomicAdd(ctr + 1, (unsigned long long)n_lane_steps);
-                atomicAdd(ctr + 3, 1ull);
-            }
-        }
+    {   // this wave's share of the step counters, into the workgroup's sums
+        unsigned long long* const cnt = reinterpret_cast<unsigned long long*>(ctl + CTL_COUNT);
+        if (lane == 0) atomicAdd(cnt, (unsigned long long)c_iters);
+        atomicAdd(cnt + 1, (unsigned long long)c_steps);
+        atomicAdd(cnt + 2, (unsigned long long)c_fused);
     }
     // ---- flush workgroup accumulators: done by the LAST wave to leave -------
     // (no closing barrier: retiring waves must never be counted by the drain-phase
@@ -2483,9 +2478,16 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     order = __builtin_amdgcn_readfirstlane(order);
     if (order != kWaves - 1) return;
     __threadfence_block();
-    if (ctr && lane == 0) {
-        const unsigned int fused = reinterpret_cast<unsigned int*>(ctl)[CTL_FUSED];
-        if (fused) atomicAdd(ctr + 2, (unsigned long long)fused);
+    {
+        const __attribute__((address_space(4))) KArgs* ak =
+            (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ak));
+        unsigned long long* ctr = ak->counters;
+        if (ctr && lane < 4) {
+            const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(ctl + CTL_COUNT);
+            const unsigned long long v = lane == 3 ? (unsigned long long)kWaves : cnt[lane];
+            if (v) atomicAdd(ctr + (blockIdx.x & 63u) * 4u + lane, v);
+        }
     }
     unsigned long long* const out_distinct = reinterpret_cast<unsigned long long*>(A.rec_distinct) + (long long)set * A.set_stride_i;
     unsigned long long* const out_crossings = reinterpret_cast<unsigned long long*>(A.rec_crossings) + (long long)set * A.set_stride_i;

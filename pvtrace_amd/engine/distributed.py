@@ -67,12 +67,15 @@ def all_reduce_tallies(tallies, group=None):
     return tallies
 
 
-def run_sharded(scene, num_rays, max_events, record_every, group, trace_shard):
+def run_sharded(scene, num_rays, max_events, record_every, group, trace_shard, prepare=None):
     """What every rank of a sharded job does around its own trace: take the index range of the rank, trace it
     (`trace_shard(compiled, start, stop) -> (tallies, finish)`: `tallies` holds torch tensors -- on whatever device
     the group's backend reduces -- and `finish(tallies) -> data` turns the reduced tallies and the rank's event log into
     the reference's `data` dict), sum the tallies over the ranks, wrap the result.  `simulate_sharded` passes the
-    GPU trace; anything that produces the same arrays shards and reduces the same way."""
+    GPU trace; anything that produces the same arrays shards and reduces the same way.
+    `prepare(compiled, start, stop)` (optional) runs BEFORE the clock starts: whatever the trace needs resident first --
+    tables uploaded, buffers allocated, device idle -- so that `EngineResult.elapsed` wraps the trace and the
+    reduction only, as `simulate()`'s does (reference convention, api.py:232-245)."""
     import torch.distributed as dist
 
     from pvtrace_amd.engine import emit as emit_mod
@@ -82,6 +85,8 @@ def run_sharded(scene, num_rays, max_events, record_every, group, trace_shard):
     start, stop = shard_range(num_rays, rank, world, align=record_every)
     compiled = compile_scene(scene)
     sources = emit_mod.sources_for(scene, num_rays)[start:stop]
+    if prepare is not None:
+        prepare(compiled, start, stop)
     tic = time.perf_counter()
     tallies, finish = trace_shard(compiled, start, stop)
     all_reduce_tallies(tallies, group=group)
@@ -113,8 +118,10 @@ def simulate_sharded(scene, num_rays, seed, emit_seed=0, maxsteps=1000, max_even
     if device is None:
         device = _default_device()
     opened = []
+    ready = {}
 
-    def trace_shard(compiled, start, stop):
+    def prepare(compiled, start, stop):
+        # everything but the trace: emitter tables, the scene's upload (with its grid / BVH planning), rays, buffers
         n_local = stop - start
         emitter = emit_mod.EmitterTables(scene, strict=True) if rays is None else None
         dscene = native.DeviceScene(compiled, device=device, emitter=emitter)
@@ -125,6 +132,12 @@ def simulate_sharded(scene, num_rays, seed, emit_seed=0, maxsteps=1000, max_even
             dev_rays = tuple(torch.from_numpy(np.ascontiguousarray(np.asarray(a)[start:stop])).to(dev) for a in rays)
         tallies = dscene.new_tallies()
         log = (dscene.new_event_log(n_local, record_every, max_events) if record_every > 0 and n_local > 0 else None)
+        ready.update(dscene=dscene, dev_rays=dev_rays, tallies=tallies, log=log)
+        torch.cuda.synchronize(device)
+
+    def trace_shard(compiled, start, stop):
+        n_local = stop - start
+        dscene, dev_rays, tallies, log = ready["dscene"], ready["dev_rays"], ready["tallies"], ready["log"]
         if n_local > 0:
             dscene.trace(dev_rays, n_local, int(seed), tallies, log=log, ray_offset=start,
                          emit_seed=int(emit_seed), record_every=int(record_every),
@@ -139,7 +152,7 @@ def simulate_sharded(scene, num_rays, seed, emit_seed=0, maxsteps=1000, max_even
 
     try:
         with torch.cuda.device(device):
-            return run_sharded(scene, num_rays, max_events, record_every, group, trace_shard)
+            return run_sharded(scene, num_rays, max_events, record_every, group, trace_shard, prepare=prepare)
     finally:
         for dscene in opened:
             dscene.close()

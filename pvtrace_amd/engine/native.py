@@ -10,6 +10,7 @@ on torch's current HIP stream.  Pointers and sizes are all the library sees.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -427,6 +428,10 @@ class DeviceScene:
               "pvt_scene_create")
         self.handle = handle
         self.has_emitter = False
+        # HIP stream handle -> weak reference to the BundlePipeline whose job lives on it (parked photons belong to a
+        # job, and torch hands the same stream handles out again: see claim_stream)
+        self._stream_owners = {}
+        self._owners_lock = threading.Lock()
         if emitter is not None:
             self.set_emitter(emitter)
 
@@ -602,8 +607,50 @@ class DeviceScene:
         return bool(self.lib.pvt_scene_carry_pending(self.handle, C.c_void_p(stream)))
 
     def trim(self):
-        """Before the scene is put aside for reuse: free staging buffers, forget parked photons (pvt_scene_trim)."""
+        """Before the scene is put aside for reuse: free staging buffers, forget parked photons (pvt_scene_trim).
+        Refused while a live pipeline still owns one of the scene's streams: its parked photons would vanish."""
+        live = self.stream_owners()
+        if live:
+            raise RuntimeError(f"{len(live)} BundlePipeline(s) still hold streams of this scene; close them first "
+                               "(trimming would drop the photons their jobs have parked)")
         check(self.lib.pvt_scene_trim(self.handle), "pvt_scene_trim")
+
+    # -- who a stream's parked photons belong to ------------------------------------------------------------------
+    def stream_owners(self):
+        """The live pipelines that own a stream of this scene."""
+        with self._owners_lock:
+            owners = {}
+            for handle, ref in list(self._stream_owners.items()):
+                owner = ref()
+                if owner is None:
+                    del self._stream_owners[handle]   # its job died with it
+                else:
+                    owners[id(owner)] = owner
+            return list(owners.values())
+
+    def claim_stream(self, owner, stream_handle):
+        """`owner` (a BundlePipeline) starts a job on `stream_handle`.  torch hands out streams from a pool of ~32 per
+        device, so the handle may be one an EARLIER pipeline used: if that pipeline is gone (closed, or dropped) whatever
+        it left parked belongs to a dead job and is discarded; if it is still alive the two jobs would resume each
+        other's photons, and the claim is refused."""
+        import weakref
+
+        with self._owners_lock:
+            ref = self._stream_owners.get(stream_handle)
+            other = ref() if ref is not None else None
+            if other is not None and other is not owner:
+                raise RuntimeError(
+                    "this HIP stream already carries the job of another live BundlePipeline on the same scene (torch reuses "
+                    "stream handles); close() that pipeline first, or give each pipeline a scene of its own")
+            self._stream_owners[stream_handle] = weakref.ref(owner)
+        if self.carry_pending(stream_handle):
+            self.carry_discard(stream_handle)
+
+    def release_stream(self, owner, stream_handle):
+        with self._owners_lock:
+            ref = self._stream_owners.get(stream_handle)
+            if ref is not None and ref() in (owner, None):
+                del self._stream_owners[stream_handle]
 
     def carry_discard(self, stream=None):
         """Forget the photons parked on `stream` (an abandoned job)."""

@@ -55,10 +55,18 @@ class BundlePipeline:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         # torch hands out streams from a small pool and a resident scene outlives a pipeline: photons an ABANDONED
         # pipeline left parked on one of these stream handles (an exception between two bundles, an object simply
-        # dropped) belong to a dead job and must not be resumed into this one
-        for s_ in self.streams:
-            if dscene.carry_pending(s_.cuda_stream):
-                dscene.carry_discard(s_.cuda_stream)
+        # dropped) belong to a dead job and must not be resumed into this one -- while a handle that a LIVE pipeline
+        # on this scene still uses must not be shared at all (DeviceScene.claim_stream keeps the ownership)
+        self._claimed = []
+        try:
+            for s_ in self.streams:
+                dscene.claim_stream(self, s_.cuda_stream)
+                self._claimed.append(s_.cuda_stream)
+        except Exception:
+            for h in self._claimed:
+                dscene.release_stream(self, h)
+            self._claimed = []
+            raise
         self.slots = [dscene.new_tallies() for _ in range(self.depth)]
         # The kernel ADDS its tallies with atomics (one per non-zero slot per workgroup), so the launches of every
         # stream can add into ONE running total: nothing to fold when the totals are read (the fold was eight tiny
@@ -164,6 +172,12 @@ class BundlePipeline:
             except Exception:   # noqa: BLE001 -- the scene may be gone already
                 pass
         self._parked = {}
+        for h in getattr(self, "_claimed", []):
+            try:
+                self.dscene.release_stream(self, h)
+            except Exception:   # noqa: BLE001
+                pass
+        self._claimed = []
 
     def __del__(self):
         try:

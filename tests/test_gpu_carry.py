@@ -184,3 +184,44 @@ def test_host_buffer_entry_ignores_the_carry_flag():
     flagged = _kernel.trace_bundle(compiled, pos, dirs, wl, 11, 1000, 16, 0, 1, 0, flags=native.FLAG_CARRY_OUT)
     for key in INT_KEYS:
         assert np.array_equal(plain[key], flagged[key]), key
+
+
+def test_a_stream_that_carries_a_live_job_is_not_handed_to_another_pipeline():
+    """torch reuses stream handles (a pool per device) and a resident scene outlives pipelines: a SECOND live pipeline
+    that were given a handle an older one still uses would drop that job's parked photons.  The scene keeps
+    the ownership: a live owner refuses the claim, a dead or closed one hands the handle over with nothing parked,
+    and a scene with live pipelines is not trimmed under them."""
+    scene = scenes.lsc_equivalent()
+    compiled = compile_scene(scene)
+    dscene = native.DeviceScene(compiled, device=0, emitter=EmitterTables(scene))
+    try:
+        first = BundlePipeline(dscene, depth=2)
+        first.submit(None, 40_000, seed=5, emit_seed=6)
+        first.submit(None, 40_000, seed=5, ray_offset=40_000, emit_seed=6)
+        handles = [s.cuda_stream for s in first.streams]
+        assert any(dscene.carry_pending(h) for h in handles)
+
+        class Other:   # (stands for a second pipeline that torch happened to give the same stream)
+            pass
+
+        other = Other()
+        with pytest.raises(RuntimeError, match="another live BundlePipeline"):
+            dscene.claim_stream(other, handles[0])
+        with pytest.raises(RuntimeError, match="still hold streams"):
+            dscene.trim()
+        assert any(dscene.carry_pending(h) for h in handles)      # nothing was dropped: the first job is intact ...
+        first.submit(None, 20_000, seed=5, ray_offset=80_000, emit_seed=6, closing=True)
+        first.submit(None, 0, seed=5, ray_offset=100_000, emit_seed=6, closing=True)
+        got = first.totals_host()
+        names = list(compiled.recorder_names)
+        assert got["rec_distinct"][names.index("entering")] + got["rec_distinct"][names.index("reflected")] == 100_000
+        # ... and once it is closed its handles are free again, with nothing parked on them
+        first.submit(None, 30_000, seed=7, emit_seed=6)
+        first.close()
+        assert not dscene.stream_owners()
+        dscene.claim_stream(other, handles[0])
+        assert not dscene.carry_pending(handles[0])
+        dscene.release_stream(other, handles[0])
+        dscene.trim()
+    finally:
+        dscene.close()
