@@ -351,12 +351,14 @@ def main():
             self.array_input = name == "cfg2" or os.environ.get("PVT_BENCH_ARRAY_INPUT") == "1"   # (developer A/B)
             self.ray_sets, self.host_rays = [None], None
             if self.array_input:
-                # each rank's shard: global indices [rank*n, (rank+1)*n); emission seeded per shard and per
-                # buffer.  The steps rotate through `--ray-buffers` distinct ray sets so that a step's input
-                # does not sit in the Infinity Cache from the previous step.
+                # each rank's shard: global indices [rank*n, (rank+1)*n).  The steps rotate through `--ray-buffers`
+                # distinct ray sets so that a step's input does not sit in the Infinity Cache from the previous step.
+                # The sets are the same on every rank (a ray's history is decided by its RNG stream, seed + GLOBAL
+                # index, which differs from rank to rank): the strong-scaling job below can then be the SAME job --
+                # photon j starts as row j % n of set (j // n) % sets -- whatever the number of ranks that share it.
                 self.ray_sets = []
                 for b in range(nbuf):
-                    p_, d_, w_, _ = emit_bundle(self.scene, photons, seed=1000 + rank + 7919 * b)
+                    p_, d_, w_, _ = emit_bundle(self.scene, photons, seed=1000 + 7919 * b)
                     if b == 0:
                         self.host_rays = (p_, d_, w_)
                     self.ray_sets.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (p_, d_, w_)))
@@ -494,16 +496,18 @@ def main():
             pipe.reset_totals()
             fenced()
             t0 = time.perf_counter()
-            at, k = lo, 0
+            at = lo
             while at < hi:
-                m = min(n, hi - at)
-                rays = leg.ray_sets[k % len(leg.ray_sets)]
-                if rays is not None and m != leg.n:
-                    rays = tuple(t[:m] for t in rays)
-                pipe.submit(rays, m, seed=777, ray_offset=at, emit_seed=4242 + k * world * leg.n, maxsteps=1000, max_events=128,
+                # bundles end on the job's own multiples of n, so that photon j is row j % n of ray set (j // n) % sets
+                # for every way of sharding the job (a shard that starts in the middle of a bundle begins with a short one)
+                g, off = divmod(at, n)
+                m = min(n - off, hi - at)
+                rays = leg.ray_sets[g % len(leg.ray_sets)]
+                if rays is not None and (off or m != leg.n):
+                    rays = tuple(t[off:off + m] for t in rays)
+                pipe.submit(rays, m, seed=777, ray_offset=at, emit_seed=4242, maxsteps=1000, max_events=128,
                             emit_method=leg.method, timed=False, tail=at + m >= hi, closing=at + m * args.streams >= hi)
                 at += m
-                k += 1
             pipe.reduce_totals()
             fenced()
             return time.perf_counter() - t0

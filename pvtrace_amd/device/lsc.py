@@ -208,18 +208,32 @@ class LSC(object):
         recorders with a source filter (light-emitted vs component-emitted photons)."""
         lo, hi = float(self.wavelength_range.min()), float(self.wavelength_range.max()) + 1.0
         nbins = max(int(round((hi - lo) / 5.0)), 1)
+        hist = lambda: [Histogram("wavelength", lo, hi, nbins)]   # noqa: E731 -- what spectrum() reads
         recs = []
         for label, normal in FACETS.items():
             recs += [
-                Recorder(f"solar-in-{label}", event="entering", facet=normal, source="lights"),
-                Recorder(f"solar-out-{label}", event="escaping", facet=normal, source="lights"),
-                Recorder(f"solar-reflected-{label}", event="reflected", facet=normal, source="lights"),
+                Recorder(f"solar-in-{label}", event="entering", facet=normal, source="lights", histograms=hist()),
+                Recorder(f"solar-out-{label}", event="escaping", facet=normal, source="lights", histograms=hist()),
+                Recorder(f"solar-reflected-{label}", event="reflected", facet=normal, source="lights", histograms=hist()),
                 Recorder(f"lum-in-{label}", event="entering", facet=normal, source="components"),
-                Recorder(f"lum-out-{label}", event="escaping", facet=normal, source="components",
-                         histograms=[Histogram("wavelength", lo, hi, nbins)]),
+                Recorder(f"lum-out-{label}", event="escaping", facet=normal, source="components", histograms=hist()),
             ]
-        recs += [Recorder("lost", event="lost"), Recorder("killed", event="killed")]
+        recs += [Recorder("lost", event="lost"), Recorder("killed", event="killed", histograms=hist()),
+                 Recorder("lost-solar", event="lost", source="lights", histograms=hist()),
+                 Recorder("lost-lum", event="lost", source="components", histograms=hist())]
+        # Several emitting components: the luminescent tallies once more per component, so that spectrum(source=...)
+        # can tell them apart (with one, "components" IS that component)
+        emitters = self._emitting_components()
+        if len(emitters) > 1:
+            for k, name in enumerate(emitters):
+                recs.append(Recorder(f"lost-lum-{k}", event="lost", source=name, histograms=hist()))
+                for label, normal in FACETS.items():
+                    recs.append(Recorder(f"lum-out-{label}-{k}", event="escaping", facet=normal, source=name, histograms=hist()))
         return recs
+
+    def _emitting_components(self):
+        """Names of the components that can be the source of a ray (luminophores and scatterers)."""
+        return [c["name"] for c in self._user_components if c["cls"] in (Luminophore, Scatterer)]
 
     @property
     def scene(self):
@@ -304,14 +318,82 @@ class LSC(object):
         except ImportError:
             return out
 
-    def spectrum(self, facets=("left", "right", "near", "far", "top", "bottom")):
-        """(bin edges, counts) of the luminescent photons leaving through `facets`."""
+    def spectrum(self, facets=set(), kind="last", source="all", events=None):
+        """Wavelength spectrum of the rays the reference's `LSC.spectrum` would select (lsc.py:505-566): same arguments,
+        same validation, same errors -- but on recorder tallies, so the answer is `(bin edges, counts)` (5 nm bins over the
+        LSC's wavelength range), not a per-ray series.
+
+        The reference keeps two rows per photon: its `kind="first"` row (the first event after generation: the photon
+        transmitted into, or reflected off, a facet) and its `kind="last"` row (the photon when it was lost, or at its
+        last interaction before it left the world: transmitted out of, or reflected off, a facet); `kind=None` selects
+        both.  `source`: "all", a name, or a set of names out of `component_names() | light_names()` -- who emitted the
+        ray in that row; `facets`: a set of facet labels (empty: no filter -- rows without a facet, i.e. photons lost
+        inside the slab, then count too); `events`: a set of event names ("transmit", "reflect", "absorb", "kill", ...).
+        Tallies count a photon once per facet recorder (its first matching crossing), the approximation `counts()`
+        makes too; several LIGHTS are tallied together (the engine knows a light-emitted ray only as such), so a
+        source set that names some but not all lights is refused."""
         if self._result is None:
             raise ValueError("Run a simulation before calling this method.")
-        total, edges = None, None
-        for f in facets:
-            edges, values = self._result.recorders[f"lum-out-{f}"].histogram(0)
-            total = values.copy() if total is None else total + values
+        if kind is not None:
+            if kind not in {"first", "last"}:
+                raise ValueError("Direction must be either `'first'` or `'last'.`")
+        all_sources = self.component_names() | self.light_names()
+        if source == "all":
+            want_sources = set(all_sources)
+        else:
+            if isinstance(source, str):
+                source = {source}
+            if not set(source).issubset(all_sources):
+                raise ValueError("Unknown source requested.", set(source).difference(all_sources))
+            want_sources = set(source)
+        if isinstance(facets, (list, tuple, set)):
+            want_facets = set(facets)
+        else:
+            raise ValueError("`'facets'` should be a set `{'left', 'right'}`", {"got": facets})
+        if events is not None:
+            from pvtrace_amd.light import Event
+
+            all_events = {e.name.lower() for e in Event}
+            if isinstance(events, (list, tuple, set)):
+                events = set(events)
+                if not events.issubset(all_events):
+                    raise ValueError("Contained some unknown events", {"got": events, "expected": all_events})
+            else:
+                raise ValueError("Events must be set of event strings", {"allowed": all_events})
+        lights = self.light_names()
+        picked = want_sources & lights
+        if picked and picked != lights:
+            raise ValueError("the lights of an LSC are tallied together: name all of them or none", {"got": picked})
+        emitters = self._emitting_components()
+        # (recorder, row kind, event of the row, facet or None, sources it stands for)
+        rows = []
+        for f in FACETS:
+            rows += [(f"solar-in-{f}", "first", "transmit", f, lights), (f"solar-reflected-{f}", "first", "reflect", f, lights),
+                     (f"solar-out-{f}", "last", "transmit", f, lights), (f"solar-reflected-{f}", "last", "reflect", f, lights)]
+            if len(emitters) > 1:
+                rows += [(f"lum-out-{f}-{k}", "last", "transmit", f, {name}) for k, name in enumerate(emitters)]
+            elif emitters:
+                rows.append((f"lum-out-{f}", "last", "transmit", f, set(emitters)))
+        rows.append(("lost-solar", "last", "absorb", None, lights))
+        if len(emitters) > 1:
+            rows += [(f"lost-lum-{k}", "last", "absorb", None, {name}) for k, name in enumerate(emitters)]
+        elif emitters:
+            rows.append(("lost-lum", "last", "absorb", None, set(emitters)))
+        if want_sources == set(all_sources):
+            rows.append(("killed", "last", "kill", None, set(all_sources)))
+        recs = self._result.recorders
+        edges, total = recs["lost-solar"].histogram(0)
+        total = np.zeros_like(total)
+        for name, row_kind, event, facet, stands_for in rows:
+            if kind is not None and row_kind != kind:
+                continue
+            if want_facets and facet not in want_facets:
+                continue
+            if events is not None and event not in events:
+                continue
+            if not stands_for <= want_sources:
+                continue
+            total = total + recs[name].histogram(0)[1]
         return edges, total
 
     def report(self):

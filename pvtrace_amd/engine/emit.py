@@ -15,6 +15,15 @@ is lowered to a small `EmitterTables` record that either
 A delegate that cannot be lowered (a lambda, a user function) keeps working in
 host mode: THAT delegate is called once per ray, the light's other delegates are
 still sampled vectorised and no Ray object is built per photon.
+
+**Vectorised user delegates.**  A user's own delegate is called once per BUNDLE instead
+of once per ray when it says it can be: an object with a ``sample(n)`` method, or a
+callable carrying ``vectorized = True`` (then called as ``delegate(n)``), returning
+``n`` wavelengths (shape ``(n,)``) or ``n`` positions / directions (shape ``(n, 3)``)
+in the light's frame.  Called without arguments it must still give one sample (that is
+what `Light.emit` and the reference's per-ray path do, pvtrace/light/light.py:226-233),
+so the same object works everywhere; `vectorized_delegate` wraps a per-bundle function
+into such an object.
 """
 import functools
 import threading
@@ -95,6 +104,49 @@ def classify_direction(d):
     if g is not None:
         return (DIR_ISOTROPIC, 0.0) if abs(g) < 1e-12 else (DIR_HG, g)
     return None
+
+
+def vectorized_delegate(sample_n):
+    """Wrap `sample_n(n) -> array of n samples` into a light delegate: `delegate()` gives one sample (any Light, the
+    per-ray paths), `delegate.sample(n)` the whole bundle at once (what `emit_bundle` uses)."""
+
+    class _Vectorized:
+        vectorized = True
+
+        def __call__(self, n=None):
+            if n is None:
+                one = np.asarray(sample_n(1))
+                return float(one[0]) if one.ndim == 1 else tuple(one[0].tolist())
+            return sample_n(int(n))
+
+        def sample(self, n):
+            return sample_n(int(n))
+
+    return _Vectorized()
+
+
+def _bundle_sampler(delegate):
+    """`f(n)` when the user's delegate can produce a whole bundle at once (see the module docstring), else None."""
+    if callable(getattr(delegate, "sample", None)) and not isinstance(delegate, type):
+        return delegate.sample
+    if getattr(delegate, "vectorized", False):
+        return delegate
+    return None
+
+
+def _user_samples(call, count, width):
+    """`count` samples of a user delegate, (count,) for width 1 else (count, width): one call for the bundle when the
+    delegate offers it, else one call per ray (the reference's behaviour, pvtrace/engine/emit.py:116-124)."""
+    many = _bundle_sampler(call)
+    if many is not None:
+        out = np.asarray(many(count), dtype=np.float64)
+        want = (count,) if width == 1 else (count, width)
+        if out.shape != want:
+            raise ValueError(f"vectorised light delegate returned shape {out.shape}, expected {want}")
+        return np.ascontiguousarray(out)
+    if width == 1:
+        return np.fromiter((call() for _ in range(count)), dtype=np.float64, count=count)
+    return np.array([tuple(np.asarray(call()).tolist()) for _ in range(count)], dtype=np.float64).reshape(count, width)
 
 
 class EmitterTables:
@@ -288,16 +340,13 @@ def emit_bundle(scene, num_rays, seed=None):
             # THAT delegate: the light's recognised delegates were sampled vectorised above, no Ray object is
             # built per photon and the change of frame below is one matrix product for the whole bundle.
             custom = tab.custom[i]
+            # (a delegate that offers it is asked for the whole bundle at once: `sample(n)` / `vectorized = True`)
             if "wavelength" in custom:
-                call = custom["wavelength"]
-                wl = np.fromiter((call() for _ in range(count)), dtype=np.float64, count=count)
+                wl = _user_samples(custom["wavelength"], count, 1)
             if "position" in custom:
-                call = custom["position"]
-                pos = np.array([tuple(call()) for _ in range(count)], dtype=np.float64).reshape(count, 3)
+                pos = _user_samples(custom["position"], count, 3)
             if "direction" in custom:
-                call = custom["direction"]
-                direc = np.array([tuple(np.asarray(call()).tolist()) for _ in range(count)],
-                                 dtype=np.float64).reshape(count, 3)
+                direc = _user_samples(custom["direction"], count, 3)
         m = tab.light_to_world[i]
         positions[rows] = _to_world(pos, m, translate=True)
         directions[rows] = _to_world(direc, m, translate=False)

@@ -139,8 +139,27 @@ def test_lsc_high_level_api_runs_on_the_engine():
     assert abs(lum_out / n - 0.62) < 0.01 and c["Luminescent In"]["top"] == 0
     assert s["Optical Efficiency"] == 0.0 and s["Incident"] == sum(c["Solar In"])   # no cells attached
     assert abs(s["Non-radiative Loss (fraction):"] - 0.340 / 0.960) < 0.01
-    edges, spectrum = lsc.spectrum()
+    # spectrum(facets, kind, source, events): the reference's signature (lsc.py:505-566) on tallies
+    edges, spectrum = lsc.spectrum(source=lsc.component_names(), events={"transmit"})
     assert spectrum.sum() == lum_out and edges[np.argmax(spectrum)] > 580
+    recs = lsc._result.recorders
+    _, everything = lsc.spectrum()                       # kind="last", every source: one row per photon
+    assert everything.sum() == n                         # each photon ends lost, through a facet, or reflected off the top
+    _, first = lsc.spectrum(kind="first")
+    assert first.sum() == n and first[np.searchsorted(edges, 555.0, side="right") - 1] == n    # the lamp's 555 nm, in or reflected
+    _, top_in = lsc.spectrum(facets={"top"}, kind="first", source="Light", events={"transmit"})
+    assert top_in.sum() == c["Solar In"]["top"]
+    _, lost = lsc.spectrum(events={"absorb"})
+    assert lost.sum() == recs["lost"].rays
+    _, lost_lum = lsc.spectrum(events={"absorb"}, source="Lumogen F Red 305")
+    assert lost_lum.sum() == recs["lost-lum"].rays and 0 < lost_lum.sum() < lost.sum()
+    _, edge_lum = lsc.spectrum(facets={"left", "right"}, source={"Lumogen F Red 305"})
+    assert edge_lum.sum() == c["Luminescent Out"]["left"] + c["Luminescent Out"]["right"]
+    assert lsc.spectrum(source="Background")[1].sum() == 0            # an absorber emits nothing
+    assert lsc.spectrum(kind=None)[1].sum() == 2 * n                  # both rows of every photon
+    for bad in (dict(kind="middle"), dict(source="Sun"), dict(facets="top"), dict(events={"teleport"}), dict(events="absorb")):
+        with pytest.raises(ValueError):
+            lsc.spectrum(**bad)
     cells = LSC((5.0, 5.0, 1.0)); cells.add_solar_cell({"left", "right", "near", "far"}); cells.add_back_surface_mirror()
     cells.simulate(n, seed=4, emit_seed=6)
     t, ct = cells.summary(), cells.counts()
