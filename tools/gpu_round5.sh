@@ -1,13 +1,15 @@
 #!/bin/bash
-# One GPU-box pass of round 4: tests, smoke, bench (the driver's flags), rocprof kernel trace of the same command, the
-# scene / mesh / end-to-end / history / lone-step tables.  (PMC passes: tools/gpu_pmc.sh pipelined <config>, run separately.)
-# usage: tools/gpu_round4.sh [skip-tests]
+# One GPU-box pass of round 5: tests (the 8-rank rehearsal's line is kept), smoke, bench (the driver's flags), rocprof kernel
+# trace of the same command, the scene / mesh / end-to-end / history / lone-step tables.  (PMC passes: tools/gpu_pmc.sh
+# pipelined <config>, run separately; earlier rounds' passes -- gpu_round.sh, gpu_round3.sh, gpu_round4.sh -- were this
+# script's predecessors and are in the history.)
+# usage: tools/gpu_round5.sh [skip-tests]
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 if [ "$1" != skip-tests ]; then
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|rror" gpurun_out/pytest_gpu.log | tail -5
+PVT_EIGHT_RANKS_RECORD=$R/gpurun_out/eight_ranks.json timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|rror" gpurun_out/pytest_gpu.log | tail -5
 fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/bench.err | tee gpurun_out/bench.json | cut -c1-400
