@@ -626,7 +626,9 @@ __device__ __forceinline__ u32x4 pack_dd(double a, double b) {
     const unsigned long long ua = pvt_d2u(a), ub = pvt_d2u(b);
     return u32x4{(unsigned int)ua, (unsigned int)(ua >> 32), (unsigned int)ub, (unsigned int)(ub >> 32)};
 }
-template <bool RECORD>
+// (VIA_A: inside a called function -- the tail function -- the kernel-argument segment pointer is not to be had from the
+// intrinsic (measured: garbage in a callee, ROCm 7.0); the caller's `A` already IS that segment, handed down explicitly)
+template <bool RECORD, bool VIA_A = false>
 __device__ __forceinline__ void log_row(const KArgs& A, int rec_slot, int& nev, int kind, int hit,
                                         int container, int adjacent, int component, int source,
                                         const V3& pos, const V3& dir, bool has_normal, const V3& nrm,
@@ -637,7 +639,8 @@ __device__ __forceinline__ void log_row(const KArgs& A, int rec_slot, int& nev, 
         // the log pointer is read from the kernel-argument segment at the point of use (scalar load) instead of
         // living in two scalar registers across the whole loop
         const __attribute__((address_space(4))) KArgs* ak =
-            (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            VIA_A ? (const __attribute__((address_space(4))) KArgs*)(unsigned long long)&A
+                  : (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ak));
 #if PVT_LOG_STORES == 8
         // eight-byte stores straight from the registers the values live in (no 16-byte vectors to assemble: the
@@ -746,8 +749,19 @@ struct Seen {
 // MESH: the scene has triangle-mesh nodes.  The BVH walk costs ~35 VGPRs, so scenes made of
 // analytic shapes run the variant compiled without it (one more wave per SIMD).
 // GRID: scenes of many nodes -- every lane finds the nodes its ray can cross through a uniform grid (see the node loop).
-template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH, bool GRID = false>
-__device__ __forceinline__ void trace_body(const KArgs& A) {
+// TAIL: the same loop as a FUNCTION for the last wave of a draining workgroup (`tail_run`, below): no rays to claim, no
+// rendezvous -- it takes the `tail_total` photons its caller left in the exchange buffer and steps them until none is left.
+#ifndef PVT_TAIL_CALL
+#define PVT_TAIL_CALL 1
+#endif
+#ifndef PVT_TAIL_ALPHA
+#define PVT_TAIL_ALPHA 1   // (0: a developer build whose tail function looks the absorption coefficients up in every step)
+#endif
+template <bool RECORD, int TAB_LDS, int SEENW, bool MESH, bool GRID>
+__device__ void tail_run(const KArgs* kernel_args, int total);
+
+template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH, bool GRID = false, bool TAIL = false>
+__device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
     extern __shared__ double smem[];
 #if PVT_TIMELINE
     unsigned long long tl_t[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0};
@@ -792,6 +806,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     int* const tq_r = reinterpret_cast<int*>(reinterpret_cast<double*>(xbuf + kXWords * A.xslots) + kWaves * tq_doubles * kTallyQ)
                       + (threadIdx.x >> 6) * kTallyQ;
     int tq_n = 0;   // wave-uniform
+    if constexpr (!TAIL) {   // (the tail function finds the workgroup's LDS as its caller left it)
     if (threadIdx.x < CTL_WORDS) ctl[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 4 && A.cursor_next) A.cursor_next[threadIdx.x] = 0u;
     if constexpr (MESH) {   // the top of the triangle trees (two 16-byte words per record)
@@ -809,6 +824,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     if (A.bins_in_lds)
         for (int i = threadIdx.x; i < A.total_bins; i += kBlock) acc_bins[i] = 0u;
     __syncthreads();
+    }
 #if PVT_TIMELINE
     tl_t[1] = wall_clock64();
 #endif
@@ -918,6 +934,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     Rng rng{0, 0, 0, 0};
     int count = 0, source = -1, nev = 0;
     unsigned int c_iters = 0u, c_steps = 0u, c_fused = 0u;   // this lane's share of the step counters (KArgs::counters)
+    // (tail function) the absorption coefficients this lane's photon met last: container, wavelength bits, sum, first term
+    int ac_node = -1;
+    unsigned long long ac_wl = 0ull;
+    double ac_alpha = 0.0, ac_pre0 = 0.0;
     int rec_slot = -1;   // recorded rays: index among them (row block rec_slot * max_events), else -1
     Seen<SEENW> seen;
 #pragma unroll
@@ -958,6 +978,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     // drain-phase consolidation state (all wave-uniform)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int members = 0, parity = 0;
+    int tail_n = 0;   // photons this wave hands to the tail function when it leaves the loop (0: none)
+    // (mesh scenes never repack a draining workgroup -- KArgs::xslots is 0 there -- and the history variant of the grid walk
+    // has no register to spare for the call: both keep their last wave in this loop)
+    constexpr bool kTailCall = PVT_TAIL_CALL && !TAIL && !MESH && !(GRID && RECORD);
 
     // Statistics of the parked first crossings, one lane per record: the recorder's distinct count, the
     // eight running sums (the angle is acos of the parked cosine; 1.0 -> exactly 0 for events without a
@@ -1004,7 +1028,33 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         }
         tq_n = 0;
     };
+    if constexpr (TAIL) {   // the photons the caller left in the exchange buffer, one per lane
+        constexpr int X = kXSlots;
+        const int slot = lane;
+        ws = WS_EXHAUSTED | WS_COUNTED | WS_SOLO;
+        alive = slot < tail_total;
+        if (alive) {
+            pos = V3{pvt_u2d(xbuf[0 * X + slot]), pvt_u2d(xbuf[1 * X + slot]), pvt_u2d(xbuf[2 * X + slot])};
+            dir = V3{pvt_u2d(xbuf[3 * X + slot]), pvt_u2d(xbuf[4 * X + slot]), pvt_u2d(xbuf[5 * X + slot])};
+            wl = pvt_u2d(xbuf[6 * X + slot]); travelled = pvt_u2d(xbuf[7 * X + slot]); duration = pvt_u2d(xbuf[8 * X + slot]);
+            rng.s0 = xbuf[9 * X + slot]; rng.s1 = xbuf[10 * X + slot]; rng.s2 = xbuf[11 * X + slot]; rng.s3 = xbuf[12 * X + slot];
+            const unsigned long long cs_ = xbuf[13 * X + slot];
+            count = (int)(unsigned int)cs_;
+            source = (int)(unsigned int)(cs_ >> 32);
+#pragma unroll
+            for (int w = 0; w < SEENW; w++) seen.w[w] = xbuf[(14 + w) * X + slot];
+            if constexpr (RECORD) {
+                const unsigned long long rn_ = xbuf[(14 + SEENW) * X + slot];
+                rec_slot = (int)(unsigned int)rn_;
+                nev = (int)(unsigned int)(rn_ >> 32);
+            }
+        }
+    }
     for (;;) {
+        if constexpr (TAIL) {
+            if (__ballot(alive) == 0ull) break;
+        }
+        if constexpr (!TAIL) {
         // ================= refill dead lanes ==============================
         unsigned long long need = __ballot(!alive);
         if constexpr (!RECORD) {
@@ -1166,7 +1216,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if constexpr (RECORD) {
                     rec_slot = -1;
                     if (A.record_every > 0 && (long long)i % A.record_every == 0) rec_slot = (int)((long long)i / A.record_every);
-                    log_row<RECORD>(A, rec_slot, nev, PVT_EV_GENERATE, -1, -1, -1, -1, source, pos, dir, false,
+                    log_row<RECORD, TAIL>(A, rec_slot, nev, PVT_EV_GENERATE, -1, -1, -1, -1, source, pos, dir, false,
                                     pos, wl, travelled, duration);
                 }
             }
@@ -1246,6 +1296,28 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             if (live == 0) break;
             if (nw == 1) {
                 ws = (ws & ~(unsigned int)WS_REGIME) | WS_SOLO;  // last wave standing: no more rendezvous
+                // ... and no more rays: the rest of its photons' histories runs in the tail function (the loop without
+                // the refill and the rendezvous, a function of its own: it cannot move this loop's registers); the
+                // photons go through the exchange buffer, as in a consolidation
+                if constexpr (kTailCall) {
+                    constexpr int X = kXSlots;
+                    if (alive) {
+                        const int slot = (int)rank_in(live_mask);
+                        xbuf[0 * X + slot] = pvt_d2u(pos.x); xbuf[1 * X + slot] = pvt_d2u(pos.y); xbuf[2 * X + slot] = pvt_d2u(pos.z);
+                        xbuf[3 * X + slot] = pvt_d2u(dir.x); xbuf[4 * X + slot] = pvt_d2u(dir.y); xbuf[5 * X + slot] = pvt_d2u(dir.z);
+                        xbuf[6 * X + slot] = pvt_d2u(wl); xbuf[7 * X + slot] = pvt_d2u(travelled); xbuf[8 * X + slot] = pvt_d2u(duration);
+                        xbuf[9 * X + slot] = rng.s0; xbuf[10 * X + slot] = rng.s1; xbuf[11 * X + slot] = rng.s2; xbuf[12 * X + slot] = rng.s3;
+                        xbuf[13 * X + slot] = (unsigned long long)(unsigned int)count | ((unsigned long long)(unsigned int)source << 32);
+#pragma unroll
+                        for (int w = 0; w < SEENW; w++) xbuf[(14 + w) * X + slot] = seen.w[w];
+                        if constexpr (RECORD) {
+                            xbuf[(14 + SEENW) * X + slot] = (unsigned long long)(unsigned int)rec_slot | ((unsigned long long)(unsigned int)nev << 32);
+                        }
+                    }
+                    tail_n = live;   // (the call itself comes after the loop: nothing of the loop is live across it)
+                    alive = false;
+                    break;
+                }
             } else if (total <= 64 * (nw - 1) && total <= A.xslots) {
                 constexpr int X = kXSlots;   // (A.xslots is 0 or kXSlots: constant offsets in the LDS instructions)
                 if (alive) {
@@ -1264,6 +1336,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 __syncthreads();  // B
                 const int keep = (total + 63) >> 6;  // waves that stay, lowest ids of the set
                 if (pos_in_set >= keep) { alive = false; break; }
+                if constexpr (kTailCall) {
+                    if (keep == 1) {   // the survivors fit one wave: this one, in the tail function (see above)
+                        tail_n = total;
+                        alive = false;
+                        break;
+                    }
+                }
                 const int slot = pos_in_set * 64 + lane;
                 alive = slot < total;
                 if (alive) {
@@ -1291,6 +1370,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                 if (keep == 1) ws = (ws & ~(unsigned int)WS_REGIME) | WS_SOLO;
             }
         }
+        }   // (!TAIL)
 #if PVT_STATS
         {
             unsigned long long live = __popcll(__ballot(alive));
@@ -1946,7 +2026,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             cbase = T.iv(container * NI + NI_CSTART); ccount = T.iv(container * NI + NI_CCOUNT);
             if (uf(UF_BY_NODE)) crec = cbase;   // (scenes of few nodes keep one record per component id)
             else crec = T.iv(container * NI + NI_CREC);
-            if (hit != A.root) {
+            // (tail function: a photon that bounces inside one body keeps its wavelength, and with it the coefficients of
+            // the step before -- the same table values, read once instead of once per bounce; not in the kernels' own loop,
+            // where the seven registers cost more than the lookups: docs/history.md, round 4)
+            bool known = false;
+            if constexpr (TAIL && PVT_TAIL_ALPHA) known = container == ac_node && pvt_d2u(wl) == ac_wl;
+            if (hit != A.root && !known) {
                 for (int k = 0; k < ccount; k++) {
                     const int ci = L.comp_i + (crec + k) * CI, cd = L.comp_d + (crec + k) * CD;
                     alpha += interp_clamped<TAB_LDS>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
@@ -1954,6 +2039,10 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                                                             T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
                     if (k == 0) pre0 = alpha;
                 }
+                if constexpr (TAIL) { ac_node = container; ac_wl = pvt_d2u(wl); ac_alpha = alpha; ac_pre0 = pre0; }
+            }
+            if constexpr (TAIL) {
+                if (known && hit != A.root) { alpha = ac_alpha; pre0 = ac_pre0; }
             }
         }
         int comp = -1;
@@ -1991,7 +2080,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
                             if (target <= running) { comp = cbase + k; break; }
                         }
                     }
-                    log_row<RECORD>(A, rec_slot, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
+                    log_row<RECORD, TAIL>(A, rec_slot, nev, PVT_EV_ABSORB, -1, container, -1, comp, source, pos,
                                     dir, false, pos, wl, travelled, duration);
                     ev_component = comp;
                     cls = CLS_ABS;
@@ -2327,7 +2416,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
         PVT_MARK(5);  // fresnel / reflect / refract
         // ================= deferred event: log row + tallies ==============
         if (alive && ev_kind >= 0)
-            log_row<RECORD>(A, rec_slot, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
+            log_row<RECORD, TAIL>(A, rec_slot, nev, ev_kind, ev_hit, ev_container, ev_adjacent, ev_component, source, pos,
                             dir, ev_normal, nrm, wl, travelled, duration);
 
         // Lane-parallel tally.  Each lane walks the (host-precomputed) list of recorders that
@@ -2454,7 +2543,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     }
 #endif
 #if PVT_TIMELINE
-    if (A.timeline && lane == 0) {
+    if (!TAIL && A.timeline && lane == 0) {
         unsigned long long* o = A.timeline + ((unsigned long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8;
         o[0] = tl_t[0]; o[1] = tl_t[1]; o[2] = tl_t[2]; o[3] = tl_t[3]; o[4] = wall_clock64(); o[5] = tl_iters;
         // (word 7: valid | the wave ended as the last of its workgroup << 1 | HW_ID register << 32: wave slot, SIMD, CU, SE)
@@ -2463,12 +2552,20 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
     }
 #endif
     tally_flush();   // the first crossings still parked
+    if constexpr (kTailCall) {
+        if (tail_n > 0) {
+            const __attribute__((address_space(4))) KArgs* ak =
+                (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            tail_run<RECORD, TAB_LDS, SEENW, MESH, GRID>((const KArgs*)ak, tail_n);
+        }
+    }
     {   // this wave's share of the step counters, into the workgroup's sums
         unsigned long long* const cnt = reinterpret_cast<unsigned long long*>(ctl + CTL_COUNT);
         if (lane == 0) atomicAdd(cnt, (unsigned long long)c_iters);
         atomicAdd(cnt + 1, (unsigned long long)c_steps);
         atomicAdd(cnt + 2, (unsigned long long)c_fused);
     }
+    if constexpr (TAIL) return;   // (the caller leaves through the code below)
     // ---- flush workgroup accumulators: done by the LAST wave to leave -------
     // (no closing barrier: retiring waves must never be counted by the drain-phase
     // rendezvous barriers of the waves still running)
@@ -2508,6 +2605,21 @@ __device__ __forceinline__ void trace_body(const KArgs& A) {
             unsigned int v = acc_bins[i];
             if (v) atomicAdd(out_bins + i, (unsigned long long)v);
         }
+}
+
+// The last wave of a draining workgroup finishes its photons here (see the drain in trace_body): the step loop alone, as a
+// function -- the kernels' own loop keeps its registers whatever this one needs, and what is specific to a wave that runs
+// alone on its SIMD (every step is latency, nothing overlaps) can be done here without a price on the bulk.
+template <bool RECORD, int TAB_LDS, int SEENW, bool MESH, bool GRID>
+__device__ __attribute__((noinline)) void tail_run(const KArgs* kernel_args, int total) {
+    // The kernel's arguments, read where the kernel itself reads them.  The pointer arrives in vector registers: it is made
+    // a scalar again (readfirstlane) and a pointer into the constant address space, so that the fields come through the
+    // scalar cache and what is decided by them stays wave-uniform.  (The kernel-argument intrinsic itself returns garbage
+    // inside a called function -- build/probe, ROCm 7.0 -- hence the explicit argument.)
+    const unsigned long long bits = (unsigned long long)kernel_args;
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)bits), hi = __builtin_amdgcn_readfirstlane((unsigned int)(bits >> 32));
+    const __attribute__((address_space(4))) KArgs* ak = (const __attribute__((address_space(4))) KArgs*)(((unsigned long long)hi << 32) | lo);
+    trace_body<RECORD, TAB_LDS, SEENW, false, MESH, GRID, true>(*(const KArgs*)ak, __builtin_amdgcn_readfirstlane(total));
 }
 
 // Entry points.  Every variant runs four waves per SIMD.  Scenes of analytic shapes, tally launches and
