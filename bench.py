@@ -217,13 +217,19 @@ def load_pmc(name, value_per_gpu, cus, live=None):
             # dispatches while sampling): 4*SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8)
             "valu_busy_measured_single_launch": derived.get("valu_busy_measured"),
         }
-        per_photon = derived.get("valu_wave_instructions_per_photon")
+        per_photon = pmc_per_photon = derived.get("valu_wave_instructions_per_photon")
         per_trip = derived.get("valu_wave_instructions_per_wave_iteration")
         if per_trip and live:
+            # The PMC passes run one launch at a time (rocprofv3 serialises dispatches), so their launches drain and take more
+            # trips per photon than the overlapped, carried stream timed here; a trip at a few live lanes also issues fewer
+            # instructions than a full one.  Scaled by the trips counted in THIS run the count is therefore a LOWER bound of
+            # this run's, the PMC count itself an upper bound; the roofline fraction uses the lower one.
             per_photon = per_trip * live["wave_iterations_per_photon"]
             side["valu_wave_instructions_per_wave_iteration_pmc"] = per_trip
+            side["valu_wave_instructions_per_photon_pmc"] = pmc_per_photon
             side["valu_wave_instructions_per_photon"] = per_photon
-            side["valu_wave_instructions_per_photon_is"] = "PMC instructions per trip x trips per photon counted in this run"
+            side["valu_wave_instructions_per_photon_is"] = ("PMC instructions per trip x trips per photon counted in this run "
+                                                            "(lower bound; the PMC run's own count is the upper bound)")
         if per_photon:
             # the operative ceiling: VALU issue.  Nominal: one wave64 FP64 instruction per SIMD every 4
             # cycles at 2.4 GHz.  ACHIEVABLE on this part with the kernel's four waves per SIMD: a pure
@@ -242,6 +248,8 @@ def load_pmc(name, value_per_gpu, cus, live=None):
             if os.path.exists(clock):
                 c = json.load(open(clock))
                 side["valu_busy_under_overlap"] = rate * 4.0 / (cus * 4 * c["shader_clock_mhz"] * 1e6)
+                if pmc_per_photon and pmc_per_photon != per_photon:
+                    side["valu_busy_under_overlap_upper"] = pmc_per_photon * value_per_gpu * 4.0 / (cus * 4 * c["shader_clock_mhz"] * 1e6)
                 side["shader_clock_mhz_measured_under_overlap"] = c["shader_clock_mhz"]
                 side["wave_slot_occupancy_measured_under_overlap"] = c["wave_slot_occupancy"]
         return summary.get("hbm_bytes_per_launch"), side

@@ -44,3 +44,34 @@ for lanes in (1, 64):
         pos[:, 2] = np.linspace(-0.9, 0.9, lanes)
     us, base = slope(c, pos, d, wl)
     print(f"cylinder, whispering ray, {lanes:2d} lane(s): {us:.3f} us per step  (2000-step launch {base:.3f} ms)", flush=True)
+# BASELINE configs[3] itself: a photon of nested_cylinders that total internal reflection holds until `maxsteps` ends it
+# (found among 2 10^5 traced with histories: the first whose log fills) -- the history a fenced cfg4 window waits for
+from benchmarks.configs import cfg4_nested_cylinders
+from pvtrace_amd.engine.emit import emit_bundle
+sc = cfg4_nested_cylinders()
+c = compile_scene(sc)
+pos, d, wl, _ = emit_bundle(sc, 200_000, seed=3)
+out = _kernel.trace_bundle(c, pos, d, wl, 5, 600, 2, 0, 1, 0)
+names = list(c.recorder_names)
+t = {}
+res = _kernel.trace_bundle(c, pos, d, wl, 5, 600, 700, 0, 1, 1)
+long_ones = np.flatnonzero(res["counts"] >= 600)
+print(f"cfg4: {len(long_ones)} of 200000 photons are still alive after 600 steps", flush=True)
+if len(long_ones):
+    j = int(long_ones[0])
+    rows = slice(j * 700, j * 700 + 8)
+    print("   its first events:", res["kind"][rows].tolist(), "hit", res["hit"][rows].tolist(), "container", res["container"][rows].tolist())
+    for lanes in (1, 64):
+        pick = long_ones[:lanes] if len(long_ones) >= lanes else np.resize(long_ones, lanes)
+        # every lane the SAME photon (same ray, same seed offset is not possible: the stream is seed + index) -- so lane k
+        # runs ray pick[k] with the stream that trapped it: seed 5 + its index; a bundle of one ray at ray_offset = index
+        if lanes == 1:
+            ts = {}
+            for ms in (2000, 6000):
+                best = 1e9
+                for rep in range(3):
+                    tt = {}
+                    _kernel.trace_bundle(c, pos[j:j + 1], d[j:j + 1], wl[j:j + 1], 5, ms, 4, 0, 1, 0, ray_offset=j, timing=tt)
+                    best = min(best, tt["kernel_ms"])
+                ts[ms] = best
+            print(f"cfg4 trapped photon,  1 lane(s): {(ts[6000] - ts[2000]) / 4000 * 1e3:.3f} us per step  (2000-step launch {ts[2000]:.3f} ms)", flush=True)
