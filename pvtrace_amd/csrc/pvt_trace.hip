@@ -1029,7 +1029,7 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
         {
             const LdsPlan tally = plan_lds(s, false), hist = plan_lds(s, true);
             const size_t other = (tally.bytes > hist.bytes ? tally.bytes : hist.bytes) + (size_t)s->meshq * kBlock * 4;
-            const size_t per_wg = (size_t)39 * 1024 * 4 / PVT_MESH_WAVES;
+            const size_t per_wg = (size_t)39 * 1024 * 4 / kMeshWaves;
             size_t room = tally.ok && hist.ok && other < per_wg ? per_wg - other : 0;
             if (room > 32 * 1024) room = 32 * 1024;
             if (const char* env = getenv("PVT_MESH_TOP_BYTES")) {   // (developer override, never past the room computed above; 0: no copy)

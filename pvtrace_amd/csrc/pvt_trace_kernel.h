@@ -3,19 +3,11 @@
 // and the trace kernel itself.  Included once, by pvt_trace.hip (which holds the design
 // overview, the host-side packing and the C ABI).
 #pragma once
-// Developer-only counters (tools/: -DPVT_STATS=1 builds print per-launch lane statistics; off in the product).
-#ifndef PVT_CARRY_IN
-#define PVT_CARRY_IN 1
-#endif
-#ifndef PVT_CARRY_OUT
-#define PVT_CARRY_OUT 1
-#endif
-#ifndef PVT_MESH_Q
-#define PVT_MESH_Q 8
-#endif
-#ifndef PVT_MESH_WAVES
-#define PVT_MESH_WAVES 4   // waves per SIMD the mesh variants are held to (registers: 512 / waves; LDS per workgroup: 160 KB / waves)
-#endif
+// Developer switches (build-time; everything else that used to be one is a constant now -- the experiments behind them are
+// closed, docs/history.md): PVT_STATS (tools/: -DPVT_STATS=1 builds print per-launch lane statistics), PVT_TIMELINE (per-wave
+// stamps), PVT_COUNTERS / PVT_TAIL_CALL / PVT_TAIL_ALPHA (round 5's A/B switches: profiles/r05_tail_ab.txt), and
+// PVT_DEV_VARIANTS in pvt_trace.hip (fast developer builds of a few variants).
+constexpr int kMeshWaves = 4;   // waves per SIMD the mesh variants are held to (registers: 512 / waves; LDS per workgroup: 160 KB / waves)
 #ifndef PVT_STATS
 #define PVT_STATS 0
 #endif
@@ -27,28 +19,13 @@
 #ifndef PVT_TIMELINE
 #define PVT_TIMELINE 0
 #endif
-#ifndef PVT_WAVE_SCALAR
-#define PVT_WAVE_SCALAR 1
-#endif
-#ifndef PVT_MESH_FULL_LANES
-#define PVT_MESH_FULL_LANES 4   // lanes with full leaf slots that end a walk phase of the mesh walk (1 / 4 / 16 measured: within 3 %)
-#endif
-#ifndef PVT_LOG_STORES
-#define PVT_LOG_STORES 16   // bytes per store of an event record (8: from the value registers; 16: assembled vectors)
-#endif
 
 namespace {
 
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kChunk = 64;           // rays a wave seeds and hands out at a time
-#ifndef PVT_CLAIM_CHUNKS
-#define PVT_CLAIM_CHUNKS 1
-#endif
-#ifndef PVT_END_CLAIM
-#define PVT_END_CLAIM 64
-#endif
-constexpr int kEndClaim = PVT_END_CLAIM;   // rays per claim in the last two rounds of a launch (see the refill)
-constexpr int kClaim = kChunk * PVT_CLAIM_CHUNKS;   // rays a wave claims per cursor atomic: every wave of a launch adds to the SAME
+constexpr int kEndClaim = 64;   // rays per claim in the last two rounds of a launch (see the refill)
+constexpr int kClaim = kChunk;   // rays a wave claims per cursor atomic: every wave of a launch adds to the SAME
                                      // word, and a device-scope atomic that returns a value costs the wave a round trip
                                      // through the fabric; claiming several chunks at once takes the cursor off the critical
                                      // path -- measured (round 3): 1, 2 and 4 chunks per claim give the same throughput at
@@ -215,7 +192,7 @@ struct KArgs {
     // atomics per workgroup.  null = off.
     unsigned long long* counters;
 };
-constexpr int kMeshQ = PVT_MESH_Q;    // leaves a lane notes before its triangles are tested
+constexpr int kMeshQ = 8;    // leaves a lane notes before its triangles are tested
 constexpr int kCarryBase = 14;     // u64 words of a parked photon before its seen-mask
 constexpr int kCarryStride = 18;   // words per parked photon (room for the four-word mask of scenes with > 64 recorders)
 
@@ -555,9 +532,6 @@ __device__ __forceinline__ void emit_one(const KArgs& A, unsigned long long gi, 
 // The sampler as a FUNCTION (trace kernels, device emission): called by the wave that claims a chunk of rays, once per 64
 // rays -- its 15 KB of code then sit beside the trace kernel's text instead of inside it (every EMIT variant as large
 // as its array-input twin plus a call), at the price of the caller's live registers going through scratch around the call.
-#ifndef PVT_EMIT_CALL
-#define PVT_EMIT_CALL 1
-#endif
 __device__ __attribute__((noinline)) void emit_chunk(const KArgs* A, unsigned long long gi, double* pool) {
     V3 ep, ed;
     double ew;
@@ -642,20 +616,6 @@ __device__ __forceinline__ void log_row(const KArgs& A, int rec_slot, int& nev, 
             VIA_A ? (const __attribute__((address_space(4))) KArgs*)(unsigned long long)&A
                   : (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ak));
-#if PVT_LOG_STORES == 8
-        // eight-byte stores straight from the registers the values live in (no 16-byte vectors to assemble: the
-        // history variants sit at the register limit, and every spilled register is HBM write traffic of its own)
-        unsigned long long* dst = ak->log_rows + row * kRecWords;
-        const V3 n = has_normal ? nrm : V3{0.0, 0.0, 0.0};
-        dst[0] = (unsigned long long)(unsigned int)hit | ((unsigned long long)(unsigned int)container << 32);
-        dst[1] = (unsigned long long)(unsigned int)adjacent | ((unsigned long long)(unsigned int)component << 32);
-        dst[2] = (unsigned long long)(unsigned int)source | ((unsigned long long)(unsigned int)kind << 32);
-        dst[3] = pvt_d2u(pos.x); dst[4] = pvt_d2u(pos.y); dst[5] = pvt_d2u(pos.z);
-        dst[6] = pvt_d2u(dir.x); dst[7] = pvt_d2u(dir.y); dst[8] = pvt_d2u(dir.z);
-        dst[9] = pvt_d2u(n.x); dst[10] = pvt_d2u(n.y); dst[11] = pvt_d2u(n.z);
-        dst[12] = pvt_d2u(wl); dst[13] = pvt_d2u(travelled); dst[14] = pvt_d2u(duration);
-        dst[15] = (unsigned long long)row;
-#else
         u32x4* dst = reinterpret_cast<u32x4*>(ak->log_rows + row * kRecWords);
         const unsigned long long p0 = pvt_d2u(pos.x);
         const V3 n = has_normal ? nrm : V3{0.0, 0.0, 0.0};
@@ -667,7 +627,6 @@ __device__ __forceinline__ void log_row(const KArgs& A, int rec_slot, int& nev, 
         dst[5] = pack_dd(n.y, n.z);
         dst[6] = pack_dd(wl, travelled);
         dst[7] = pack_dd(duration, pvt_u2d((unsigned long long)row));
-#endif
         nev += 1;
     }
 }
@@ -960,7 +919,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
     const unsigned int wgs_in_set = A.set_size ? (unsigned int)A.wgs_per_set : gridDim.x;
     const unsigned int waves_in_set = wgs_in_set * kWaves;
     const unsigned int wave_in_set = (blockIdx.x - set * (A.set_size ? (unsigned int)A.wgs_per_set : 0u)) * kWaves +
-                                     (PVT_WAVE_SCALAR ? (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (threadIdx.x >> 6));
+                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned int w_first = wave_in_set * (unsigned int)kClaim;
     unsigned int w_next = w_first, w_end = w_first, w_base = 0;
     unsigned int w_claim_end = w_first < n_local ? (n_local - w_first < (unsigned int)kClaim ? n_local : w_first + kClaim) : w_first;
@@ -1064,7 +1023,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             // beyond is claimed through the claim cursor, one atomic per 64.  (A claim per refill, for just the lanes
             // that died in the last step, put a queue of ~10^5 same-address atomics in front of every step: measured
             // 21 us per iteration instead of 11.)
-            if (PVT_CARRY_IN && (ws & WS_CARRY_IN) && need != 0ull) {
+            if ((ws & WS_CARRY_IN) && need != 0ull) {
                 const __attribute__((address_space(4))) KArgs* ak =
                     (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(ak));
@@ -1116,7 +1075,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                                                  // 4096 waves starting together on ONE word cost the launch ~50 us)
                     // (Smaller claims towards the end of the rays -- a wave that takes the last 64 rays runs some six
                     // iterations longer than its neighbours, which found the cursor dry -- were measured and NOT kept:
-                    // with PVT_END_CLAIM 32 / 16 in the last two rounds the pipelined bench lost 4 % / 13 %, the extra
+                    // with claims of 32 / 16 rays in the last two rounds the pipelined bench lost 4 % / 13 %, the extra
                     // same-address atomics cost more than the ragged end.  Between two claims of a wave every other
                     // wave claims about once, so the cursor stands near w_claim_end + waves x 64 now.)
                     const unsigned int claim = (n_local - w_claim_end > 2u * waves_in_set * (unsigned int)kClaim || w_claim_end > n_local)
@@ -1142,16 +1101,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                     if (b + lane_here < w_end) {
                         double* pool = ak->emit_pool + ((unsigned long long)blockIdx.x * kWaves + (unsigned long long)wave) * (7 * 64) + lane_here;
                         const unsigned long long gi_ = A.ray_offset + (unsigned long long)ray_lo + (unsigned long long)b + (unsigned long long)lane_here;
-#if PVT_EMIT_CALL
                         emit_chunk((const KArgs*)ak, gi_, pool);
-#else
-                        V3 ep, ed;
-                        double ew;
-                        emit_one(A, gi_, ep, ed, ew);
-                        pool[0] = ep.x; pool[64] = ep.y; pool[128] = ep.z;
-                        pool[192] = ed.x; pool[256] = ed.y; pool[320] = ed.z;
-                        pool[384] = ew;
-#endif
                     }
                 }
                 if (seed_pool) {
@@ -1233,7 +1183,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
         // emptied waves retire.  Which lane carries a photon never affects its history (RNG
         // stream, seen-mask and log rows travel with it), so results stay bit-identical.
         if constexpr (!RECORD) {
-            if (PVT_CARRY_OUT && (ws & WS_EXHAUSTED) && (A.carry_flags & 2)) {
+            if ((ws & WS_EXHAUSTED) && (A.carry_flags & 2)) {
                 // no rays left for this wave: its live photons are parked for the next launch on the stream
                 const unsigned long long live_mask = __ballot(alive);
                 if (live_mask != 0ull) {
@@ -1814,7 +1764,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                         // ---- walk: every lane goes on until its walk is over or its slots are full
                         for (;;) {
                             const bool go = i != end && qn < qcap;
-                            if (__ballot(go) == 0ull || __popcll(__ballot(i != end && qn >= qcap)) >= PVT_MESH_FULL_LANES) break;
+                            if (__ballot(go) == 0ull || __popcll(__ballot(i != end && qn >= qcap)) >= 4) break;   // (lanes with full leaf slots that end a walk phase: 1 / 4 / 16 measured within 3 %)
 #if PVT_STATS
                             if (MESH) { st_g[0] += 1; st_g[1] += __popcll(__ballot(go)); }
 #endif
@@ -2630,21 +2580,15 @@ __device__ __attribute__((noinline)) void tail_run(const KArgs* kernel_args, int
 // touch), and the fourth wave is worth more than that costs -- the walk is a chain of dependent loads: +8 ... +19 % in
 // the pipelined stream, 3.1 -> 2.7 ms for a single 10^6-photon launch on the 327 680-face ball (five waves: worse).
 template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_MESH_WAVES, PVT_MESH_WAVES))) trace_kernel(KArgs A) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMeshWaves, kMeshWaves))) trace_kernel(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, MESH>(A);
 }
-#ifndef PVT_W4_WAVES
-#define PVT_W4_WAVES 4   // (developer builds: other occupancies of the analytic variants)
-#endif
 template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_W4_WAVES, PVT_W4_WAVES))) trace_kernel_w4(KArgs A) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_w4(KArgs A) {
     trace_body<RECORD, TAB_LDS, SEENW, EMIT, false>(A);
 }
-#ifndef PVT_GRID_WAVES
-#define PVT_GRID_WAVES 4
-#endif
 template <bool RECORD, int SEENW, bool EMIT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PVT_GRID_WAVES, PVT_GRID_WAVES))) trace_kernel_grid(KArgs A) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) trace_kernel_grid(KArgs A) {
     trace_body<RECORD, 1, SEENW, EMIT, false, true>(A);
 }
 
