@@ -713,11 +713,73 @@ struct Seen {
 #ifndef PVT_TAIL_CALL
 #define PVT_TAIL_CALL 1
 #endif
+#ifndef PVT_TAIL_HOIST
+#define PVT_TAIL_HOIST 1   // (0: a developer build whose tail function reads the hit node's record where the kernels' loop does)
+#endif
 #ifndef PVT_TAIL_ALPHA
 #define PVT_TAIL_ALPHA 1   // (0: a developer build whose tail function looks the absorption coefficients up in every step)
 #endif
 template <bool RECORD, int TAB_LDS, int SEENW, bool MESH, bool GRID>
 __device__ void tail_run(const KArgs* kernel_args, int total);
+
+// A wave leaves its workgroup: the LAST one to do so adds the workgroup's accumulators (LDS) to the launch's outputs -- one
+// global atomic per non-zero slot -- and its step counters to the scene's.  (No closing barrier: retiring waves must never
+// be counted by the drain-phase rendezvous barriers of the waves still running.)  A function of its own, given nothing but
+// the kernel's argument pointer (made a scalar and a pointer to constant memory again, as in tail_run): where the
+// accumulators lie in LDS is worked out here, from the same quantities trace_body lays them out by.
+template <int TAB_LDS>
+__device__ __attribute__((noinline)) void leave_workgroup(const KArgs* kernel_args) {
+    extern __shared__ double smem[];
+    const unsigned long long bits = (unsigned long long)kernel_args;
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)bits), hi = __builtin_amdgcn_readfirstlane((unsigned int)(bits >> 32));
+    const __attribute__((address_space(4))) KArgs* ak = (const __attribute__((address_space(4))) KArgs*)(((unsigned long long)hi << 32) | lo);
+    const KArgs& A = *(const KArgs*)ak;
+    const int lane = threadIdx.x & 63;
+    // (the layout of trace_body: tables | sums | crossings | distinct | bins | control words)
+    const int nd_lds = TAB_LDS == 1 ? A.nd : TAB_LDS == 2 ? A.nd_lds : 0;
+    const int ni_stage = TAB_LDS == 1 ? A.ni : TAB_LDS == 2 ? A.ni_lds : 0;
+    const int ni_lds = (ni_stage + 1) & ~1;
+    int* lds_i = reinterpret_cast<int*>(smem + nd_lds);
+    double* acc_sums = reinterpret_cast<double*>(lds_i + ni_lds);
+    unsigned long long* acc_cross = reinterpret_cast<unsigned long long*>(acc_sums + A.n_rec * 8);
+    unsigned int* acc_distinct = reinterpret_cast<unsigned int*>(acc_cross + A.n_rec);
+    unsigned int* acc_bins = acc_distinct + ((A.n_rec + 1) & ~1);
+    int* ctl = reinterpret_cast<int*>(acc_bins + ((A.bins_in_lds ? A.total_bins : 0) + 1 & ~1));
+    const unsigned int set = A.set_size ? blockIdx.x / (unsigned int)A.wgs_per_set : 0u;
+    __threadfence_block();
+    int order = 0;
+    if (lane == 0) order = atomicAdd(&ctl[CTL_DONE], 1);
+    order = __builtin_amdgcn_readfirstlane(order);
+    if (order != kWaves - 1) return;
+    __threadfence_block();
+    {
+        unsigned long long* ctr = A.counters;
+        if (ctr && lane < 4) {
+            const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(ctl + CTL_COUNT);
+            const unsigned long long v = lane == 3 ? (unsigned long long)kWaves : cnt[lane];
+            if (v) atomicAdd(ctr + (blockIdx.x & 63u) * 4u + lane, v);
+        }
+    }
+    unsigned long long* const out_distinct = reinterpret_cast<unsigned long long*>(A.rec_distinct) + (long long)set * A.set_stride_i;
+    unsigned long long* const out_crossings = reinterpret_cast<unsigned long long*>(A.rec_crossings) + (long long)set * A.set_stride_i;
+    unsigned long long* const out_bins = reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i;
+    double* const out_sums = A.rec_sums + (long long)set * A.set_stride_d;
+    for (int i = lane; i < A.n_rec; i += 64) {
+        const unsigned long long c = acc_cross[i];
+        const unsigned int d = acc_distinct[i];
+        if (c) atomicAdd(out_crossings + i, c);
+        if (d) atomicAdd(out_distinct + i, (unsigned long long)d);
+    }
+    for (int i = lane; i < A.n_rec * 8; i += 64) {
+        double v = acc_sums[i];
+        if (v != 0.0) atomicAdd(out_sums + i, v);
+    }
+    if (A.bins_in_lds)
+        for (int i = lane; i < A.total_bins; i += 64) {
+            unsigned int v = acc_bins[i];
+            if (v) atomicAdd(out_bins + i, (unsigned long long)v);
+        }
+}
 
 template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH, bool GRID = false, bool TAIL = false>
 __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
@@ -897,6 +959,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
     int ac_node = -1;
     unsigned long long ac_wl = 0ull;
     double ac_alpha = 0.0, ac_pre0 = 0.0;
+    // (tail function) the record of the node this step's nearest crossing lies on, and the Fresnel constants of the pair
+    // (container, adjacent), read in one go right after the node loop
+    V3 hr_t{0, 0, 0}, hr_g{0, 0, 0};
+    unsigned long long hr_bits = 0ull;
+    int hr_surf = 0;
+    double hr_n2 = 0.0, hr_rn2 = 0.0, hr_cc = 0.0;
+    constexpr bool kHoist = TAIL && PVT_TAIL_HOIST;
     int rec_slot = -1;   // recorded rays: index among them (row block rec_slot * max_events), else -1
     Seen<SEENW> seen;
 #pragma unroll
@@ -1976,6 +2045,24 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             cbase = T.iv(container * NI + NI_CSTART); ccount = T.iv(container * NI + NI_CCOUNT);
             if (uf(UF_BY_NODE)) crec = cbase;   // (scenes of few nodes keep one record per component id)
             else crec = T.iv(container * NI + NI_CREC);
+            // (tail function: a wave alone on its SIMD waits out every LDS round trip in full, and the records the rest of the
+            // step needs -- the hit node's, the far side's refractive index, the pair's Fresnel constants -- are all
+            // addressed by what the node loop has just found: read together HERE they cost one wait instead of five spread
+            // over the step; the same words, so the same bits)
+            if constexpr (TAIL && PVT_TAIL_HOIST) {
+                const int hn = hit * ND;
+                hr_t = V3{T.dv(hn + ND_T), T.dv(hn + ND_T + 1), T.dv(hn + ND_T + 2)};
+                hr_g = V3{T.dv(hn + ND_PARAMS), T.dv(hn + ND_PARAMS + 1), T.dv(hn + ND_PARAMS + 2)};
+                hr_bits = pvt_d2u(T.dv(hn + ND_BITS));
+                hr_surf = T.iv(hit * NI + NI_SURF);
+                if (adjacent >= 0) {
+                    int kc = container, ka = adjacent;
+                    if (!uf(UF_BY_NODE)) { kc = T.iv(container * NI + NI_NCLS); ka = T.iv(adjacent * NI + NI_NCLS); }
+                    hr_n2 = T.dv(adjacent * ND + ND_N);
+                    hr_rn2 = T.dv(L.ncls_d + ka * 2 + 1);
+                    hr_cc = uf(UF_CRIT) ? T.dv(L.ccrit_d + kc * L.n_cls + ka) : __builtin_nan("");
+                }
+            }
             // (tail function: a photon that bounces inside one body keeps its wavelength, and with it the coefficients of
             // the step before -- the same table values, read once instead of once per bounce; not in the kernels' own loop,
             // where the seven registers cost more than the lookups: docs/history.md, round 4)
@@ -2144,6 +2231,15 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
         // x,y,z histogram axes RECOMPUTE them where needed (same arithmetic, same bits) instead of
         // keeping 12 VGPRs alive across the transcendental sites, the register-pressure peak.
         auto local_point = [&]() -> V3 {
+            if constexpr (kHoist) {
+                if (t_normal) {   // (an event with a normal refers to the node that was hit: its record is in registers)
+                    if (node_ident(hr_bits)) return V3{pos.x + hr_t.x, pos.y + hr_t.y, pos.z + hr_t.z};
+                    const int m = node_rot(hr_bits) + RT_W2L;
+                    return V3{T.dv(m + 0) * pos.x + T.dv(m + 1) * pos.y + T.dv(m + 2) * pos.z + hr_t.x,
+                              T.dv(m + 3) * pos.x + T.dv(m + 4) * pos.y + T.dv(m + 5) * pos.z + hr_t.y,
+                              T.dv(m + 6) * pos.x + T.dv(m + 7) * pos.y + T.dv(m + 8) * pos.z + hr_t.z};
+                }
+            }
             const int tr = t_node * ND + ND_T;
             const unsigned long long tb = node_bits(t_node);
             if (node_ident(tb))   // unrotated node: translate only
@@ -2155,7 +2251,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
         };
         auto local_normal = [&](const V3& lp) -> V3 {   // outward normal (_kernel.pyx:359-400)
             const int gp = t_node * ND + ND_PARAMS;
-            const int gt = node_geom(node_bits(t_node));
+            // (every caller stands at a surface event: the node is the one that was hit -- tail function: its record is in registers)
+            const int gt = kHoist ? node_geom(hr_bits) : node_geom(node_bits(t_node));
+            auto param = [&](int a) -> double {
+                if constexpr (kHoist) return a == 0 ? hr_g.x : (a == 1 ? hr_g.y : hr_g.z);
+                return T.dv(gp + a);
+            };
             if (MESH && gt == PVT_GEOM_MESH) {   // face normal of the crossed triangle (geometry/mesh.py:63-86)
                 const pvt::MeshTri* tr = A.tris + tri1;
                 return V3{tr->n[0], tr->n[1], tr->n[2]};
@@ -2165,7 +2266,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                 // winning only when strictly nearer (_kernel.pyx:359-377).  Per axis that is the smaller of
                 // |p + h| and |p - h| (the + face only when strictly smaller), and across axes the first
                 // smallest: the same six distances and the same comparisons, without the running triple.
-                const double hx = 0.5 * T.dv(gp), hy = 0.5 * T.dv(gp + 1), hz = 0.5 * T.dv(gp + 2);
+                const double hx = 0.5 * param(0), hy = 0.5 * param(1), hz = 0.5 * param(2);
                 const double mx = pvt_fabs(lp.x - (-1.0) * hx), px = pvt_fabs(lp.x - hx);
                 const double my = pvt_fabs(lp.y - (-1.0) * hy), py = pvt_fabs(lp.y - hy);
                 const double mz = pvt_fabs(lp.z - (-1.0) * hz), pz = pvt_fabs(lp.z - hz);
@@ -2180,7 +2281,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                 double mag = pvt_sqrt(dot3(lp, lp));
                 return V3{lp.x / mag, lp.y / mag, lp.z / mag};
             }
-            double half = 0.5 * T.dv(gp);
+            double half = 0.5 * param(0);
             double tol = 1e-8 + 1e-5 * pvt_fabs(half);
             if (pvt_fabs(lp.z + half) <= tol) return V3{0.0, 0.0, -1.0};
             if (pvt_fabs(lp.z - half) <= tol) return V3{0.0, 0.0, 1.0};
@@ -2189,7 +2290,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
         };
         if (alive && t_normal) {
             const V3 nloc = local_normal(local_point());
-            const unsigned long long tb = node_bits(t_node);
+            const unsigned long long tb = kHoist ? hr_bits : node_bits(t_node);
             if (node_ident(tb)) {
                 nrm = nloc;
             } else {
@@ -2223,7 +2324,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             }
         }
         if (alive && t_normal) t_cos = ac_arg;
-        const bool fres = surf && T.iv(ev_hit * NI + NI_SURF) == PVT_SURF_FRESNEL;
+        const bool fres = surf && (kHoist ? hr_surf : T.iv(ev_hit * NI + NI_SURF)) == PVT_SURF_FRESNEL;
         const double c1 = ac_arg, s1 = fres ? sqrt1m2_normal(ac_arg) : 0.0;   // cos / sin of the incidence angle
 
         PVT_MARK(4);  // cosines of the incidence / exit angle
@@ -2232,23 +2333,28 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             const int hit = ev_hit, container = ev_container, adjacent = ev_adjacent;
             double r = 0.0, n1 = 0.0, n2 = 0.0, rn2 = 0.0;
             if (fres) {  // unpolarised Fresnel, 1.0 beyond the critical angle (:406-419)
-                n1 = T.dv(container * ND + ND_N);
-                n2 = T.dv(adjacent * ND + ND_N);
+                // (tail function: the container's index was read for the clock, the far side's and the pair's constants with
+                // the hit node's record -- all right after the node loop)
+                n1 = kHoist ? n_container : T.dv(container * ND + ND_N);
+                n2 = kHoist ? hr_n2 : T.dv(adjacent * ND + ND_N);
                 // what depends on the refractive indices alone is tabulated per pair of index CLASSES
                 int kc = container, ka = adjacent;
-                if (!uf(UF_BY_NODE)) { kc = T.iv(container * NI + NI_NCLS); ka = T.iv(adjacent * NI + NI_NCLS); }
+                if (!kHoist && !uf(UF_BY_NODE)) { kc = T.iv(container * NI + NI_NCLS); ka = T.iv(adjacent * NI + NI_NCLS); }
                 const int ncls_d = L.ncls_d, n_cls = L.n_cls;
-                rn2 = T.dv(ncls_d + ka * 2 + 1);
+                rn2 = kHoist ? hr_rn2 : T.dv(ncls_d + ka * 2 + 1);
                 // critical angle asin(n2/n1): a function of the node pair, tabulated by the host
                 // with the same pvt_asin (small scenes), else computed here
                 bool tir;
                 // (the reference compares acos(c1) with the critical angle; the host has turned that into a
                 // comparison of c1 itself wherever it could prove the two agree for every double)
                 const bool crit_tab = uf(UF_CRIT);
-                const double cc = crit_tab ? T.dv(L.ccrit_d + kc * n_cls + ka) : __builtin_nan("");
+                const double cc = kHoist ? hr_cc : (crit_tab ? T.dv(L.ccrit_d + kc * n_cls + ka) : __builtin_nan(""));
                 if (cc == cc) tir = c1 < cc;
-                else if (crit_tab) tir = pvt_acos(c1) > T.dv(L.crit_d + kc * n_cls + ka);
-                else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(ncls_d + kc * 2 + 1)));
+                else {   // (rare: the threshold could not be proven, or the scene has too many indices for the tables)
+                    if (kHoist && !uf(UF_BY_NODE)) { kc = T.iv(container * NI + NI_NCLS); ka = T.iv(adjacent * NI + NI_NCLS); }
+                    if (crit_tab) tir = pvt_acos(c1) > T.dv(L.crit_d + kc * n_cls + ka);
+                    else tir = n2 < n1 && pvt_acos(c1) > pvt_asin(div_known(n2, n1, T.dv(ncls_d + kc * 2 + 1)));
+                }
                 if (tir) {
                     r = 1.0;
                 } else {
@@ -2271,7 +2377,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                 V3 lpos{0, 0, 0}, nloc = nrm;
                 if (cs < ce) {
                     lpos = local_point();
-                    if (!node_ident(node_bits(hit))) nloc = local_normal(lpos);
+                    if (!node_ident(kHoist ? hr_bits : node_bits(hit))) nloc = local_normal(lpos);
                 }
                 const double nl3[3] = {nloc.x, nloc.y, nloc.z}, pl3[3] = {lpos.x, lpos.y, lpos.z};
                 for (int c = cs; c < ce && coat < 0; c++) {
@@ -2352,7 +2458,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                 (ev_kind == PVT_EV_REFLECT ? container == A.root : adjacent == A.root)) {
                 const V3 lp = local_point();
                 const int gp = hit * ND + ND_PARAMS;
-                const double h = 0.5 * (pvt_fabs(nrm.x) * T.dv(gp) + pvt_fabs(nrm.y) * T.dv(gp + 1) + pvt_fabs(nrm.z) * T.dv(gp + 2));
+                const double h = kHoist ? 0.5 * (pvt_fabs(nrm.x) * hr_g.x + pvt_fabs(nrm.y) * hr_g.y + pvt_fabs(nrm.z) * hr_g.z)
+                                        : 0.5 * (pvt_fabs(nrm.x) * T.dv(gp) + pvt_fabs(nrm.y) * T.dv(gp + 1) + pvt_fabs(nrm.z) * T.dv(gp + 2));
                 const double g = h - dot3(nrm, lp), dn = dot3(nrm, dir);
                 if (dn > 0.0 && g <= (0.5 * kEps) * dn) {
                     terminal = true;
@@ -2502,59 +2609,28 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
     }
 #endif
     tally_flush();   // the first crossings still parked
-    if constexpr (kTailCall) {
-        if (tail_n > 0) {
-            const __attribute__((address_space(4))) KArgs* ak =
-                (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-            tail_run<RECORD, TAB_LDS, SEENW, MESH, GRID>((const KArgs*)ak, tail_n);
-        }
-    }
     {   // this wave's share of the step counters, into the workgroup's sums
         unsigned long long* const cnt = reinterpret_cast<unsigned long long*>(ctl + CTL_COUNT);
         if (lane == 0) atomicAdd(cnt, (unsigned long long)c_iters);
         atomicAdd(cnt + 1, (unsigned long long)c_steps);
         atomicAdd(cnt + 2, (unsigned long long)c_fused);
     }
-    if constexpr (TAIL) return;   // (the caller leaves through the code below)
-    // ---- flush workgroup accumulators: done by the LAST wave to leave -------
-    // (no closing barrier: retiring waves must never be counted by the drain-phase
-    // rendezvous barriers of the waves still running)
-    __threadfence_block();
-    int order = 0;
-    if (lane == 0) order = atomicAdd(&ctl[CTL_DONE], 1);
-    order = __builtin_amdgcn_readfirstlane(order);
-    if (order != kWaves - 1) return;
-    __threadfence_block();
+    if constexpr (TAIL) return;   // (the caller leaves the workgroup)
+    // The rest of its photons' histories, when this wave was the last of a draining workgroup (see the drain), then the
+    // workgroup's epilogue -- both as FUNCTIONS, called here at the very end: nothing of the loop above is live across either
+    // call, so the loop's register allocation does not know of them (a value that were live across a call would be spilled
+    // where it is defined and reloaded where it is used, the loop included), and what the epilogue needs -- the
+    // accumulators' places in LDS, the tally set, the output pointers -- is worked out inside it instead of being held
+    // (or spilled) for the kernel's whole life.
     {
         const __attribute__((address_space(4))) KArgs* ak =
             (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ak));
-        unsigned long long* ctr = ak->counters;
-        if (ctr && lane < 4) {
-            const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(ctl + CTL_COUNT);
-            const unsigned long long v = lane == 3 ? (unsigned long long)kWaves : cnt[lane];
-            if (v) atomicAdd(ctr + (blockIdx.x & 63u) * 4u + lane, v);
+        if constexpr (kTailCall) {
+            if (tail_n > 0) tail_run<RECORD, TAB_LDS, SEENW, MESH, GRID>((const KArgs*)ak, tail_n);
         }
+        leave_workgroup<TAB_LDS>((const KArgs*)ak);
     }
-    unsigned long long* const out_distinct = reinterpret_cast<unsigned long long*>(A.rec_distinct) + (long long)set * A.set_stride_i;
-    unsigned long long* const out_crossings = reinterpret_cast<unsigned long long*>(A.rec_crossings) + (long long)set * A.set_stride_i;
-    unsigned long long* const out_bins = reinterpret_cast<unsigned long long*>(A.rec_bins) + (long long)set * A.set_stride_i;
-    double* const out_sums = A.rec_sums + (long long)set * A.set_stride_d;
-    for (int i = lane; i < A.n_rec; i += 64) {
-        const unsigned long long c = acc_cross[i];
-        const unsigned int d = acc_distinct[i];
-        if (c) atomicAdd(out_crossings + i, c);
-        if (d) atomicAdd(out_distinct + i, (unsigned long long)d);
-    }
-    for (int i = lane; i < A.n_rec * 8; i += 64) {
-        double v = acc_sums[i];
-        if (v != 0.0) atomicAdd(out_sums + i, v);
-    }
-    if (A.bins_in_lds)
-        for (int i = lane; i < A.total_bins; i += 64) {
-            unsigned int v = acc_bins[i];
-            if (v) atomicAdd(out_bins + i, (unsigned long long)v);
-        }
+
 }
 
 // The last wave of a draining workgroup finishes its photons here (see the drain in trace_body): the step loop alone, as a
