@@ -720,7 +720,7 @@ struct Seen {
 #define PVT_TAIL_ALPHA 1   // (0: a developer build whose tail function looks the absorption coefficients up in every step)
 #endif
 template <bool RECORD, int TAB_LDS, int SEENW, bool MESH, bool GRID>
-__device__ void tail_run(const KArgs* kernel_args, int total);
+__device__ void tail_run(const KArgs* kernel_args, int total, unsigned int lds);
 
 // A wave leaves its workgroup: the LAST one to do so adds the workgroup's accumulators (LDS) to the launch's outputs -- one
 // global atomic per non-zero slot -- and its step counters to the scene's.  (No closing barrier: retiring waves must never
@@ -782,14 +782,32 @@ __device__ __attribute__((noinline)) void leave_workgroup(const KArgs* kernel_ar
 }
 
 template <bool RECORD, int TAB_LDS, int SEENW, bool EMIT, bool MESH, bool GRID = false, bool TAIL = false>
-__device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
-    extern __shared__ double smem[];
+__device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, unsigned int tail_lds = 0u) {
+    extern __shared__ double smem_of_kernel[];
+    // (In a called function the address of the kernel's dynamic LDS is looked up in a table in memory wherever it is used --
+    // six scalar loads and waits per step of the tail function, measured in its ISA; the kernel hands it over instead.)
+    double* const smem = TAIL ? (double*)(__attribute__((address_space(3))) double*)(unsigned long long)tail_lds
+                              : (double*)smem_of_kernel;
+    // A wave alone waits out every scalar-cache round trip too: what the loop asks of the kernel's arguments time and again
+    // is held in registers by the tail function (the kernels' own loop re-reads them where it needs them: a scalar load
+    // costs it nothing, a register does).
+    auto held = [](int v) __attribute__((always_inline)) -> int {
+        if constexpr (TAIL) asm volatile("" : "+s"(v));
+        return v;
+    };
+    const int k_root = held(A.root), k_maxsteps = held(A.maxsteps), k_nodes = held(A.n_nodes);
 #if PVT_TIMELINE
     unsigned long long tl_t[6] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0, 0};
     unsigned long long tl_iters = 0;
     const unsigned long long tl_c0 = __builtin_readcyclecounter();   // shader clock (s_memtime); wall_clock64 is the constant 100 MHz one
 #endif
-    const Lay L = A.lay;
+    Lay L = A.lay;
+    if constexpr (TAIL) {   // (every field the step reads, resident)
+        L.comp_d = held(L.comp_d); L.rec_d = held(L.rec_d); L.hist_d = held(L.hist_d); L.coat_d = held(L.coat_d);
+        L.comp_i = held(L.comp_i); L.rec_i = held(L.rec_i); L.hist_i = held(L.hist_i); L.coat_i = held(L.coat_i);
+        L.cand_i = held(L.cand_i); L.cand_list = held(L.cand_list); L.crit_d = held(L.crit_d); L.ccrit_d = held(L.ccrit_d);
+        L.grid_d = held(L.grid_d); L.rot_d = held(L.rot_d); L.ncls_d = held(L.ncls_d); L.n_cls = held(L.n_cls);
+    }
     // Launch constants that the loop only asks yes/no questions of, in ONE scalar register.  Kept as separate
     // conditions each becomes a 64-bit lane mask that the allocator holds (spills) for the whole loop; `uf(bit)`
     // re-derives the answer from the word where it is asked (the empty asm keeps the compiler from hoisting it).
@@ -956,9 +974,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
     int count = 0, source = -1, nev = 0;
     unsigned int c_iters = 0u, c_steps = 0u, c_fused = 0u;   // this lane's share of the step counters (KArgs::counters)
     // (tail function) the absorption coefficients this lane's photon met last: container, wavelength bits, sum, first term
+    // -- kept in LDS, in the exchange buffer the function was handed its photons through (free once they are read): four
+    // words per lane, read together (one wait) where two table lookups stood; in registers they were seven more than the
+    // function has (the hit node's record, below, went to scratch for them: PVT_TAIL_ALPHA 2 keeps that variant)
     int ac_node = -1;
     unsigned long long ac_wl = 0ull;
     double ac_alpha = 0.0, ac_pre0 = 0.0;
+    unsigned long long* const ac_lds = xbuf + lane;   // [4][64] words: container, wavelength bits, sum, first term
     // (tail function) the record of the node this step's nearest crossing lies on, and the Fresnel constants of the pair
     // (container, adjacent), read in one go right after the node loop
     V3 hr_t{0, 0, 0}, hr_g{0, 0, 0};
@@ -1078,6 +1100,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             }
         }
     }
+    if constexpr (TAIL && PVT_TAIL_ALPHA == 1) ac_lds[0] = ~0ull;   // (nothing known yet; after the reads above, same wave: in order)
     for (;;) {
         if constexpr (TAIL) {
             if (__ballot(alive) == 0ull) break;
@@ -1571,7 +1594,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                             il0 = rcp_normal(dl.x); il1 = rcp_normal(dl.y); il2 = rcp_normal(dl.z);
                         }
                         bool root_known = false;
-                        if (lazy_root && node == A.root) {   // (see the plain node loop: same bound, same conditions)
+                        if (lazy_root && node == k_root) {   // (see the plain node loop: same bound, same conditions)
                             double bound;
                             if (lazy_root == 1) {
                                 bound = __builtin_fmin(__builtin_fmin(0.5 * g0 - pvt_fabs(o.x), 0.5 * g1 - pvt_fabs(o.y)), 0.5 * g2 - pvt_fabs(o.z));
@@ -1641,7 +1664,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                             }
                         }
                         bool test = false;
-                        int node = A.root;
+                        int node = k_root;
                         if (m_lo != 0ull) { node = __builtin_ctzll(m_lo); seen_lo |= m_lo & (0ull - m_lo); test = true; }
                         else if (m_hi != 0ull) { node = 64 + __builtin_ctzll(m_hi); seen_hi |= m_hi & (0ull - m_hi); test = true; }
                         else if (!walk && root_todo) { root_todo = false; test = true; }
@@ -1652,8 +1675,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                     }
                 }
                 // (grid scenes have visited every node they need by now)
-                for (int k = 0; k < (GRID ? 0 : A.n_nodes); k++) {
-                    const int node = !lazy_root ? k : (k == A.n_nodes - 1 ? A.root : (k < A.root ? k : k + 1));
+                for (int k = 0; k < (GRID ? 0 : k_nodes); k++) {
+                    const int node = !lazy_root ? k : (k == k_nodes - 1 ? k_root : (k < k_root ? k : k + 1));
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
                     // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,
                     // quotient or stored value below can see.
@@ -1694,7 +1717,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                 int nl = 0;
                 double tfirst = 0.0;
                 bool root_known = false;   // this lane's root crossing is accounted for without its distance
-                if (lazy_root && node == A.root) {
+                if (lazy_root && node == k_root) {
                     double bound;   // <= distance to the root's surface along any direction
                     if (lazy_root == 1) {
                         const double mx = 0.5 * gpar[0] - pvt_fabs(o.x), my = 0.5 * gpar[1] - pvt_fabs(o.y),
@@ -2023,7 +2046,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                         }
                     }
                     ev_container = container;
-                    if (count > A.maxsteps) {  // (:716-723)
+                    if (count > k_maxsteps) {  // (:716-723)
                         ev_kind = PVT_EV_KILL;
                         terminal = true;
                         t_sel = PVT_REC_KILLED; t_node = container;
@@ -2067,8 +2090,12 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             // the step before -- the same table values, read once instead of once per bounce; not in the kernels' own loop,
             // where the seven registers cost more than the lookups: docs/history.md, round 4)
             bool known = false;
+            if constexpr (TAIL && PVT_TAIL_ALPHA == 1) {
+                ac_node = (int)(unsigned int)ac_lds[0]; ac_wl = ac_lds[64];
+                ac_alpha = pvt_u2d(ac_lds[128]); ac_pre0 = pvt_u2d(ac_lds[192]);
+            }
             if constexpr (TAIL && PVT_TAIL_ALPHA) known = container == ac_node && pvt_d2u(wl) == ac_wl;
-            if (hit != A.root && !known) {
+            if (hit != k_root && !known) {
                 for (int k = 0; k < ccount; k++) {
                     const int ci = L.comp_i + (crec + k) * CI, cd = L.comp_d + (crec + k) * CD;
                     alpha += interp_clamped<TAB_LDS>(T, wl, T.iv(ci + CI_ABS_X), T.iv(ci + CI_ABS_Y), T.iv(ci + CI_ABS_N),
@@ -2076,10 +2103,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
                                                             T.dv(cd + CD_ABS_RCP), T.dv(cd + CD_ABS_W));
                     if (k == 0) pre0 = alpha;
                 }
-                if constexpr (TAIL) { ac_node = container; ac_wl = pvt_d2u(wl); ac_alpha = alpha; ac_pre0 = pre0; }
+                if constexpr (TAIL && PVT_TAIL_ALPHA == 1) {
+                    ac_lds[0] = (unsigned long long)(unsigned int)container; ac_lds[64] = pvt_d2u(wl);
+                    ac_lds[128] = pvt_d2u(alpha); ac_lds[192] = pvt_d2u(pre0);
+                } else if constexpr (TAIL) { ac_node = container; ac_wl = pvt_d2u(wl); ac_alpha = alpha; ac_pre0 = pre0; }
             }
             if constexpr (TAIL) {
-                if (known && hit != A.root) { alpha = ac_alpha; pre0 = ac_pre0; }
+                if (known && hit != k_root) { alpha = ac_alpha; pre0 = ac_pre0; }
             }
         }
         int comp = -1;
@@ -2087,14 +2117,14 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             // free path in the container (no draw when the photon leaves the scene or the medium is clear), then
             // ONE advance for all three outcomes: to the absorption point if that comes first, else to the surface
             double depth = INFINITY;
-            if (hit != A.root && alpha > kAlphaZero) depth = div_normal(-pvt_log(1.0 - rng_uniform(rng)), alpha);
+            if (hit != k_root && alpha > kAlphaZero) depth = div_normal(-pvt_log(1.0 - rng_uniform(rng)), alpha);
             {
                 const double adv = __builtin_fmin(depth, t0);   // (depth == t0 is a surface event: same value)
                 pos.x = pos.x + dir.x * adv; pos.y = pos.y + dir.y * adv; pos.z = pos.z + dir.z * adv;
                 travelled += adv;
                 duration += div_known(adv * n_container, kCcm, kRcpCcm);
             }
-            if (hit == A.root) {  // leaves the scene (:728-744)
+            if (hit == k_root) {  // leaves the scene (:728-744)
                 ev_kind = PVT_EV_EXIT; ev_hit = hit; ev_adjacent = adjacent;
                 terminal = true;
                 t_sel = PVT_REC_EXIT; t_node = hit; t_normal = true;
@@ -2454,8 +2484,8 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
             // g / dn -- below kEps, hence ignored (_kernel.pyx:271-276), whenever g <= kEps/2 * dn; g is formed
             // with the very operations the next step would use (o = pos + t, h = 0.5 * size).  A photon that
             // cannot be cleared this way (grazing departures) simply takes its next step.
-            if (!RECORD && !MESH && uf(UF_FUSE_EXIT) && !terminal && count < A.maxsteps &&
-                (ev_kind == PVT_EV_REFLECT ? container == A.root : adjacent == A.root)) {
+            if (!RECORD && !MESH && uf(UF_FUSE_EXIT) && !terminal && count < k_maxsteps &&
+                (ev_kind == PVT_EV_REFLECT ? container == k_root : adjacent == k_root)) {
                 const V3 lp = local_point();
                 const int gp = hit * ND + ND_PARAMS;
                 const double h = kHoist ? 0.5 * (pvt_fabs(nrm.x) * hr_g.x + pvt_fabs(nrm.y) * hr_g.y + pvt_fabs(nrm.z) * hr_g.z)
@@ -2626,7 +2656,13 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
         const __attribute__((address_space(4))) KArgs* ak =
             (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         if constexpr (kTailCall) {
-            if (tail_n > 0) tail_run<RECORD, TAB_LDS, SEENW, MESH, GRID>((const KArgs*)ak, tail_n);
+            if (tail_n > 0) {
+                // (behind an opaque copy: every caller passes the same address expression, which interprocedural constant
+                // propagation would otherwise put back into the callee -- table lookups and all)
+                unsigned int lds_at = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) double*)smem_of_kernel;
+                asm volatile("" : "+s"(lds_at));
+                tail_run<RECORD, TAB_LDS, SEENW, MESH, GRID>((const KArgs*)ak, tail_n, lds_at);
+            }
         }
         leave_workgroup<TAB_LDS>((const KArgs*)ak);
     }
@@ -2637,7 +2673,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0) {
 // function -- the kernels' own loop keeps its registers whatever this one needs, and what is specific to a wave that runs
 // alone on its SIMD (every step is latency, nothing overlaps) can be done here without a price on the bulk.
 template <bool RECORD, int TAB_LDS, int SEENW, bool MESH, bool GRID>
-__device__ __attribute__((noinline)) void tail_run(const KArgs* kernel_args, int total) {
+__device__ __attribute__((noinline)) void tail_run(const KArgs* kernel_args, int total, unsigned int lds) {
     // The kernel's arguments, read where the kernel itself reads them.  The pointer arrives in vector registers: it is made
     // a scalar again (readfirstlane) and a pointer into the constant address space, so that the fields come through the
     // scalar cache and what is decided by them stays wave-uniform.  (The kernel-argument intrinsic itself returns garbage
@@ -2645,7 +2681,8 @@ __device__ __attribute__((noinline)) void tail_run(const KArgs* kernel_args, int
     const unsigned long long bits = (unsigned long long)kernel_args;
     const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)bits), hi = __builtin_amdgcn_readfirstlane((unsigned int)(bits >> 32));
     const __attribute__((address_space(4))) KArgs* ak = (const __attribute__((address_space(4))) KArgs*)(((unsigned long long)hi << 32) | lo);
-    trace_body<RECORD, TAB_LDS, SEENW, false, MESH, GRID, true>(*(const KArgs*)ak, __builtin_amdgcn_readfirstlane(total));
+    trace_body<RECORD, TAB_LDS, SEENW, false, MESH, GRID, true>(*(const KArgs*)ak, __builtin_amdgcn_readfirstlane(total),
+                                                                __builtin_amdgcn_readfirstlane(lds));
 }
 
 // Entry points.  Every variant runs four waves per SIMD.  Scenes of analytic shapes, tally launches and
