@@ -2635,7 +2635,9 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
         o[0] = tl_t[0]; o[1] = tl_t[1]; o[2] = tl_t[2]; o[3] = tl_t[3]; o[4] = wall_clock64(); o[5] = tl_iters;
         // (word 7: valid | the wave ended as the last of its workgroup << 1 | HW_ID register << 32: wave slot, SIMD, CU, SE)
         o[6] = __builtin_readcyclecounter() - tl_c0;
-        o[7] = 1ull | ((ws & WS_SOLO) ? 2ull : 0ull) | ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32);
+        // (the XCC_ID register, hwreg 20, says which of the eight dies: bits 2-5 of this word)
+        o[7] = 1ull | ((ws & WS_SOLO) || tail_n > 0 ? 2ull : 0ull) | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) << 2) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32);
     }
 #endif
     tally_flush();   // the first crossings still parked

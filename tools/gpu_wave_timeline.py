@@ -24,7 +24,26 @@ while at + 32 <= len(data):
               f"first step us [min p5 p50 p95 max] {pct(w[:,2])}; cursor dry {pct(w[w[:,3] > 0][:,3])}; end {pct(w[:,4])}")
         # where the waves that end last ran: the HW_ID register (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
         hw = (w[:, 7] >> 32) & 0xffffffff
-        simd, cu, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7
+        xcc = (w[:, 7] >> 2) & 15
+        simd, cu, se = (hw >> 4) & 3, (hw >> 8) & 31, ((hw >> 13) & 7) + 8 * xcc   # (SH bit folded into the CU number; SE x die)
+        solo = (w[:, 7] & 2) != 0
+        if solo.any():   # the last wave of every workgroup: how many of them share a SIMD with another one?
+            key = (se[solo] * 32 + cu[solo]) * 4 + simd[solo]
+            uniq, cnt = np.unique(key, return_counts=True)
+            cus = len(np.unique(key // 4))
+            print(f"   last waves of their workgroups: {solo.sum()} on {cus} CUs, {len(uniq)} SIMDs; waves per occupied SIMD: "
+                  f"{dict(zip(*np.unique(cnt, return_counts=True)))}")
+            blk = np.arange(len(w))[solo] // 4     # workgroup index (rows are blockIdx * 4 + wave)
+            wave = np.arange(len(w))[solo] % 4
+            print("   which wave of the workgroup is the last one:", np.bincount(wave, minlength=4), " its SIMD:", np.bincount(simd[solo], minlength=4))
+            # do workgroups b, b + 256, ... share a CU?
+            cukey = se * 32 + cu
+            first = cukey[0::4] if len(cukey) % 4 == 0 else None
+            if first is not None and len(first) >= 1024:
+                same = sum(len(set(first[b::256])) == 1 for b in range(256))
+                print(f"   workgroups b, b+256, b+512, b+768 on ONE CU for {same} of 256 b; distinct CUs seen: {len(set(first))}")
+                for b in (0, 1, 2, 3, 257):
+                    print(f"      workgroup {b}: CU key {first[b]}, SIMDs of its waves {simd[b * 4:b * 4 + 4].tolist()}")
         late = us(w[:, 4]) > 0.5 * us(w[:, 4]).max()
         key = (se[late] * 16 + cu[late]) * 4 + simd[late]
         uniq, cnt = np.unique(key, return_counts=True)
