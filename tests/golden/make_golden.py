@@ -305,6 +305,46 @@ def make_surface():
     save("surface.npz", **out)
 
 
+def make_py_tracer():
+    """Histories of the REFERENCE's per-ray Python tracer (algorithm/photon_tracer.py:276-328 `follow`, with its
+    `find_container`, `next_hit`, `step_forward`) -- the semantic ground truth of SURVEY §8(a)'s last row.  Its scene graph
+    (scene/node.py, scene/scene.py) imports anytree, which is not here, and no stand-in for anytree is written: the
+    PRODUCT's Node / Scene are put in its place (`sys.modules`), i.e. the reference's tracer walks the product's tree and
+    calls the product's `Scene.intersections` / `Node.point_to_node` -- while geometry (Sphere, Cylinder), Material,
+    components, surface delegate, Distribution and Ray are all the reference's own.  Every ray is traced under its own
+    numpy seed; `oracle/py_tracer.py` must reproduce every history from the same seeds (tests/test_py_tracer.py)."""
+    import pvtrace_amd.scene as prod_scene
+    from tests import scenes
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "algorithm", "common"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules["pvtrace.scene.node"] = prod_scene
+    sys.modules["pvtrace.scene.scene"] = prod_scene
+    tracer = ref_module("pvtrace.algorithm.photon_tracer")
+    ray_cls = ref_module("pvtrace.light.ray").Ray
+    comp = ref_module("pvtrace.material.component")
+    classes = types.SimpleNamespace(
+        Sphere=ref_module("pvtrace.geometry.sphere").Sphere, Cylinder=ref_module("pvtrace.geometry.cylinder").Cylinder,
+        Material=ref_module("pvtrace.material.material").Material, Luminophore=comp.Luminophore, Absorber=comp.Absorber,
+        Scatterer=comp.Scatterer, lumogen=ref_module("pvtrace.data.lumogen_f_red_305"))
+    scene = scenes.py_tracer_pin_scene(classes)
+    dirs, wls, seeds = scenes.py_tracer_pin_rays()
+    counts, kinds, pos, direc, wl = [], [], [], [], []
+    for d, w, sd in zip(dirs, wls, seeds):
+        np.random.seed(int(sd))
+        hist = tracer.follow(scene, ray_cls(position=(0.0, 0.0, 0.0), direction=tuple(d), wavelength=float(w)))
+        counts.append(len(hist))
+        for ray, event in hist:
+            kinds.append(event.value); pos.append(ray.position); direc.append(ray.direction); wl.append(ray.wavelength)
+    save("py_tracer.npz", directions=dirs, wavelengths=wls, seeds=seeds, counts=np.array(counts), kind=np.array(kinds),
+         position=np.array(pos, dtype=float), direction=np.array(direc, dtype=float), wavelength=np.array(wl, dtype=float))
+    print("   events:", np.bincount(np.array(kinds), minlength=10).tolist())
+
+
 def make_recorder_ids():
     """The reference's recorder vocabulary (engine/recorder.py:33-55: PROPERTIES, EVENTS) and what its constructors
     refuse, as JSON."""
@@ -348,6 +388,7 @@ if __name__ == "__main__":
         make_phase()
         make_surface()
         make_recorder_ids()
+        make_py_tracer()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
         make_config_tallies(only=sys.argv[2:])
@@ -359,6 +400,7 @@ if __name__ == "__main__":
     make_phase()
     make_surface()
     make_recorder_ids()
+    make_py_tracer()
     make_traces()
     make_lsc_tallies()
     make_config_tallies()

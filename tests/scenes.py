@@ -449,6 +449,44 @@ def reference_spec_scene(name="tests/data/pvtrace-scene-spec.yml"):
         return spec.load(json.load(fp)[name], base=os.path.join(gold, "spec_data"))
 
 
+def py_tracer_pin_scene(classes=None):
+    """The scene tests/golden/py_tracer.npz was made on: a dyed, scattering glass ball and a tilted glass rod in an air
+    sphere.  `classes`: a namespace with Sphere / Cylinder / Material / Luminophore / Absorber / Scatterer and the
+    `lumogen` data module -- the product's by default; tests/golden/make_golden.py passes the REFERENCE's own classes
+    (hung on the product's Node / Scene: the reference's scene graph needs anytree), so that the reference's
+    photon_tracer.follow runs on its own geometry, materials, components and surface delegates."""
+    import types
+
+    if classes is None:
+        classes = types.SimpleNamespace(Sphere=Sphere, Cylinder=Cylinder, Material=Material, Luminophore=Luminophore,
+                                        Absorber=Absorber, Scatterer=Scatterer, lumogen=lumogen_f_red_305)
+    c = classes
+    x = np.arange(400.0, 800.0)
+    comps = [c.Luminophore(np.column_stack((x, c.lumogen.absorption(x) * 3.0)),
+                           emission=np.column_stack((x, c.lumogen.emission(x))), quantum_yield=0.9),
+             c.Absorber(0.3), c.Scatterer(0.5, quantum_yield=0.95)]
+    world = Node(name="world", geometry=c.Sphere(10.0, material=c.Material(refractive_index=1.0)))
+    ball = Node(name="ball", parent=world, geometry=c.Sphere(1.0, material=c.Material(refractive_index=1.5, components=comps)))
+    ball.translate((0.0, 0.0, 2.0))
+    rod = Node(name="rod", parent=world, geometry=c.Cylinder(2.0, 0.5, material=c.Material(refractive_index=1.4)))
+    rod.translate((0.3, 0.0, -2.0))
+    rod.rotate(0.7, (0.0, 1.0, 0.2))
+    return Scene(world)
+
+
+def py_tracer_pin_rays(n=300):
+    """(directions, wavelengths, numpy seeds) of the rays of that fixture, all from the origin."""
+    rng = np.random.default_rng(5)
+    dirs, wls = [], []
+    for k in range(n):
+        d = rng.normal(size=3)
+        if k % 2:   # every other ray straight at the ball (+z) or at the rod (-z)
+            d = np.array([0.05 * rng.normal(), 0.05 * rng.normal(), 1.0 if k % 4 == 1 else -1.0])
+        dirs.append(d / np.linalg.norm(d))
+        wls.append(float(rng.uniform(450, 650)))
+    return np.array(dirs), np.array(wls), 1000 + np.arange(n)
+
+
 REFERENCE_SCENES = {   # expressible in the reference engine (no coatings)
     "hello_world": hello_world,
     "lsc_equivalent": lsc_equivalent,

@@ -198,3 +198,35 @@ def test_find_container_known_answers():
     scene, world, box = _embedded()
     for z, want in ((-1.0, world), (-0.4, box), (0.6, world)):
         assert P.find_container(scene.intersections((0.0, 0.0, z), (0.0, 0.0, 1.0))) is want
+
+
+def test_py_tracer_reproduces_the_references_python_tracer_history_by_history():
+    """tests/golden/py_tracer.npz: 300 rays through the REFERENCE's `photon_tracer.follow`
+    (pvtrace/algorithm/photon_tracer.py:26-328) -- on its own Sphere / Cylinder, Material, Luminophore / Absorber /
+    Scatterer, Fresnel surface delegate, Distribution and Ray, hung on the product's Node / Scene (the reference's scene
+    graph needs anytree, which is absent; no stand-in for it is written) -- each under its own numpy seed.  The
+    restatement must produce the SAME history from the same seed: every event, in order, with its position, direction and
+    wavelength (the order of the random draws is part of what is pinned).  SURVEY §8(a), last row."""
+    from tests.util import load_golden
+    from pvtrace_amd.light import Ray
+
+    g = load_golden("py_tracer.npz")
+    dirs, wls, seeds = scenes.py_tracer_pin_rays()
+    assert np.array_equal(dirs, g["directions"]) and np.array_equal(wls, g["wavelengths"]) and np.array_equal(seeds, g["seeds"])
+    scene = scenes.py_tracer_pin_scene()
+    at = 0
+    seen = set()
+    for d, w, sd, n in zip(dirs, wls, seeds, g["counts"]):
+        np.random.seed(int(sd))
+        hist = P.follow(scene, Ray(position=(0.0, 0.0, 0.0), direction=tuple(d), wavelength=float(w)))
+        assert len(hist) == n, (sd, len(hist), n)
+        for k, item in enumerate(hist):
+            ray, event = item[0], item[1]
+            assert event.value == g["kind"][at + k], (sd, k)
+            assert np.allclose(ray.position, g["position"][at + k], rtol=0, atol=1e-9), (sd, k)
+            assert np.allclose(ray.direction, g["direction"][at + k], rtol=0, atol=1e-9), (sd, k)
+            assert abs(ray.wavelength - g["wavelength"][at + k]) < 1e-9, (sd, k)
+            seen.add(event)
+        at += n
+    assert at == len(g["kind"])
+    assert {Event.REFLECT, Event.TRANSMIT, Event.ABSORB, Event.EMIT, Event.SCATTER, Event.NONRADIATIVE, Event.EXIT} <= seen
