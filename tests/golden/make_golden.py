@@ -345,6 +345,36 @@ def make_py_tracer():
     print("   events:", np.bincount(np.array(kinds), minlength=10).tolist())
 
 
+def make_emit():
+    """The reference's host emitter, `engine/emit.py:92-134 emit_bundle`, on five posed lights with every built-in
+    delegate (the reference's own Light, mask and phase-function classes on the product's Nodes; its scene graph needs
+    anytree, see make_py_tracer), under numpy seeds: the product's `emit_bundle(scene, n, seed=None)` draws from the same
+    global generator in the same order and must return the same arrays, bit for bit (tests/test_scene_api.py)."""
+    import pvtrace_amd.scene as prod_scene
+    from tests import scenes
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "algorithm", "common", "engine"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules["pvtrace.scene.node"] = prod_scene
+    sys.modules["pvtrace.scene.scene"] = prod_scene
+    emit = ref_module("pvtrace.engine.emit")
+    full = scenes.emit_pin_scene(ref_module("pvtrace.light.light"), ref_module("pvtrace.material.utils"),
+                                 ref_module("pvtrace.material.distribution").Distribution)
+    # (the product's Scene.light_nodes looks for the product's Light class; the reference's emitter needs two attributes)
+    scene = types.SimpleNamespace(root=full.root, light_nodes=[n for n in full.root.levelorder() if getattr(n, "light", None) is not None])
+    out = {}
+    for n, seed in ((1, 11), (7, 12), (1003, 13)):
+        np.random.seed(seed)
+        pos, direc, wl, sources = emit.emit_bundle(scene, n)
+        out.update({f"n{n}_seed": np.int64(seed), f"n{n}_position": pos, f"n{n}_direction": direc, f"n{n}_wavelength": wl,
+                    f"n{n}_sources": np.array(sources)})
+    save("emit.npz", **out)
+
+
 def make_recorder_ids():
     """The reference's recorder vocabulary (engine/recorder.py:33-55: PROPERTIES, EVENTS) and what its constructors
     refuse, as JSON."""
@@ -389,6 +419,7 @@ if __name__ == "__main__":
         make_surface()
         make_recorder_ids()
         make_py_tracer()
+        make_emit()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
         make_config_tallies(only=sys.argv[2:])
@@ -401,6 +432,7 @@ if __name__ == "__main__":
     make_surface()
     make_recorder_ids()
     make_py_tracer()
+    make_emit()
     make_traces()
     make_lsc_tallies()
     make_config_tallies()

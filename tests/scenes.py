@@ -474,6 +474,29 @@ def py_tracer_pin_scene(classes=None):
     return Scene(world)
 
 
+def emit_pin_scene(light_module=None, phase_module=None, distribution_class=None):
+    """Five posed lights with every built-in mask and direction delegate: the scene tests/golden/emit.npz was made on.
+    The modules the delegates come from: the product's by default; make_golden.py passes the reference's
+    (pvtrace.light.light, pvtrace.material.utils, Distribution)."""
+    from pvtrace_amd import light as product_light, material as product_material
+
+    L = light_module or product_light
+    U = phase_module or product_material
+    D = distribution_class or Distribution
+    world = Node(name="w", geometry=Sphere(20.0, material=Material(refractive_index=1.0)))
+    x = np.linspace(400, 700, 31)
+    y = np.exp(-((x - 550) / 40.0) ** 2)
+    specs = [dict(direction=U.Cone(0.4)), dict(direction=U.isotropic, position=L.RectangularMask(1.0, 2.0)),
+             dict(direction=U.lambertian, position=L.CircularMask(1.5), wavelength=L.ConstantWavelengthMask(610.0)),
+             dict(direction=U.HenyeyGreenstein(0.7), position=L.CubeMask(1, 2, 3), wavelength=L.SpectrumWavelengthMask(D(x, y))),
+             dict()]
+    for k, kw in enumerate(specs):
+        n = Node(name=f"L{k}", parent=world, light=L.Light(name=f"L{k}", **kw))
+        n.translate((0.3 * k, -0.2 * k, 1.0 + k))
+        n.rotate(0.3 + 0.2 * k, (1.0, 0.2 * k, 0.1))
+    return Scene(world)
+
+
 def py_tracer_pin_rays(n=300):
     """(directions, wavelengths, numpy seeds) of the rays of that fixture, all from the origin."""
     rng = np.random.default_rng(5)

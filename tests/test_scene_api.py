@@ -526,3 +526,21 @@ def test_a_vectorised_user_delegate_is_called_once_per_bundle():
     bad = Node(name="b", parent=world, light=Light(wavelength=vectorized_delegate(lambda k: np.zeros((k, 2))), name="b"))
     with pytest.raises(ValueError, match="shape"):
         emit_bundle(Scene(world), 10, seed=1)
+
+
+def test_host_emitter_is_the_references_bit_for_bit_under_a_numpy_seed():
+    """tests/golden/emit.npz: the REFERENCE's `emit_bundle` (engine/emit.py:92-134) on five posed lights with every
+    built-in wavelength / position / direction delegate, under numpy seeds.  With `seed=None` the product's host emitter
+    draws from numpy's global generator like the reference -- same draws, same order, same arithmetic: identical arrays
+    and the same round-robin of sources."""
+    from tests import scenes
+    from tests.util import load_golden
+
+    g = load_golden("emit.npz")
+    scene = scenes.emit_pin_scene()
+    for n in (1, 7, 1003):
+        np.random.seed(int(g[f"n{n}_seed"]))
+        pos, dirs, wl, sources = emit_bundle(scene, n, seed=None)
+        assert np.array_equal(pos, g[f"n{n}_position"]) and np.array_equal(dirs, g[f"n{n}_direction"])
+        assert np.array_equal(wl, g[f"n{n}_wavelength"])
+        assert list(sources) == g[f"n{n}_sources"].tolist()
