@@ -375,6 +375,82 @@ def make_emit():
     save("emit.npz", **out)
 
 
+LSC_DELEGATE_CONFIGS = [   # (back-surface mirror, solar-cell edges)
+    (False, ()), (True, ()), (True, ("left", "right", "near", "far")), (False, ("left", "far")),
+]
+
+
+def lsc_delegate_rays(seed=31, per_face=14):
+    """Rays meeting the six faces of a 5 x 5 x 1 box from inside (n 1.5 -> 1.0) and from outside (1.0 -> 1.5):
+    (positions on the faces, directions, n1, n2).  Shared by the generator and tests/test_coating_known_rays.py."""
+    rng = np.random.default_rng(seed)
+    half = np.array([2.5, 2.5, 0.5])
+    pos, direc, n1, n2 = [], [], [], []
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            for k in range(per_face):
+                p = rng.uniform(-0.95, 0.95, 3) * half
+                p[axis] = sign * half[axis]
+                d = rng.normal(size=3)
+                d /= np.linalg.norm(d)
+                outward = d[axis] * sign > 0
+                if (k % 2 == 0) != outward:   # even k: leaving the box, odd k: arriving from outside
+                    d[axis] = -d[axis]
+                pos.append(p); direc.append(d)
+                n1.append(1.5 if k % 2 == 0 else 1.0); n2.append(1.0 if k % 2 == 0 else 1.5)
+    return np.array(pos), np.array(direc), np.array(n1), np.array(n2)
+
+
+def make_lsc_delegates():
+    """The reference's LSC surface delegates (`device/lsc.py:22-86`: OptionalMirrorAndSolarCell, AirGapMirror) asked
+    about rays on every face of the slab, in four configurations.  `device/lsc.py` imports the reference's trimesh-backed
+    Box, its anytree-based scene graph and its meshcat renderer: the product's geometry / scene modules are put in the
+    place of the first two (as in make_py_tracer) and an EMPTY object in the place of the renderer module (a visualiser,
+    nothing of the path) -- no third-party package is imitated.  The box the delegates ask for normals is the product's
+    (itself held to the reference's known answers, tests/test_golden_units.py)."""
+    import pvtrace_amd.geometry as prod_geometry
+    import pvtrace_amd.scene as prod_scene
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "algorithm", "common", "device"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules["pvtrace.scene.node"] = prod_scene
+    sys.modules["pvtrace.scene.scene"] = prod_scene
+    sys.modules["pvtrace.geometry.box"] = prod_geometry
+    sys.modules["pvtrace.scene.renderer"] = types.SimpleNamespace(MeshcatRenderer=None)
+    lsc = ref_module("pvtrace.device.lsc")
+    box = prod_geometry.Box((5.0, 5.0, 1.0))
+    pos, direc, n1, n2 = lsc_delegate_rays()
+
+    def node(n):
+        return types.SimpleNamespace(geometry=types.SimpleNamespace(material=types.SimpleNamespace(refractive_index=n)))
+
+    out = {"positions": pos, "directions": direc, "n1": n1, "n2": n2}
+    for c, (mirror, cells) in enumerate(LSC_DELEGATE_CONFIGS):
+        owner = types.SimpleNamespace(_solar_cell_surfaces=set(cells), _back_surface_mirror_info={"want_back_surface_mirror": mirror},
+                                      _air_gap_mirror_info={"want_air_gap_mirror": True, "lambertian": False})
+        delegate = lsc.OptionalMirrorAndSolarCell(owner)
+        refl, trans, spec = [], [], []
+        for p_, d_, a, b in zip(pos, direc, n1, n2):
+            ray = types.SimpleNamespace(position=tuple(p_), direction=tuple(d_))
+            args = (None, ray, box, node(a), node(b))
+            r = delegate.reflectivity(*args)
+            refl.append(r)
+            spec.append(delegate.reflected_direction(*args))
+            with np.errstate(invalid="ignore"):
+                trans.append(delegate.transmitted_direction(*args) if r < 1.0 else (np.nan,) * 3)
+        out.update({f"cfg{c}_reflectivity": np.array(refl, dtype=float), f"cfg{c}_reflected": np.array(spec, dtype=float),
+                    f"cfg{c}_transmitted": np.array(trans, dtype=float)})
+        if c == 0:
+            gap = lsc.AirGapMirror(owner)
+            out["airgap_reflectivity"] = np.array([gap.reflectivity(None, types.SimpleNamespace(position=tuple(p_), direction=tuple(d_)),
+                                                                    box, node(a), node(b)) for p_, d_, a, b in zip(pos, direc, n1, n2)])
+    save("lsc_delegates.npz", **out)
+
+
 def make_recorder_ids():
     """The reference's recorder vocabulary (engine/recorder.py:33-55: PROPERTIES, EVENTS) and what its constructors
     refuse, as JSON."""
@@ -420,6 +496,7 @@ if __name__ == "__main__":
         make_recorder_ids()
         make_py_tracer()
         make_emit()
+        make_lsc_delegates()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
         make_config_tallies(only=sys.argv[2:])
@@ -433,6 +510,7 @@ if __name__ == "__main__":
     make_recorder_ids()
     make_py_tracer()
     make_emit()
+    make_lsc_delegates()
     make_traces()
     make_lsc_tallies()
     make_config_tallies()

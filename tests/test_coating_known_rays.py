@@ -176,3 +176,49 @@ def test_hand_traced_rays_on_the_referee(case):
 @pytest.mark.parametrize("case", [run_mirror_and_cells, run_air_gap_mirror, run_partial_top_mirror])
 def test_hand_traced_rays_on_the_hip_engine(case):
     case(gpu_tracer)
+
+
+def test_declarative_lsc_delegate_answers_like_the_references_delegate():
+    """tests/golden/lsc_delegates.npz: the REFERENCE's `OptionalMirrorAndSolarCell` (device/lsc.py:22-62) asked for the
+    reflectivity, the reflected and the transmitted direction of 168 rays on the six faces of the 5 x 5 x 1 slab, from
+    inside and from outside, in four configurations (no coating; back mirror; mirror + four cell edges; two cell edges).
+    The product's delegate of the same name is DECLARATIVE -- it only lists coatings, which the flattener lowers into the
+    device table -- and its host methods (what the per-ray Python tracer calls, and what the C referee's coating branch is
+    held to in tests/test_scene_api.py) must give the same answers.  `AirGapMirror`: reflectivity 1 everywhere."""
+    import types
+
+    from pvtrace_amd import Box
+    from pvtrace_amd.device.lsc import AirGapMirror, OptionalMirrorAndSolarCell
+    from tests.util import load_golden
+
+    g = load_golden("lsc_delegates.npz")
+    configs = [(False, ()), (True, ()), (True, ("left", "right", "near", "far")), (False, ("left", "far"))]
+    box = Box((5.0, 5.0, 1.0))
+
+    def node(n):
+        return types.SimpleNamespace(geometry=types.SimpleNamespace(material=types.SimpleNamespace(refractive_index=n)))
+
+    for c, (mirror, cells) in enumerate(configs):
+        lsc = LSC((5.0, 5.0, 1.0))
+        if mirror:
+            lsc.add_back_surface_mirror()
+        if cells:
+            lsc.add_solar_cell(set(cells))
+        delegate = OptionalMirrorAndSolarCell(lsc)
+        overridden = 0
+        for k, (p, d, n1, n2) in enumerate(zip(g["positions"], g["directions"], g["n1"], g["n2"])):
+            ray = types.SimpleNamespace(position=tuple(p), direction=tuple(d))
+            args = (None, ray, box, node(n1), node(n2))
+            want_r = g[f"cfg{c}_reflectivity"][k]
+            got_r = delegate.reflectivity(*args)
+            assert got_r == pytest.approx(want_r, rel=1e-12, abs=1e-15), (c, k)
+            assert np.allclose(delegate.reflected_direction(*args), g[f"cfg{c}_reflected"][k], rtol=0, atol=1e-14), (c, k)
+            if want_r < 1.0:
+                assert np.allclose(delegate.transmitted_direction(*args), g[f"cfg{c}_transmitted"][k], rtol=0, atol=1e-14), (c, k)
+            overridden += want_r != g["cfg0_reflectivity"][k]
+        assert (overridden > 0) == (c > 0), (c, overridden)     # the coated configurations really differ from plain Fresnel
+    gap_owner = LSC((5.0, 5.0, 1.0)); gap_owner.add_air_gap_mirror()
+    gap = AirGapMirror(gap_owner)
+    for k, (p, d, n1, n2) in enumerate(zip(g["positions"], g["directions"], g["n1"], g["n2"])):
+        ray = types.SimpleNamespace(position=tuple(p), direction=tuple(d))
+        assert gap.reflectivity(None, ray, box, node(n1), node(n2)) == g["airgap_reflectivity"][k] == 1.0
