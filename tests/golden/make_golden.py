@@ -451,6 +451,38 @@ def make_lsc_delegates():
     save("lsc_delegates.npz", **out)
 
 
+def make_lsc_scenes():
+    """The scenes the reference's `LSC` class builds (`device/lsc.py:95-219`: `_make_scene` through its public `add_*`
+    methods), described node by node -- names, box sizes, refractive indices, poses, components with their spectra, lights
+    with their delegates.  BASELINE configs[1] is `LSC((5, 5, 1))`: the product's builder must make the same scene
+    (tests/test_scene_api.py).  Module substitutions as in make_lsc_delegates."""
+    import pvtrace_amd.geometry as prod_geometry
+    import pvtrace_amd.scene as prod_scene
+    from tests import scenes
+    from tests.util import describe_lsc_scene
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "algorithm", "common", "device"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules["pvtrace.scene.node"] = prod_scene
+    sys.modules["pvtrace.scene.scene"] = prod_scene
+    sys.modules["pvtrace.geometry.box"] = prod_geometry
+    sys.modules.setdefault("pvtrace.scene.renderer", types.SimpleNamespace(MeshcatRenderer=None))
+    lsc = ref_module("pvtrace.device.lsc")
+    light = ref_module("pvtrace.light.light")
+    utils = ref_module("pvtrace.material.utils")
+    cases = scenes.lsc_builder_cases(lsc.LSC, utils.cone, light.rectangular_mask, ref_module("pvtrace.data.lumogen_f_red_305"))
+    out = {}
+    for name, device in cases.items():
+        device._make_scene()
+        for key, value in describe_lsc_scene(device._scene).items():
+            out[f"{name}/{key}"] = value
+    save("lsc_scenes.npz", **out)
+
+
 def make_recorder_ids():
     """The reference's recorder vocabulary (engine/recorder.py:33-55: PROPERTIES, EVENTS) and what its constructors
     refuse, as JSON."""
@@ -497,6 +529,7 @@ if __name__ == "__main__":
         make_py_tracer()
         make_emit()
         make_lsc_delegates()
+        make_lsc_scenes()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
         make_config_tallies(only=sys.argv[2:])
@@ -511,6 +544,7 @@ if __name__ == "__main__":
     make_py_tracer()
     make_emit()
     make_lsc_delegates()
+    make_lsc_scenes()
     make_traces()
     make_lsc_tallies()
     make_config_tallies()

@@ -497,6 +497,24 @@ def emit_pin_scene(light_module=None, phase_module=None, distribution_class=None
     return Scene(world)
 
 
+def lsc_builder_cases(LSC, cone, rectangular_mask, lumogen):
+    """The LSC objects tests/golden/lsc_scenes.npz describes, built through `LSC`'s public methods: the default device
+    (BASELINE configs[1]) and one with everything set by hand.  Called with the product's classes by the test and with
+    the reference's by tests/golden/make_golden.py."""
+    import functools
+
+    x = np.arange(450.0, 750.0, 2.0)
+    custom = LSC((8.0, 4.0, 0.5), wavelength_range=x, n0=1.0, n1=1.6)
+    custom.add_luminophore("Dye", np.column_stack((x, lumogen.absorption(x) * 4.0)), np.column_stack((x, lumogen.emission(x))), 0.85)
+    custom.add_absorber("Host", 0.02)   # (no add_scatterer: the reference's raises NameError -- `Scatterer` is not imported in device/lsc.py:250-258)
+    custom.add_light("Lamp", (0.5, -0.5, 3.0), rotation=(np.radians(180), (1, 0, 0)), direction=functools.partial(cone, np.radians(10)),
+                     position=functools.partial(rectangular_mask, 2.0, 1.0))
+    custom.add_solar_cell({"left", "right"})
+    custom.add_back_surface_mirror()
+    custom.add_air_gap_mirror(lambertian=True)
+    return {"default": LSC((5.0, 5.0, 1.0)), "custom": custom}
+
+
 def py_tracer_pin_rays(n=300):
     """(directions, wavelengths, numpy seeds) of the rays of that fixture, all from the origin."""
     rng = np.random.default_rng(5)

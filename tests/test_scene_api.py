@@ -544,3 +544,26 @@ def test_host_emitter_is_the_references_bit_for_bit_under_a_numpy_seed():
         assert np.array_equal(pos, g[f"n{n}_position"]) and np.array_equal(dirs, g[f"n{n}_direction"])
         assert np.array_equal(wl, g[f"n{n}_wavelength"])
         assert list(sources) == g[f"n{n}_sources"].tolist()
+
+
+def test_lsc_builder_makes_the_scene_the_references_lsc_class_makes():
+    """tests/golden/lsc_scenes.npz: what the REFERENCE's `LSC` class builds (device/lsc.py:95-219) for the default
+    device -- BASELINE configs[1] -- and for one configured through every public `add_*` method that works there
+    (`add_scatterer` raises NameError in the reference), described node by node: names, tree, box sizes, refractive
+    indices, poses, surface delegate classes, components with coefficient and emission arrays, lights with their
+    delegates.  The product's builder must describe the same, array for array, bit for bit."""
+    from pvtrace_amd import light as product_light, material as product_material
+    from pvtrace_amd.data import lumogen_f_red_305
+    from tests import scenes
+    from tests.util import describe_lsc_scene, load_golden
+
+    g = load_golden("lsc_scenes.npz")
+    cases = scenes.lsc_builder_cases(LSC, product_material.cone, product_light.rectangular_mask, lumogen_f_red_305)
+    for name, device in cases.items():
+        mine = describe_lsc_scene(device.scene)
+        theirs = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+        assert set(mine) == set(theirs), (name, sorted(set(mine) ^ set(theirs)))
+        for key, want in theirs.items():
+            assert mine[key].shape == want.shape and np.array_equal(mine[key], want), (name, key)
+    assert g["default/names"].tolist() == ["World", "LSC", "Light"]
+    assert g["custom/names"].tolist() == ["World", "LSC", "Air Gap Mirror", "Lamp"]
