@@ -483,6 +483,154 @@ def make_lsc_scenes():
     save("lsc_scenes.npz", **out)
 
 
+def reference_classes_for_scenes():
+    """{name in tests/scenes.py: the reference's object of that name} -- geometry (but Box), materials, components, surfaces,
+    lights and masks, phase functions, recorders, spectra data -- for building the twins of the test scenes."""
+    comp, surf, light, utils = (ref_module("pvtrace.material.component"), ref_module("pvtrace.material.surface"),
+                                ref_module("pvtrace.light.light"), ref_module("pvtrace.material.utils"))
+    rec = ref_module("pvtrace.engine.recorder")
+    return dict(
+        Absorber=comp.Absorber, Luminophore=comp.Luminophore, Scatterer=comp.Scatterer, Reactor=comp.Reactor,
+        Material=ref_module("pvtrace.material.material").Material, Surface=surf.Surface, NullSurfaceDelegate=surf.NullSurfaceDelegate,
+        Sphere=ref_module("pvtrace.geometry.sphere").Sphere, Cylinder=ref_module("pvtrace.geometry.cylinder").Cylinder,
+        Light=light.Light, rectangular_mask=light.rectangular_mask, CircularMask=light.CircularMask,
+        ConstantWavelengthMask=light.ConstantWavelengthMask, CubeMask=light.CubeMask, SpectrumWavelengthMask=light.SpectrumWavelengthMask,
+        cone=utils.cone, isotropic=utils.isotropic, lambertian=utils.lambertian, Cone=utils.Cone, HenyeyGreenstein=utils.HenyeyGreenstein,
+        gaussian=utils.gaussian, Distribution=ref_module("pvtrace.material.distribution").Distribution,
+        Recorder=rec.Recorder, Histogram=rec.Histogram, Heatmap=rec.Heatmap, lumogen_f_red_305=ref_module("pvtrace.data.lumogen_f_red_305"))
+
+
+def make_compiled_tables():
+    """The flat tables of the REFERENCE's own flattener, `engine/compiler.py:57-331 compile_scene`, for the eight test
+    scenes the reference engine can express -- the flattener's pin from outside (it had been hand-restated tables only).
+    The scenes are built by tests/scenes.py's own builders with the reference's classes put under the names they use
+    (materials, components, surfaces, Sphere, Cylinder, lights, masks, phase functions, recorders); Node / Scene / Box are the
+    product's, standing where the reference's anytree- and trimesh-based ones are looked for, and the ONE name the
+    reference compiler takes from anytree, `PreOrderIter`, is bound to the product tree's own pre-order walk
+    (`Node.preorder`): an adapter to the tree that is there, not an imitation of the package."""
+    import contextlib
+
+    import pvtrace_amd.geometry as prod_geometry
+    import pvtrace_amd.scene as prod_scene
+    from tests import scenes
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "algorithm", "common", "device", "engine"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules["pvtrace.scene.node"] = prod_scene
+    sys.modules["pvtrace.scene.scene"] = prod_scene
+    sys.modules["pvtrace.geometry.box"] = prod_geometry
+    sys.modules["pvtrace.geometry.mesh"] = prod_geometry
+    sys.modules["anytree"] = types.SimpleNamespace(PreOrderIter=lambda root: root.preorder())
+    compiler = ref_module("pvtrace.engine.compiler")
+    theirs = reference_classes_for_scenes()
+
+    @contextlib.contextmanager
+    def reference_names():
+        old = {k: getattr(scenes, k) for k in theirs if hasattr(scenes, k)}
+        for k in old:
+            setattr(scenes, k, theirs[k])
+        try:
+            yield
+        finally:
+            for k, v in old.items():
+                setattr(scenes, k, v)
+
+    out = {}
+    fields = ("geom_type", "geom_params", "local_to_world", "world_to_local", "refractive_index", "surface_type", "comp_start",
+              "comp_count", "comp_type", "comp_qy", "comp_tau_rad", "comp_tau_nr", "comp_phase_type", "comp_phase_param",
+              "comp_abs_start", "comp_abs_n", "comp_ems_start", "comp_ems_n", "abs_x", "abs_y", "ems_x", "ems_cdf", "rec_node",
+              "rec_event", "rec_has_facet", "rec_facet", "rec_atol", "rec_hist_start", "rec_hist_n", "hist_prop_a", "hist_prop_b",
+              "hist_na", "hist_nb", "hist_lo_a", "hist_hi_a", "hist_lo_b", "hist_hi_b", "hist_offset")
+    for name, build in scenes.REFERENCE_SCENES.items():
+        with reference_names():
+            scene = build()
+        compiled = compiler.compile_scene(scene)
+        for f in fields:
+            out[f"{name}/{f}"] = np.asarray(getattr(compiled, f))
+        out[f"{name}/total_bins"] = np.int64(compiled.total_bins)
+        out[f"{name}/root_id"] = np.int64(compiled.root_id)
+        out[f"{name}/node_names"] = np.array(compiled.node_names)
+        out[f"{name}/component_names"] = np.array(list(compiled.component_names) or [""])
+        out[f"{name}/recorder_names"] = np.array([spec if isinstance(spec, str) else spec[0] for spec in getattr(compiled, "recorder_names", [])] or [""])
+    save("compiled_tables.npz", **out)
+
+
+def describe_engine_result(result, moment_properties=("wavelength", "angle", "duration", "pathlength")):
+    """Everything an `EngineResult` answers (reference api.py:81-194), as a flat {key: array} dict -- the reference's and
+    the product's alike (tests/test_scene_api.py imports this function)."""
+    out = {"num_rays": np.int64(result.num_rays), "num_recorded": np.int64(result.num_recorded),
+           "recorded_indices": np.asarray(result.recorded_indices)}
+    names = []
+    for name, rec in result.recorders.items():
+        names.append(name)
+        out[f"rec/{name}/counts"] = np.array([rec.rays, rec.crossings], dtype=np.int64)
+        out[f"rec/{name}/stats"] = np.array([[rec.mean(p), rec.std(p), rec.error(p)] for p in moment_properties], dtype=float)
+        for h in range(len(rec.spec.histograms)):
+            parts = rec.histogram(h)
+            for k, part in enumerate(parts):
+                out[f"rec/{name}/hist{h}/{k}"] = np.asarray(part)
+    out["recorder_names"] = np.array(names or [""])
+    counts = result.event_counts()
+    out["event_counts"] = np.array([counts.get(type(next(iter(counts)))(v), 0) if counts else 0 for v in range(10)], dtype=np.int64)
+    rows, texts, lengths = [], [], []
+    for history in result.histories():
+        lengths.append(len(history))
+        for ray, event, meta in history:
+            normal = meta.get("normal", (np.nan, np.nan, np.nan))
+            rows.append([event.value, *ray.position, *ray.direction, ray.wavelength, ray.travelled, ray.duration, *normal])
+            texts.append("|".join(str(x) for x in (ray.source, meta["hit"], meta["container"], meta["adjacent"], meta["component"],
+                                                   sorted(meta))))
+    out["history_lengths"] = np.array(lengths, dtype=np.int64)
+    out["history_rows"] = np.array(rows, dtype=float).reshape(len(rows), 13)
+    out["history_texts"] = np.array(texts or [""])
+    return out
+
+
+def make_engine_result():
+    """The reference's whole host pipeline around its kernel -- `compile_scene` (compiler.py), `emit_bundle` (emit.py, under a
+    numpy seed), `_kernel.trace_bundle` (its own compiled kernel, oracle/_ref), `EngineResult` / `RecorderResult` (api.py:26-194)
+    -- on the kitchen-sink scene built with the reference's classes (substitutions: make_compiled_tables).  Saved: the
+    kernel's raw `data` dict with the emitted rays' sources, and everything the reference's result object answers about
+    it.  The product's `EngineResult` on the SAME `data` and the product's tables must answer the same
+    (tests/test_scene_api.py): recorder counts, moments, histogram edges and counts, event counts, and every history with
+    its Ray fields, source names and metadata."""
+    import contextlib
+
+    from oracle import oracle as O
+    from tests import scenes
+
+    make_compiled_tables()   # (sets the substitutions up; its own output is rewritten identically)
+    compiler = ref_module("pvtrace.engine.compiler")
+    api = ref_module("pvtrace.engine.api")
+    emit = ref_module("pvtrace.engine.emit")
+    theirs = reference_classes_for_scenes()
+    old = {k: getattr(scenes, k) for k in theirs if hasattr(scenes, k)}
+    for k in old:
+        setattr(scenes, k, theirs[k])
+    try:
+        full = scenes.kitchen_sink()
+    finally:
+        for k, v in old.items():
+            setattr(scenes, k, v)
+    compiled = compiler.compile_scene(full)
+    lights = types.SimpleNamespace(root=full.root, light_nodes=[n for n in full.root.levelorder() if getattr(n, "light", None) is not None])
+    n, max_events, record_every = 900, 48, 3
+    np.random.seed(77)
+    pos, direc, wl, sources = emit.emit_bundle(lights, n)
+    data = O.reference_trace_bundle(compiled, pos, direc, wl, 31, 1000, max_events, 2, 1, record_every)
+    result = api.EngineResult(compiled, data, sources, max_events, record_every, 0.0)
+    out = {f"data/{k}": np.asarray(v) for k, v in data.items()}
+    out["sources"] = np.array(sources)
+    out["par"] = np.array([n, max_events, record_every], dtype=np.int64)
+    for k, v in describe_engine_result(result, api.MOMENT_PROPERTIES).items():
+        out[f"ref/{k}"] = v
+    save("engine_result.npz", **out)
+
+
 def make_recorder_ids():
     """The reference's recorder vocabulary (engine/recorder.py:33-55: PROPERTIES, EVENTS) and what its constructors
     refuse, as JSON."""
@@ -530,6 +678,8 @@ if __name__ == "__main__":
         make_emit()
         make_lsc_delegates()
         make_lsc_scenes()
+        make_compiled_tables()
+        make_engine_result()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
         make_config_tallies(only=sys.argv[2:])
@@ -545,6 +695,8 @@ if __name__ == "__main__":
     make_emit()
     make_lsc_delegates()
     make_lsc_scenes()
+    make_compiled_tables()
+    make_engine_result()
     make_traces()
     make_lsc_tallies()
     make_config_tallies()

@@ -18,11 +18,13 @@ that never call `compile_scene` or any pvtrace_amd table code:
   taking na*nb bins (:137-204).
 """
 import functools
+import os
 
 import numpy as np
 import pytest
 
 import pvtrace_amd as pv
+from tests import scenes
 from pvtrace_amd.material import Cone, HenyeyGreenstein
 from pvtrace_amd.engine import Heatmap, Histogram, Recorder, compile_scene
 
@@ -212,3 +214,33 @@ def test_null_surfaces_phase_functions_and_lifetimes_are_tagged_like_the_referen
         abs_y=np.array([1.5, 1, 2, 3, 4, 0.2, 4, 3, 2, 1], F),
         ems_x=x, ems_cdf=np.array([0.0, 0.25, 0.75, 1.0], F),
     ))
+
+
+@pytest.mark.parametrize("name", sorted(scenes.REFERENCE_SCENES))
+def test_flattener_equals_the_references_own_compile_scene(name):
+    """tests/golden/compiled_tables.npz: the tables the REFERENCE's flattener (`engine/compiler.py:57-331`) makes of the
+    eight test scenes the reference engine can express, built by tests/scenes.py's builders with the reference's own
+    materials, components, surfaces, lights, recorders, Sphere and Cylinder (tests/golden/make_golden.py:
+    make_compiled_tables says what stands where the reference's anytree / trimesh based classes are looked for).  Every
+    field of the product's `compile_scene` on the product's twin must equal it bit for bit -- poses and their inverses,
+    pooled spectra and CDFs, component and recorder rows, histogram offsets, names -- and the tables the reference does not
+    have (coatings, meshes, histogram-sampled spectra, source filters) must be in their neutral state."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "compiled_tables.npz"))
+    compiled = compile_scene(scenes.REFERENCE_SCENES[name]())
+    theirs = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+    mine = compiled.tables()
+    assert len(theirs) >= 40
+    for key, want in theirs.items():
+        if key in ("node_names", "component_names", "recorder_names"):
+            got = list(getattr(compiled, key))
+            assert got == [v for v in want.tolist() if v != ""] or (got == [] and want.tolist() == [""]), (name, key)
+            continue
+        got = np.asarray(mine[key] if key in mine else getattr(compiled, key))
+        assert got.shape == want.shape and np.array_equal(got, want), (name, key)
+        if key not in ("total_bins", "root_id"):   # (plain Python ints in the reference, saved as int64)
+            assert got.dtype == want.dtype, (name, key, got.dtype, want.dtype)
+    # extensions: tables the reference does not have -- inactive in these scenes (no node has a coating or a mesh, no
+    # spectrum is histogram-sampled, no recorder filters by source)
+    for key in ("coat_count", "mesh_face_count", "comp_abs_hist", "comp_ems_hist", "rec_source_mode"):
+        if key in mine:
+            assert not np.any(np.asarray(mine[key])), (name, key)

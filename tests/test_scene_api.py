@@ -2,6 +2,7 @@
 pure-Python tally — the parts of the reference API the hot path sits behind
 (constructor surface of SURVEY.md §8(b))."""
 import functools
+import os
 
 import numpy as np
 import pytest
@@ -567,3 +568,38 @@ def test_lsc_builder_makes_the_scene_the_references_lsc_class_makes():
             assert mine[key].shape == want.shape and np.array_equal(mine[key], want), (name, key)
     assert g["default/names"].tolist() == ["World", "LSC", "Light"]
     assert g["custom/names"].tolist() == ["World", "LSC", "Air Gap Mirror", "Lamp"]
+
+
+def test_engine_result_answers_like_the_references_on_the_same_kernel_output():
+    """tests/golden/engine_result.npz: the reference's whole host pipeline around its kernel -- its `compile_scene`, its
+    `emit_bundle` under a numpy seed, its compiled `_kernel.trace_bundle`, its `EngineResult` / `RecorderResult`
+    (engine/api.py:26-194) -- on the kitchen-sink scene (900 rays, every third with a history).  The product's result
+    object, given the SAME kernel output and the product's tables of the product's twin scene, must answer the same:
+    recorder rays / crossings / mean / std / error of the four properties, histogram edges and counts (1-D and 2-D), event
+    counts, and every history -- Ray fields, source names (light or component), metadata keys and node names."""
+    import importlib.util
+
+    from pvtrace_amd.engine.api import EngineResult
+    from tests import scenes
+    from tests.util import GOLD, load_golden
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)           # (only its describe_engine_result is used: nothing of the reference is touched)
+
+    g = load_golden("engine_result.npz")
+    data = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith("data/")}
+    n, max_events, record_every = (int(v) for v in g["par"])
+    compiled = compile_scene(scenes.kitchen_sink())
+    result = EngineResult(compiled, data, g["sources"].tolist(), max_events, record_every, 0.0)
+    mine = mg.describe_engine_result(result)
+    theirs = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith("ref/")}
+    assert set(mine) == set(theirs), sorted(set(mine) ^ set(theirs))
+    for key, want in theirs.items():
+        got = mine[key]
+        assert got.shape == want.shape, key
+        if want.dtype.kind == "f":
+            assert np.array_equal(got, want, equal_nan=True), key
+        else:
+            assert np.array_equal(got, want), key
+    assert theirs["history_lengths"].sum() > 1000 and len(theirs["recorder_names"]) >= 8
