@@ -559,6 +559,20 @@ def make_compiled_tables():
     save("compiled_tables.npz", **out)
 
 
+def describe_recorders(recorders, moment_properties=("wavelength", "angle", "duration", "pathlength")):
+    """{name: RecorderResult} -> flat {key: array}: counts, mean / std / error of the four properties, histograms."""
+    out, names = {}, []
+    for name, rec in recorders.items():
+        names.append(name)
+        out[f"rec/{name}/counts"] = np.array([rec.rays, rec.crossings], dtype=np.int64)
+        out[f"rec/{name}/stats"] = np.array([[rec.mean(p), rec.std(p), rec.error(p)] for p in moment_properties], dtype=float)
+        for h in range(len(rec.spec.histograms)):
+            for k, part in enumerate(rec.histogram(h)):
+                out[f"rec/{name}/hist{h}/{k}"] = np.asarray(part)
+    out["recorder_names"] = np.array(names or [""])
+    return out
+
+
 def describe_engine_result(result, moment_properties=("wavelength", "angle", "duration", "pathlength")):
     """Everything an `EngineResult` answers (reference api.py:81-194), as a flat {key: array} dict -- the reference's and
     the product's alike (tests/test_scene_api.py imports this function)."""
@@ -628,6 +642,10 @@ def make_engine_result():
     out["par"] = np.array([n, max_events, record_every], dtype=np.int64)
     for k, v in describe_engine_result(result, api.MOMENT_PROPERTIES).items():
         out[f"ref/{k}"] = v
+    # ... and the reference's pure-Python tally of the same histories (engine/tally.py:86-150), recorder by recorder
+    tally = ref_module("pvtrace.engine.tally").tally_histories(full, list(result.histories()))
+    for k, v in describe_recorders(tally, api.MOMENT_PROPERTIES).items():
+        out[f"tally/{k}"] = v
     save("engine_result.npz", **out)
 
 

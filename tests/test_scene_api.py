@@ -603,3 +603,15 @@ def test_engine_result_answers_like_the_references_on_the_same_kernel_output():
         else:
             assert np.array_equal(got, want), key
     assert theirs["history_lengths"].sum() > 1000 and len(theirs["recorder_names"]) >= 8
+    # ... and the pure-Python tally of those histories (reference engine/tally.py:86-150 on the reference's scene) against
+    # the product's tally_histories on the product's twin: counts and histograms exactly, moments to rounding
+    mine = mg.describe_recorders(tally_histories(scenes.kitchen_sink(), list(result.histories())))
+    theirs = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith("tally/")}
+    assert set(mine) == set(theirs)
+    for key, want in theirs.items():
+        got = mine[key]
+        assert got.shape == want.shape, key
+        if want.dtype.kind == "f":
+            assert np.allclose(got, want, rtol=1e-12, atol=0, equal_nan=True), key
+        else:
+            assert np.array_equal(got, want), key
