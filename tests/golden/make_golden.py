@@ -483,6 +483,62 @@ def make_lsc_scenes():
     save("lsc_scenes.npz", **out)
 
 
+LSC_TRACER_RAYS = {"default": 3000, "cells": 3000, "custom": 3000}
+
+
+def make_lsc_tracer():
+    """the reference's per-ray Python tracer (`algorithm/photon_tracer.py follow`) run on the scenes the
+    reference's `LSC` class builds, CALLING the reference's LSC surface delegates (solar cells, back-surface mirror,
+    air-gap mirror, specular and lambertian) at every hit -- the semantic ground truth for what the product lowers to
+    coating tables.  Rays come from the reference's `emit_bundle` under a numpy seed.  Kept: per-ray event counts by
+    kind, the last event's kind, and the position the reference's `LSC.simulate` would store as the exit ray
+    (`device/lsc.py:349-359`: the last ray for ABSORB / KILL, the one before the last for EXIT).  Compared
+    statistically (Welch, 5 sigma) with the C referee and with the GPU engine on the PRODUCT's `LSC` of the same
+    configuration.  Module substitutions as in make_lsc_delegates."""
+    import pvtrace_amd.geometry as prod_geometry
+    import pvtrace_amd.scene as prod_scene
+    from tests import scenes
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "algorithm", "common", "device", "engine"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules["pvtrace.scene.node"] = prod_scene
+    sys.modules["pvtrace.scene.scene"] = prod_scene
+    sys.modules["pvtrace.geometry.box"] = prod_geometry
+    sys.modules.setdefault("pvtrace.scene.renderer", types.SimpleNamespace(MeshcatRenderer=None))
+    lsc = ref_module("pvtrace.device.lsc")
+    light = ref_module("pvtrace.light.light")
+    utils = ref_module("pvtrace.material.utils")
+    emit = ref_module("pvtrace.engine.emit")
+    tracer = ref_module("pvtrace.algorithm.photon_tracer")
+    ray_cls = ref_module("pvtrace.light.ray").Ray
+    event_cls = ref_module("pvtrace.light.event").Event
+    cases = scenes.lsc_tracer_cases(lsc.LSC, utils.cone, light.rectangular_mask, ref_module("pvtrace.data.lumogen_f_red_305"))
+    out = {}
+    for c, (name, device) in enumerate(cases.items()):
+        device._make_scene()
+        full = device._scene
+        view = types.SimpleNamespace(root=full.root, light_nodes=[n for n in full.root.levelorder() if getattr(n, "light", None) is not None])
+        n = LSC_TRACER_RAYS[name]
+        np.random.seed(700 + c)
+        pos, direc, wl, _ = emit.emit_bundle(view, n)
+        counts = np.zeros((n, 10), dtype=np.uint16)
+        last = np.zeros(n, dtype=np.uint8)
+        where = np.zeros((n, 3))
+        for j in range(n):
+            hist = tracer.follow(full, ray_cls(position=tuple(pos[j]), direction=tuple(direc[j]), wavelength=float(wl[j])))
+            for _, event in hist:
+                counts[j, event.value] += 1
+            last[j] = hist[-1][1].value
+            where[j] = hist[-2][0].position if hist[-1][1] == event_cls.EXIT else hist[-1][0].position
+        out.update({f"{name}/counts": counts, f"{name}/last": last, f"{name}/where": where})
+        print("  ", name, "mean events per ray by kind value:", np.round(counts.mean(axis=0), 3).tolist())
+    save("lsc_tracer.npz", **out)
+
+
 def reference_classes_for_scenes():
     """{name in tests/scenes.py: the reference's object of that name} -- geometry (but Box), materials, components, surfaces,
     lights and masks, phase functions, recorders, spectra data -- for building the twins of the test scenes."""
@@ -696,8 +752,13 @@ if __name__ == "__main__":
         make_emit()
         make_lsc_delegates()
         make_lsc_scenes()
+        make_lsc_tracer()
         make_compiled_tables()
         make_engine_result()
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":   # the named generators, e.g. --only make_lsc_tracer
+        for fn in sys.argv[2:]:
+            globals()[fn]()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--tallies":   # only the named config tallies (e.g. --tallies tiles6)
         make_config_tallies(only=sys.argv[2:])
@@ -713,6 +774,7 @@ if __name__ == "__main__":
     make_emit()
     make_lsc_delegates()
     make_lsc_scenes()
+    make_lsc_tracer()
     make_compiled_tables()
     make_engine_result()
     make_traces()

@@ -515,6 +515,18 @@ def lsc_builder_cases(LSC, cone, rectangular_mask, lumogen):
     return {"default": LSC((5.0, 5.0, 1.0)), "custom": custom}
 
 
+def lsc_tracer_cases(LSC, cone, rectangular_mask, lumogen):
+    """The LSC objects of tests/golden/lsc_tracer.npz (per-ray event counts of the reference's Python tracer calling the
+    reference's LSC surface delegates): the two above and the default device with solar cells on all four edges and a
+    back-surface mirror -- SURVEY §8(c)(5)'s case."""
+    cases = lsc_builder_cases(LSC, cone, rectangular_mask, lumogen)
+    cells = LSC((5.0, 5.0, 1.0))
+    cells.add_solar_cell({"left", "right", "near", "far"})
+    cells.add_back_surface_mirror()
+    cases["cells"] = cells
+    return cases
+
+
 def py_tracer_pin_rays(n=300):
     """(directions, wavelengths, numpy seeds) of the rays of that fixture, all from the origin."""
     rng = np.random.default_rng(5)

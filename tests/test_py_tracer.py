@@ -112,6 +112,85 @@ def test_coatings_python_delegates_against_the_coating_tables():
     assert_means_close(py, ref)
 
 
+# -- the REFERENCE's Python tracer calling the REFERENCE's LSC delegates (tests/golden/lsc_tracer.npz) ------------
+def lsc_product_cases():
+    from pvtrace_amd import light as product_light, material as product_material
+    from pvtrace_amd.data import lumogen_f_red_305
+    from pvtrace_amd.device.lsc import LSC
+
+    return scenes.lsc_tracer_cases(LSC, product_material.cone, product_light.rectangular_mask, lumogen_f_red_305)
+
+
+def reference_lsc_counts(g, name):
+    """(n, kinds) in this file's KINDS order from the fixture's by-event-value table."""
+    by_value = g[f"{name}/counts"].astype(float)
+    return np.stack([by_value[:, kind.value] for kind in KINDS], axis=1)
+
+
+def facet_classes(last, where, size):
+    """What the reference's `LSC.simulate` keeps of a ray (device/lsc.py:349-359) put into classes: (last event, facet of
+    the stored exit position) -- facet 0 for a position inside the slab, 1..6 for -x +x -y +y -z +z."""
+    half = 0.5 * np.asarray(size, dtype=float)
+    facet = np.zeros(len(last), dtype=int)
+    for axis in range(3):
+        facet[np.isclose(where[:, axis], -half[axis], atol=1e-6) & (facet == 0)] = 1 + 2 * axis
+        facet[np.isclose(where[:, axis], half[axis], atol=1e-6) & (facet == 0)] = 2 + 2 * axis
+    return last.astype(int) * 8 + facet
+
+
+def data_last_and_where(data, max_events):
+    counts = data["counts"].astype(int)
+    base = np.arange(len(counts)) * max_events
+    last = data["kind"][base + counts - 1]
+    row = np.where(last == Event.EXIT.value, base + counts - 2, base + counts - 1)
+    return last, data["position"][row]
+
+
+def assert_fractions_close(a, b, nsigma=5.0):
+    """Two-sample binomial comparison of every class's share."""
+    for cls in np.union1d(np.unique(a), np.unique(b)):
+        pa, pb = (a == cls).mean(), (b == cls).mean()
+        p = ((a == cls).sum() + (b == cls).sum()) / (len(a) + len(b))
+        se = math.sqrt(max(p * (1 - p), 1e-12) * (1 / len(a) + 1 / len(b)))
+        assert abs(pa - pb) <= nsigma * se + 1e-9, (int(cls) // 8, int(cls) % 8, pa, pb, nsigma * se)
+
+
+LSC_CASE_SIZES = {"default": (5.0, 5.0, 1.0), "cells": (5.0, 5.0, 1.0), "custom": (8.0, 4.0, 0.5)}
+
+
+@pytest.mark.parametrize("name", ["default", "cells", "custom"])
+def test_references_tracer_with_its_lsc_delegates_against_the_coating_tables(name):
+    """SURVEY §8(c)(5).  tests/golden/lsc_tracer.npz: 3 000 rays per device traced by the REFERENCE's
+    `photon_tracer.follow` through the scene the REFERENCE's `LSC` class builds, its `OptionalMirrorAndSolarCell` /
+    `AirGapMirror` delegates called at every hit (solar cells on the edges, back-surface mirror, lambertian air-gap
+    mirror).  The product builds the same device, lowers the delegates to coating tables, and the table-driven path
+    must give the same per-ray event-count means (Welch, 5 sigma) and the same shares of (last event, exit facet)."""
+    from tests.util import load_golden
+
+    g = load_golden("lsc_tracer.npz")
+    device = lsc_product_cases()[name]
+    mine, result = referee_counts(device.scene, 20000, seed=21)
+    assert_means_close(reference_lsc_counts(g, name), mine)
+    last, where = data_last_and_where(result.data, 256)
+    assert_fractions_close(facet_classes(g[f"{name}/last"], g[f"{name}/where"], LSC_CASE_SIZES[name]),
+                           facet_classes(last, where, LSC_CASE_SIZES[name]))
+
+
+@pytest.mark.gpu
+def test_references_tracer_with_its_lsc_delegates_against_the_gpu_engine():
+    from pvtrace_amd import engine
+    from tests.util import load_golden
+
+    g = load_golden("lsc_tracer.npz")
+    for name, device in lsc_product_cases().items():
+        result = engine.simulate(device.scene, 100000, seed=23, max_events=256)
+        assert result.data["counts"].max() < 255
+        assert_means_close(reference_lsc_counts(g, name), table_counts(result.data, 256))
+        last, where = data_last_and_where(result.data, 256)
+        assert_fractions_close(facet_classes(g[f"{name}/last"], g[f"{name}/where"], LSC_CASE_SIZES[name]),
+                               facet_classes(last, where, LSC_CASE_SIZES[name]))
+
+
 @pytest.mark.gpu
 def test_python_tracer_against_the_gpu_engine():
     from pvtrace_amd import engine
