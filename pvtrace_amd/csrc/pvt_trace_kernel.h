@@ -2647,6 +2647,15 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
         atomicAdd(cnt + 1, (unsigned long long)c_steps);
         atomicAdd(cnt + 2, (unsigned long long)c_fused);
     }
+#if PVT_TIMELINE
+    if constexpr (TAIL) {   // (the caller has written the wave's record: word 1 becomes when this function was entered, 4 when it
+                            // returns, 5 gets its trips << 32)
+        if (A.timeline && lane == 0) {
+            unsigned long long* o = A.timeline + ((unsigned long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8;
+            o[1] = tl_t[0]; o[4] = wall_clock64(); o[5] |= tl_iters << 32;
+        }
+    }
+#endif
     if constexpr (TAIL) return;   // (the caller leaves the workgroup)
     // The rest of its photons' histories, when this wave was the last of a draining workgroup (see the drain), then the
     // workgroup's epilogue -- both as FUNCTIONS, called here at the very end: nothing of the loop above is live across either

@@ -20,7 +20,7 @@ while at + 32 <= len(data):
         us = lambda c: (c - t0) / 100.0
         pct = lambda x: " ".join(f"{v:7.1f}" for v in np.percentile(us(x), [0, 5, 50, 95, 100]))
         mhz = w[:, 6].sum() / ((w[:, 4] - w[:, 0]).sum() / 100.0)
-        print(f"launch {launch} grid {grid} n {n}: waves {len(w)} iterations/wave {w[:,5].mean():.1f}; shader clock {mhz:.0f} MHz; "
+        print(f"launch {launch} grid {grid} n {n}: waves {len(w)} iterations/wave {(w[:,5] & 0xffffffff).mean():.1f}; shader clock {mhz:.0f} MHz; "
               f"first step us [min p5 p50 p95 max] {pct(w[:,2])}; cursor dry {pct(w[w[:,3] > 0][:,3])}; end {pct(w[:,4])}")
         # where the waves that end last ran: the HW_ID register (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
         hw = (w[:, 7] >> 32) & 0xffffffff
@@ -49,11 +49,21 @@ while at + 32 <= len(data):
         uniq, cnt = np.unique(key, return_counts=True)
         print(f"   waves ending in the last half of the launch: {late.sum()} on {len(uniq)} distinct SIMDs (max {cnt.max() if len(cnt) else 0} on one), "
               f"{len(np.unique(key // 4))} distinct CUs; SIMD histogram of ALL waves {np.bincount(simd, minlength=4)}, of the late ones {np.bincount(simd[late], minlength=4)}")
+        tail = (w[:, 5] >> 32) > 0   # waves that ran the tail function: word 1 = when it was entered, 5 = its trips << 32 | the loop's
+        if tail.any():
+            trips, enter, leave = (w[tail, 5] >> 32), us(w[tail, 1]), us(w[tail, 4])
+            per = (leave - enter) / np.maximum(trips, 1)
+            order = np.argsort(leave)[::-1][:8]
+            print(f"   tail function: {tail.sum()} waves; entered us [min p5 p50 p95 max] {' '.join(f'{v:7.1f}' for v in np.percentile(enter, [0, 5, 50, 95, 100]))}; "
+                  f"trips [p50 p95 max] {np.percentile(trips, 50):.0f} {np.percentile(trips, 95):.0f} {trips.max()}; us per trip [p5 p50 p95] "
+                  f"{' '.join(f'{v:5.2f}' for v in np.percentile(per[trips >= 8], [5, 50, 95]))}")
+            print("   the last to return: " + "; ".join(f"in {enter[k]:.0f} out {leave[k]:.0f} trips {trips[k]} ({per[k]:.2f} us each), loop trips {w[tail, 5][k] & 0xffffffff}" for k in order))
+        w = w.copy(); w[:, 5] &= 0xffffffff
         end_us = us(w[:, 4])
         for q in (50, 90, 99, 99.9, 100):
             print(f"   end percentile {q}: {np.percentile(end_us, q):.1f} us")
 w = np.concatenate(allw)
-start, end, iters, cyc = w[:, 0], w[:, 4], w[:, 5], w[:, 6]
+start, end, iters, cyc = w[:, 0], w[:, 4], w[:, 5] & 0xffffffff, w[:, 6]
 life_us = (end - start) / 100.0
 span_us = (end.max() - start.min()) / 100.0
 clock_mhz = cyc.sum() / life_us.sum()
