@@ -183,10 +183,12 @@ def test_references_tracer_with_its_lsc_delegates_against_the_gpu_engine():
 
     g = load_golden("lsc_tracer.npz")
     for name, device in lsc_product_cases().items():
-        result = engine.simulate(device.scene, 100000, seed=23, max_events=256)
-        assert result.data["counts"].max() < 255
-        assert_means_close(reference_lsc_counts(g, name), table_counts(result.data, 256))
-        last, where = data_last_and_where(result.data, 256)
+        result = engine.simulate(device.scene, 50000, seed=23, max_events=512)
+        # (a photon in 10^5 is trapped between the mirror and the faces for hundreds of events: the few histories that
+        # fill their rows end in KILL and would only blur the comparison by their own share)
+        assert (result.data["counts"] >= 511).sum() <= 2
+        assert_means_close(reference_lsc_counts(g, name), table_counts(result.data, 512))
+        last, where = data_last_and_where(result.data, 512)
         assert_fractions_close(facet_classes(g[f"{name}/last"], g[f"{name}/where"], LSC_CASE_SIZES[name]),
                                facet_classes(last, where, LSC_CASE_SIZES[name]))
 
