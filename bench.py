@@ -597,7 +597,7 @@ def main():
                 "ms_per_window": dts[len(dts) // 2] * 1e3, "kernel_ms_mean": sum(kms) / len(kms),
                 "launch": other.dscene.launch_info(), "instruction_side": side, "tallies": frac, "sustained": sus,
                 "note": "a fenced window ends with the longest history of its last bundles traced alone (cfg4: photons "
-                        "trapped by total internal reflection for hundreds of steps at ~4 us each, DESIGN.md §6); "
+                        "trapped by total internal reflection until the step limit, ~1 in 10^7: 1000 steps at ~3.8 us each, DESIGN.md §6); "
                         "`sustained` is the same stream without intermediate fences",
             }
         finally:
