@@ -1298,6 +1298,7 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     const bool record = p->record_every > 0;
     // nobody looks at where a photon leaves the scene: the root's distance is only needed to ORDER crossings
     a.lazy_root = (!record && !s->exit_observed && !s->d_bvh) ? s->lazy_root : 0;
+    a.lazy_tail = s->d_bvh ? 0 : s->lazy_root;
     a.fuse_exit = (a.lazy_root && s->fuse_exit) ? 1 : 0;
     a.lazy_k = s->lazy_k;
     if (record) {

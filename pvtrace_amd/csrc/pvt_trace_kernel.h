@@ -191,6 +191,10 @@ struct KArgs {
     // ends (its own step count `count` is what is added), one in the fused exit; summed in LDS when a wave retires, four
     // atomics per workgroup.  null = off.
     unsigned long long* counters;
+    // The tail function's own lazy root (same codes as `lazy_root`, which is 0 when somebody looks at where photons leave
+    // the scene -- an event log, an `exit` recorder): there the root's crossing is skipped only when another crossing is known
+    // to lie before it, and worked out exactly when it is the nearest one -- among a lone wave's few photons hardly ever.
+    int lazy_tail;
 };
 constexpr int kMeshQ = 8;    // leaves a lane notes before its triangles are tested
 constexpr int kCarryBase = 14;     // u64 words of a parked photon before its seen-mask
@@ -716,6 +720,9 @@ struct Seen {
 #ifndef PVT_TAIL_HOIST
 #define PVT_TAIL_HOIST 1   // (0: a developer build whose tail function reads the hit node's record where the kernels' loop does)
 #endif
+#ifndef PVT_TAIL_LAZY
+#define PVT_TAIL_LAZY 1   // (0: a developer build whose tail function intersects the root wherever the kernels' loop does)
+#endif
 #ifndef PVT_TAIL_ALPHA
 #define PVT_TAIL_ALPHA 1   // (0: a developer build whose tail function looks the absorption coefficients up in every step)
 #endif
@@ -811,12 +818,17 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
     // Launch constants that the loop only asks yes/no questions of, in ONE scalar register.  Kept as separate
     // conditions each becomes a 64-bit lane mask that the allocator holds (spills) for the whole loop; `uf(bit)`
     // re-derives the answer from the word where it is asked (the empty asm keeps the compiler from hoisting it).
-    enum { UF_COATED = 0, UF_FUSE_EXIT, UF_CRIT, UF_HAS_REC, UF_TQ_POS, UF_BINS_LDS, UF_EMIT_FULL, UF_EMIT_KT, UF_LAZY1, UF_LAZY2, UF_BY_NODE };
-    const unsigned int uflags =
+    enum { UF_COATED = 0, UF_FUSE_EXIT, UF_CRIT, UF_HAS_REC, UF_TQ_POS, UF_BINS_LDS, UF_EMIT_FULL, UF_EMIT_KT, UF_LAZY1, UF_LAZY2, UF_BY_NODE,
+           UF_TAIL_LAZY1, UF_TAIL_LAZY2 };
+    unsigned int uflags_ =
         (A.n_coat > 0 ? 1u << UF_COATED : 0u) | (A.fuse_exit != 0 ? 1u << UF_FUSE_EXIT : 0u) | (L.crit_d >= 0 ? 1u << UF_CRIT : 0u) |
         (A.n_rec > 0 ? 1u << UF_HAS_REC : 0u) | (A.tq_pos ? 1u << UF_TQ_POS : 0u) | (A.bins_in_lds ? 1u << UF_BINS_LDS : 0u) |
         (A.emit_method == PVT_EMIT_FULL ? 1u << UF_EMIT_FULL : 0u) | (A.emit_method == PVT_EMIT_KT ? 1u << UF_EMIT_KT : 0u) |
         (A.lazy_root == 1 ? 1u << UF_LAZY1 : 0u) | (A.lazy_root == 2 ? 1u << UF_LAZY2 : 0u) | (L.by_node ? 1u << UF_BY_NODE : 0u);
+    if constexpr (TAIL && PVT_TAIL_LAZY) {   // (only where the launch itself has no lazy root: see KArgs::lazy_tail)
+        if (A.lazy_root == 0) uflags_ |= (A.lazy_tail == 1 ? 1u << UF_TAIL_LAZY1 : 0u) | (A.lazy_tail == 2 ? 1u << UF_TAIL_LAZY2 : 0u);
+    }
+    const unsigned int uflags = uflags_;
     auto uf = [&](int bit) -> bool {
         unsigned int f = uflags;
         asm volatile("" : "+s"(f));
@@ -1477,7 +1489,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
                 // compare the crossings they have with a cheap lower bound of the root's distance -- the
                 // distance to the root's nearest face -- and only the lanes it cannot decide for pay for the
                 // root's intersection; in a typical scene (a 5 cm slab in a 5 m world) none ever does.
-                const int lazy_root = (MESH || RECORD) ? 0 : (uf(UF_LAZY1) ? 1 : (uf(UF_LAZY2) ? 2 : 0));   // wave-uniform (tally launches only)
+                // (tail function: also where exits are looked at -- `lazy_exact`: the root's own distance is worked out whenever
+                // it is the nearest crossing, i.e. the photon leaves the scene)
+                const bool lazy_exact = TAIL && PVT_TAIL_LAZY && !MESH && (uf(UF_TAIL_LAZY1) || uf(UF_TAIL_LAZY2));
+                const int lazy_root = MESH ? 0 : (lazy_exact ? (uf(UF_TAIL_LAZY1) ? 1 : 2)
+                                                              : (RECORD ? 0 : (uf(UF_LAZY1) ? 1 : (uf(UF_LAZY2) ? 2 : 0))));   // wave-uniform
                 // Grid scenes fold a crossing by the key (t, node): what the reference's first-minimum scans over its hit
                 // list (nodes ascending) come to, whatever the order the nodes are visited in.  Written as selects of
                 // VALUES: as branches that assign, the compiler merges the assignments into stores through a selected
@@ -1602,7 +1618,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
                                 bound = (g0 * g0 - dot3(o, o)) * A.lazy_k;
                             }
                             const bool undecided = !(bound > 0.0) || (nhits > 0 && !(t1 < bound)) || (nhits >= 2 && !(t2 < bound)) ||
-                                                   (cnode >= 0 && !(cbest < bound));
+                                                   (cnode >= 0 && !(cbest < bound)) || (lazy_exact && nhits == 0);
                             {   // one more crossing, behind all the others: nearest only if there is no other
                                 const double a1 = t1, a2 = t2;
                                 const int m1 = n1, m2 = n2, have = nhits, cn = cnode;
@@ -1728,7 +1744,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
                         bound = (radius * radius - dot3(o, o)) * A.lazy_k;
                     }
                     const bool undecided = !(bound > 0.0) || (nhits > 0 && !(t1 < bound)) || (nhits >= 2 && !(t2 < bound)) ||
-                                           (cnode >= 0 && !(cbest < bound));
+                                           (cnode >= 0 && !(cbest < bound)) || (lazy_exact && nhits == 0);
                     if (!undecided) {
                         // one more crossing, behind all the others: nearest only if there is no other
                         if (nhits == 0) { t1 = bound; n1 = node; }
