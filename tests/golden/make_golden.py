@@ -24,6 +24,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True   # the reference tree is read-only to this project: importing from it must not leave __pycache__ there
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
