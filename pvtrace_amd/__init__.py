@@ -18,3 +18,4 @@ from pvtrace_amd.scene import Node, Scene
 from pvtrace_amd import engine
 from pvtrace_amd.device.lsc import LSC
 from pvtrace_amd import spec
+from pvtrace_amd.algorithm import photon_tracer

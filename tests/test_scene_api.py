@@ -615,3 +615,31 @@ def test_engine_result_answers_like_the_references_on_the_same_kernel_output():
             assert np.allclose(got, want, rtol=1e-12, atol=0, equal_nan=True), key
         else:
             assert np.array_equal(got, want), key
+
+
+def test_photon_tracer_entry_points_shape_a_history_like_the_references(monkeypatch):
+    """`pvtrace_amd.photon_tracer.step_forward` / `follow` (reference algorithm/photon_tracer.py:112-328) around a history the
+    engine would return -- no GPU here, the history is injected: first metadata None, `follow` drops metadata, and the
+    path-length rule (:162-172) ends the photon with KILL, the ray as it stood, at the first step entered beyond the limit."""
+    from pvtrace_amd import photon_tracer
+    from pvtrace_amd.light import Event, Ray
+
+    def ray(t):
+        return Ray(position=(0.0, 0.0, t), direction=(0.0, 0.0, 1.0), wavelength=555.0, travelled=t, source="Light")
+
+    injected = [(ray(0.0), Event.GENERATE, {}), (ray(1.0), Event.TRANSMIT, {"hit": "slab", "container": "world", "adjacent": "slab"}),
+                (ray(1.5), Event.ABSORB, {"component": "dye", "container": "slab"}), (ray(1.5), Event.EMIT, {"component": "dye", "container": "slab"}),
+                (ray(3.0), Event.REFLECT, {"hit": "slab", "container": "slab", "adjacent": "world"}),
+                (ray(4.0), Event.TRANSMIT, {"hit": "slab", "container": "slab", "adjacent": "world"}),
+                (ray(9.0), Event.EXIT, {"hit": "world", "container": "world", "adjacent": None})]
+    monkeypatch.setattr(photon_tracer, "_history", lambda *a, **k: list(injected))
+    steps = list(photon_tracer.step_forward(None, ray(0.0)))
+    assert steps[0] == (ray(0.0), Event.GENERATE, None) and [e for _, e, _ in steps] == [e for _, e, _ in injected]
+    assert photon_tracer.follow(None, ray(0.0)) == [(r, e) for r, e, _ in injected]
+    cut = photon_tracer.follow(None, ray(0.0), maxpathlength=1.2)
+    # travelled 1.5 at ABSORB does not end a step; the EMIT row does, and the next step is entered at 1.5 > 1.2
+    assert [e for _, e in cut] == [Event.GENERATE, Event.TRANSMIT, Event.ABSORB, Event.EMIT, Event.KILL] and cut[-1][0] == ray(1.5)
+    killed = list(photon_tracer.step_forward(None, ray(0.0), maxpathlength=3.5))[-1]
+    assert killed[1] == Event.KILL and killed[2] == {"maxpathlength": 4.0, "container": "world"}
+    # a limit only the closing row exceeds changes nothing (the reference checks at the START of a step)
+    assert photon_tracer.follow(None, ray(0.0), maxpathlength=8.0) == [(r, e) for r, e, _ in injected]
