@@ -190,3 +190,14 @@ def test_event_record_layout_round_trips_on_the_host():
     assert C.sizeof(native.PvtEventRecords) == 16
     text = open(HEADER).read()
     assert "typedef struct PvtEventRecords" in text and "_kernel.pyx:1035-1047" in text
+
+
+def test_the_build_module_of_the_reference_has_its_counterpart():
+    """reference `python -m pvtrace.engine.build` (engine/build.py; engine/__init__.py:11-13 tells users to run it): the same
+    module name here runs the in-tree HIP build (a no-op when the library is newer than its sources)."""
+    import importlib
+
+    mod = importlib.import_module("pvtrace_amd.engine.build")
+    mod.main()
+    from pvtrace_amd.engine import native
+    assert native.library_built()
