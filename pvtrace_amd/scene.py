@@ -11,6 +11,7 @@ import numpy as np
 
 from pvtrace_amd.common import AppError
 from pvtrace_amd.geometry import Transformable
+from pvtrace_amd.light import Event
 
 
 class Intersection(object):
@@ -210,6 +211,21 @@ class Node(Transformable):
             yield ray
 
 
+def is_end_ray(event, metadata):
+    """An "end ray": a ray generated, entering, leaving or reflected from a node, or ended (reference
+    pvtrace/scene/scene.py:32-58) -- what `Scene.simulate(..., queue=q, end_rays=True)` sends to the queue."""
+    if event in (Event.EMIT, Event.SCATTER, Event.ABSORB):
+        return False
+    if event in (Event.GENERATE, Event.NONRADIATIVE, Event.REACT, Event.KILL, Event.EXIT):
+        return True
+    if event in (Event.REFLECT, Event.TRANSMIT):
+        if metadata["hit"] == metadata["adjacent"]:
+            return True    # reflected from, or transmitted into, a node
+        if metadata["hit"] == metadata["container"] and event == Event.TRANSMIT:
+            return True    # escaped a node
+    return False
+
+
 class Scene(object):
     """A scene graph of nodes rooted at `root`."""
 
@@ -250,13 +266,41 @@ class Scene(object):
         crossings = [x.to(self.root) for x in self.root.intersections(ray_origin, ray_direction)]
         return tuple(sorted(crossings, key=lambda x: x.distance))
 
-    def simulate(self, num_rays, workers=None, seed=None, **kwargs):
-        """Trace on the MI355X engine; returns an `EngineResult`.  Positional order as in the
-        reference (num_rays, workers, seed); `workers` is accepted and ignored (no CPU tracing threads).
+    def simulate(self, num_rays, workers=None, seed=None, queue=None, end_rays=False, maxsteps=1000, emit_method="kT"):
+        """Emit `num_rays` from the lights and return the list of ray histories, each `[(Ray, Event), ...]` -- the
+        reference's contract (pvtrace/scene/scene.py:197-313: `len(results) == num_rays`, equal results for equal
+        `seed`, a `ValueError` for a seed with several workers).  The reference fans its Python tracer over a process
+        pool; here the rays are traced by the engine on the GPU, 8 192 at a time with room for every event of a
+        history, and the histories are rebuilt on the host -- for the engine's own result object (recorder tallies,
+        packed logs, 10^6+ rays) call `engine.simulate(scene, num_rays, ...)` instead.
 
-        (The reference's Scene.simulate, pvtrace/scene/scene.py:197-313, fans the
-        Python tracer over a process pool; here the device engine is the tracer.)
-        """
+        `workers` only decides, as in the reference, whether a `seed` is allowed (it is for one worker: the seed
+        re-seeds numpy's generator, which samples the lights and names the kernel's streams).  `queue`: every event goes
+        to the queue as `(pid, ray index, Ray, Event, metadata)` instead of being returned (`end_rays`: only the events
+        `is_end_ray` keeps, :32-58); the call then returns the pid, like the reference's worker."""
+        import multiprocessing
+        import os
+
         from pvtrace_amd import engine
 
-        return engine.simulate(self, num_rays, seed=seed, workers=workers, **kwargs)
+        if workers is None:
+            workers = max(1, multiprocessing.cpu_count() // 2)
+        if workers != 1 and num_rays // workers > 0 and seed is not None:
+            raise ValueError("Seed must be None to ensure different quasi-random sequences in each process")
+        if seed is not None:
+            np.random.seed(seed)
+        results, pid, done = [], os.getpid(), 0
+        while done < num_rays:
+            n = min(8192, num_rays - done)
+            result = engine.simulate(self, n, seed=None, maxsteps=maxsteps, max_events=2 * int(maxsteps) + 8,
+                                     emit_method=emit_method, record_every=1, emission="host", packed_log=True)
+            for k, history in enumerate(result.histories()):
+                if queue is None:
+                    results.append([(ray, event) for ray, event, _ in history])
+                    continue
+                for ray, event, metadata in history:
+                    metadata = None if event == Event.GENERATE else metadata
+                    if not end_rays or is_end_ray(event, metadata):
+                        queue.put((pid, done + k, ray, event, metadata))
+            done += n
+        return pid if queue is not None else results

@@ -689,3 +689,55 @@ def test_photon_tracer_follow_traces_ray_by_ray_like_the_references_loop():
     aged = dataclasses.replace(rays[0], travelled=2.5, duration=1e-9)
     h0, h1 = photon_tracer.follow(scene, rays[0], seed=7), photon_tracer.follow(scene, aged, seed=7)
     assert [e for _, e in h0] == [e for _, e in h1] and h1[-1][0].travelled == h0[-1][0].travelled + 2.5
+
+
+# -- Scene.simulate: the reference's tests of it (tests/test_scene.py:20-182), one by one ---------------------------------
+def reference_scene_of_test_scene():
+    import functools
+    from pvtrace_amd import Box, Light, Material, Node, Scene, Sphere, cone
+
+    world = Node(name="world (air)", geometry=Sphere(radius=50.0, material=Material(refractive_index=1.0)))
+    Node(name="sphere (glass)", geometry=Box((10.0, 10.0, 1.0), material=Material(refractive_index=1.5)), parent=world)
+    light = Node(name="Light (555nm)", light=Light(direction=functools.partial(cone, np.pi / 16)), parent=world)
+    light.rotate(np.radians(60), (1.0, 0.0, 0.0))
+    return Scene(world)
+
+
+def test_scene_simulate_keeps_the_references_contract():
+    import os
+    import queue as queue_mod
+
+    RAYS = max(16, os.cpu_count())
+    scene = reference_scene_of_test_scene()
+    for workers in (1, None):                                   # :129-137
+        results = scene.simulate(RAYS, workers=workers)
+        assert isinstance(results, list) and len(results) == RAYS, "Missing simulation results"
+    for history in results:                                     # each a list of (Ray, Event), GENERATE first
+        assert history[0][1] == Event.GENERATE and history[-1][1] in (Event.EXIT, Event.KILL)
+        assert all(len(item) == 2 for item in history)
+    r1, r2 = scene.simulate(RAYS, workers=1, seed=1), scene.simulate(RAYS, workers=1, seed=1)   # :139-143
+    assert r1 == r2, "Simulation should be identical"
+    with pytest.raises(ValueError):                             # :145-157
+        scene.simulate(RAYS, workers=os.cpu_count() if os.cpu_count() > 1 else 2, seed=1)
+    assert scene.simulate(RAYS, workers=1, seed=1) != scene.simulate(RAYS, workers=1, seed=2)     # :159-163
+    assert scene.simulate(RAYS, workers=os.cpu_count()) != scene.simulate(RAYS, workers=os.cpu_count())   # :165-169
+    assert scene.simulate(RAYS) != scene.simulate(RAYS)         # :171-175
+    assert scene.simulate(1) != scene.simulate(1)               # :177-181
+    # the queue form (:60-89): every event, or only the "end rays", as (pid, index, Ray, Event, metadata); returns the pid
+    q = queue_mod.Queue()
+    pid = scene.simulate(RAYS, workers=1, seed=5, queue=q)
+    items = []
+    while not q.empty():
+        items.append(q.get())
+    direct = scene.simulate(RAYS, workers=1, seed=5)
+    assert pid == os.getpid() and len(items) == sum(len(h) for h in direct)
+    assert sorted({i[1] for i in items}) == list(range(RAYS)) and items[0][3] == Event.GENERATE and items[0][4] is None
+    assert [(i[2], i[3]) for i in items if i[1] == 3] == direct[3]
+    q = queue_mod.Queue()
+    scene.simulate(RAYS, workers=1, seed=5, queue=q, end_rays=True)
+    kept = []
+    while not q.empty():
+        kept.append(q.get())
+    from pvtrace_amd.scene import is_end_ray
+    assert 0 < len(kept) <= len(items) and all(is_end_ray(i[3], i[4]) for i in kept)
+    assert len(kept) == sum(1 for i in items if is_end_ray(i[3], i[4]))

@@ -643,3 +643,20 @@ def test_photon_tracer_entry_points_shape_a_history_like_the_references(monkeypa
     assert killed[1] == Event.KILL and killed[2] == {"maxpathlength": 4.0, "container": "world"}
     # a limit only the closing row exceeds changes nothing (the reference checks at the START of a step)
     assert photon_tracer.follow(None, ray(0.0), maxpathlength=8.0) == [(r, e) for r, e, _ in injected]
+
+
+def test_scene_simulate_refuses_a_seed_with_several_workers_and_classifies_end_rays():
+    """reference tests/test_scene.py:145-157 (a seed with several workers raises ValueError -- decided before anything is
+    traced, so no GPU is needed to see it) and scene/scene.py:32-58 (`is_end_ray`)."""
+    from pvtrace_amd.light import Event
+    from pvtrace_amd.scene import is_end_ray
+
+    scene = scenes.fresnel_box()
+    with pytest.raises(ValueError, match="Seed must be None"):
+        scene.simulate(64, workers=4, seed=1)
+    assert not is_end_ray(Event.ABSORB, {}) and not is_end_ray(Event.EMIT, {}) and not is_end_ray(Event.SCATTER, {})
+    assert all(is_end_ray(e, None) for e in (Event.GENERATE, Event.NONRADIATIVE, Event.REACT, Event.KILL, Event.EXIT))
+    into = {"hit": "slab", "container": "world", "adjacent": "slab"}
+    out_of = {"hit": "slab", "container": "slab", "adjacent": "world"}
+    assert is_end_ray(Event.TRANSMIT, into) and is_end_ray(Event.REFLECT, into) and is_end_ray(Event.TRANSMIT, out_of)
+    assert not is_end_ray(Event.REFLECT, out_of)   # total internal reflection inside a node: not an end ray
