@@ -36,4 +36,5 @@ with Session(scene, emission="host") as session:   # (optional: keeps the scene 
 print(f"Took {time.time() - start_t:.2f}s to trace 100 rays.")
 print(f"Got {len(results)} ray histories")
 reflected = sum(1 for history in results if history[1][1] == Event.REFLECT)
-print(f"{reflected} of them were reflected off the top face at 60 degrees (Fresnel: ~9 %)")
+print(f"{reflected} of them were reflected at their first hit (the light sits INSIDE the glass, as in the reference's example: "
+      f"60 degrees is beyond the critical angle of 41.8, so all of them are)")
