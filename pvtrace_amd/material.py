@@ -11,6 +11,7 @@ answers.
 """
 import abc
 import math
+from dataclasses import replace
 
 import numpy as np
 
@@ -72,43 +73,43 @@ def thermodynamic_emission(abs_spec, T=300, mu=0.5):
     return np.column_stack((spec[:, 0], emission / np.max(emission)))
 
 
-def spherical_to_cart(theta, phi, r=1.0):
-    st = np.sin(theta)
-    cart = np.column_stack((r * st * np.cos(phi), r * st * np.sin(phi), r * np.cos(theta)))
+def spherical_to_cart(theta, phi, r=1):
+    cart = np.column_stack((r * np.sin(theta) * np.cos(phi), r * np.sin(theta) * np.sin(phi), r * np.cos(theta)))
     return cart[0, :] if cart.size == 3 else cart
 
 
 # ----------------------------------------------------------------------
 # Phase functions / angular distributions (reference material/utils.py:104-186).
 # The engine recognises these by identity / type and samples them on the
-# device; calling them directly draws from numpy's global generator.
+# device; calling them directly draws from numpy's global generator -- with numpy's
+# own arccos / arcsin / sin / cos, as the reference's do: under one numpy seed the
+# two packages return the same directions to the last bit (tests/golden/object_methods.npz).
 
 def isotropic():
     g1, g2 = np.random.uniform(0, 1, 2)
-    return spherical_to_cart(math.acos(2.0 * g2 - 1.0), 2.0 * math.pi * g1)
+    return spherical_to_cart(np.arccos(2 * g2 - 1), 2 * np.pi * g1)
 
 
 def henyey_greenstein(g=0.0):
     p = np.random.uniform(0, 1)
     if abs(g) < 2.220446049250313e-13:
         return isotropic()
-    s = 2.0 * p - 1.0
-    mu = (1.0 + g * g - ((1.0 - g * g) / (1.0 + g * s)) ** 2) / (2.0 * g)
-    phi = 2.0 * math.pi * np.random.uniform()
-    return spherical_to_cart(math.acos(mu), phi)
+    s = 2 * p - 1
+    mu = 1 / (2 * g) * (1 + g ** 2 - ((1 - g ** 2) / (1 + g * s)) ** 2)
+    phi = 2 * np.pi * np.random.uniform()
+    return spherical_to_cart(np.arccos(mu), phi)
 
 
 def cone(theta_max):
-    if np.isclose(theta_max, 0.0) or theta_max > math.pi / 2:
+    if np.isclose(theta_max, 0.0) or theta_max > np.pi / 2:
         raise ValueError("Expected 0 < theta_max <= pi/2")
     p1, p2 = np.random.uniform(0, 1, 2)
-    theta = math.asin(math.sqrt(p1) * math.sin(theta_max))
-    return spherical_to_cart(theta, 2.0 * math.pi * p2)
+    return spherical_to_cart(np.arcsin(np.sqrt(p1) * np.sin(theta_max)), 2 * np.pi * p2)
 
 
 def lambertian():
     p1, p2 = np.random.uniform(0, 1, 2)
-    return spherical_to_cart(math.asin(math.sqrt(p1)), 2.0 * math.pi * p2)
+    return spherical_to_cart(np.arcsin(np.sqrt(p1)), 2 * np.pi * p2)
 
 
 class HenyeyGreenstein(object):
@@ -389,6 +390,31 @@ class Surface(object):
     def delegate(self):
         return self._delegate
 
+    # The per-interaction verbs of the reference's Python tracer (surface.py:224-272), for code that steps rays itself:
+    # one uniform draw from numpy's global generator decides, the delegate supplies reflectivity and directions.  (The
+    # engine does not call these: it lowers the delegate to tables, `engine/compiler.py`.)
+    def is_reflected(self, ray, geometry, container, adjacent):
+        r = self.delegate.reflectivity(self, ray, geometry, container, adjacent)
+        if not isinstance(r, (int, float)):
+            raise ValueError("Reflectivity must be a number.")
+        if r == 0.0:
+            return False   # (no draw: keeps a seeded sequence in step with the reference's)
+        return bool(np.random.uniform() < r)
+
+    def _turned(self, ray, which, *where):
+        direction = getattr(self.delegate, which)(self, ray, *where)
+        if not isinstance(direction, tuple):
+            raise ValueError(f"Delegate method `{which}` should return a tuple.")
+        if len(direction) != 3:
+            raise ValueError(f"Delegate method `{which}` should return a tuple of length 3.")
+        return replace(ray, direction=direction)
+
+    def reflect(self, ray, geometry, container, adjacent):
+        return self._turned(ray, "reflected_direction", geometry, container, adjacent)
+
+    def transmit(self, ray, geometry, container, adjacent):
+        return self._turned(ray, "transmitted_direction", geometry, container, adjacent)
+
 
 # ----------------------------------------------------------------------
 # Volume components (reference material/component.py:33-440)
@@ -397,6 +423,12 @@ class Component(object):
     def __init__(self, name="Component"):
         super(Component, self).__init__()
         self.name = name
+
+    def is_radiative(self, ray):
+        return False
+
+    def nonradiative_absorb(self, ray):
+        return ray
 
 
 class Scatterer(Component):
@@ -449,6 +481,20 @@ class Scatterer(Component):
     def coefficient(self, wavelength):
         return self._abs_dist(wavelength)
 
+    # What happens to an absorbed ray, one numpy draw per decision in the reference's order (component.py:168-196):
+    def is_radiative(self, ray):
+        return bool(np.random.uniform() < self.quantum_yield)
+
+    def nonradiative_absorb(self, ray):
+        """The ray as it ends: with `tau_nr` set its clock runs on by an exponentially distributed delay."""
+        if self.tau_nr:
+            return replace(ray, duration=ray.duration - np.log(1 - np.random.uniform()) * self.tau_nr)
+        return ray
+
+    def emit(self, ray, **kwargs):
+        """Scattered: a new direction from the phase function (in the frame the ray is given in), the scatterer as source."""
+        return replace(ray, direction=self.phase_function(), source=self.name)
+
 
 class Absorber(Scatterer):
     """Non-radiative absorber (quantum yield 0)."""
@@ -464,6 +510,9 @@ class Absorber(Scatterer):
             hist=hist,
             name=name,
         )
+
+    def is_radiative(self, ray):
+        return False   # (and no draw, as in the reference, component.py:236-239)
 
 
 class Reactor(Absorber):
@@ -512,6 +561,27 @@ class Luminophore(Scatterer):
         else:
             raise ValueError("Luminophore `emission` arg has wrong type.")
 
+    def emit(self, ray, method="kT", T=300.0, **kwargs):
+        """Re-emitted (reference component.py:381-440; draws in its order: phase function, wavelength, delay): a new
+        direction, a wavelength from the emission spectrum above the point `method` allows -- "kT": from 3/2 kT (at `T` K)
+        above the absorbed photon's energy, "redshift": from the absorbed wavelength, "full": the whole spectrum -- and,
+        with `tau_rad` set, an exponentially distributed emission delay.  Like the reference's it raises when "kT" lands
+        outside the spectrum's range; the engine clamps there (differences between the two tracers)."""
+        direction = self.phase_function()
+        nm = ray.wavelength
+        if method == "kT":
+            nm = 1240.0 / (1240.0 / nm + 3 / 2 * KB_EV * T)
+            start = self._ems_dist.lookup(nm)
+        elif method == "redshift":
+            start = self._ems_dist.lookup(nm)
+        elif method == "full":
+            start = 0.0
+        else:
+            raise ValueError(f"emit method {method!r}: use 'kT', 'redshift' or 'full'")
+        wavelength = self._ems_dist.sample(np.random.uniform(start, 1.0))
+        delay = -np.log(1 - np.random.uniform()) * self.tau_rad if self.tau_rad else 0.0
+        return replace(ray, direction=direction, wavelength=wavelength, source=self.name, duration=ray.duration + delay)
+
 
 class Material(object):
     def __init__(self, refractive_index, surface=None, components=None):
@@ -521,3 +591,29 @@ class Material(object):
 
     def total_attenutation_coefficient(self, wavelength):
         return float(np.sum([c.coefficient(wavelength) for c in self.components]))
+
+    # The volume decisions of the reference's Python tracer (material.py:22-63), one numpy draw each:
+    def penetration_depth(self, wavelength):
+        """How far a photon of this wavelength gets before something absorbs it: exponential with the summed
+        coefficient; inf for a clear medium, 0 for an opaque one."""
+        alpha = self.total_attenutation_coefficient(wavelength)
+        if np.isclose(alpha, 0.0):
+            return float("inf")
+        if not np.isfinite(alpha):
+            return 0.0
+        return -np.log(1 - np.random.uniform()) / alpha
+
+    def is_absorbed(self, ray, full_distance):
+        """(absorbed before `full_distance`?, the sampled depth)"""
+        depth = self.penetration_depth(ray.wavelength)
+        return (depth < full_distance, depth)
+
+    def component(self, wavelength):
+        """Which component took the photon: each in proportion to its coefficient at this wavelength."""
+        weights = np.array([c.coefficient(wavelength) for c in self.components])
+        if np.any(weights < 0.0):
+            raise ValueError("Must be positive.")
+        steps = np.cumsum(weights)
+        ladder = np.hstack([0, steps / max(steps)])
+        at = np.interp(np.random.uniform(), ladder, list(range(len(self.components) + 1)))
+        return self.components[int(np.floor(at))]

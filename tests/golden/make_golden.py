@@ -541,6 +541,32 @@ def make_lsc_tracer():
     save("lsc_tracer.npz", **out)
 
 
+def make_object_methods():
+    """The per-interaction methods of the reference's host objects -- `Material.penetration_depth / is_absorbed / component`
+    (material/material.py:22-63), `Scatterer / Absorber / Luminophore .is_radiative / nonradiative_absorb / emit`
+    (material/component.py:168-196, :236-239, :381-440), `Surface.is_reflected / reflect / transmit` (material/surface.py:
+    224-272) -- called in a fixed order under numpy seeds by `tests/scenes.py::object_method_script`; the product's classes
+    run the same script and must return the same numbers, bit for bit (tests/test_golden_units.py).  All of these modules
+    import without third-party packages but for `light/ray.py`, which names the anytree-based Node: the product's stands there."""
+    import pvtrace_amd.scene as prod_scene
+    from tests import scenes
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "common", "engine"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules.setdefault("pvtrace.scene.node", prod_scene)   # (light/ray.py names Node for `representation`, unused here)
+    c = types.SimpleNamespace(**{k: v for k, v in reference_classes_for_scenes().items()
+                                 if k in ("Material", "Absorber", "Scatterer", "Reactor", "Luminophore", "Surface",
+                                          "NullSurfaceDelegate", "Sphere", "cone")})
+    c.henyey_greenstein = ref_module("pvtrace.material.utils").henyey_greenstein
+    c.Ray = ref_module("pvtrace.light.ray").Ray
+    c.lumogen = ref_module("pvtrace.data.lumogen_f_red_305")
+    save("object_methods.npz", **scenes.object_method_script(c))
+
+
 def reference_classes_for_scenes():
     """{name in tests/scenes.py: the reference's object of that name} -- geometry (but Box), materials, components, surfaces,
     lights and masks, phase functions, recorders, spectra data -- for building the twins of the test scenes."""
@@ -755,6 +781,7 @@ if __name__ == "__main__":
         make_lsc_delegates()
         make_lsc_scenes()
         make_lsc_tracer()
+        make_object_methods()
         make_compiled_tables()
         make_engine_result()
         sys.exit(0)
@@ -777,6 +804,7 @@ if __name__ == "__main__":
     make_lsc_delegates()
     make_lsc_scenes()
     make_lsc_tracer()
+    make_object_methods()
     make_compiled_tables()
     make_engine_result()
     make_traces()

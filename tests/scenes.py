@@ -620,3 +620,67 @@ def bose_fluro_red_sample(depth=0.26):
                   wavelength=SpectrumWavelengthMask(Distribution(x, lamp)),
                   position=RectangularMask(l / 2, w / 2))
     return lsc
+
+
+def object_method_script(c):
+    """The per-interaction methods of the host objects (reference material/material.py:22-63, component.py:168-196, :381-440,
+    surface.py:224-272) called in a fixed order under numpy seeds -> {name: array}.  `c`: a namespace with Material, Absorber,
+    Scatterer, Reactor, Luminophore, Surface, NullSurfaceDelegate, Sphere, Ray, henyey_greenstein, cone and the lumogen
+    spectra module -- the product's classes in the test, the reference's in tests/golden/make_golden.py."""
+    import functools
+    import types
+
+    x = np.arange(400.0, 801.0, 1.0)
+    dye = c.Luminophore(np.column_stack((x, c.lumogen.absorption(x) * 8.0)), np.column_stack((x, c.lumogen.emission(x))),
+                        quantum_yield=0.9, tau_rad=6e-9, tau_nr=2e-9, phase_function=functools.partial(c.henyey_greenstein, 0.4), name="dye")
+    host = c.Absorber(0.3, tau_nr=1e-9, name="host")
+    haze = c.Scatterer(np.column_stack((x, 0.2 + 0.001 * (x - 400.0))), quantum_yield=0.8, phase_function=functools.partial(c.cone, 0.5), name="haze")
+    react = c.Reactor(0.05, name="react")
+    material = c.Material(1.5, components=[dye, host, haze, react])
+    clear = c.Material(1.0)
+    out = {}
+    np.random.seed(2024)
+    wls = np.random.uniform(450.0, 700.0, 40)
+    rays = [c.Ray(position=(0.1 * k, 0.0, 0.0), direction=(0.0, 0.0, 1.0), wavelength=float(w), duration=1e-10 * k) for k, w in enumerate(wls)]
+    np.random.seed(7)
+    out["depth"] = np.array([material.penetration_depth(float(w)) for w in wls])
+    out["clear_depth"] = np.array([clear.penetration_depth(555.0)])
+    absorbed = [material.is_absorbed(r, 0.8) for r in rays]
+    out["absorbed"] = np.array([float(a) for a, _ in absorbed])
+    out["absorbed_at"] = np.array([d for _, d in absorbed])
+    names = ["dye", "host", "haze", "react"]
+    out["component"] = np.array([names.index(material.component(float(w)).name) for w in wls])
+    for comp in (dye, host, haze, react):
+        out[f"{comp.name}_radiative"] = np.array([float(comp.is_radiative(r)) for r in rays])
+        out[f"{comp.name}_ended_duration"] = np.array([comp.nonradiative_absorb(r).duration for r in rays])
+    for method in ("kT", "redshift", "full"):
+        new = [dye.emit(r, method=method) for r in rays if r.wavelength > 460.0]
+        out[f"dye_emit_{method}"] = np.array([list(n.direction) + [n.wavelength, n.duration] for n in new])
+        assert all(n.source == "dye" for n in new)
+    new = [haze.emit(r) for r in rays]
+    out["haze_emit"] = np.array([list(n.direction) + [n.wavelength, n.duration] for n in new])
+    assert all(n.source == "haze" for n in new)
+    # surfaces: a glass ball in air, rays meeting it from outside and from inside
+    ball = c.Sphere(radius=1.0, material=material)
+    inside = types.SimpleNamespace(geometry=types.SimpleNamespace(material=types.SimpleNamespace(refractive_index=1.5)))
+    outside = types.SimpleNamespace(geometry=types.SimpleNamespace(material=types.SimpleNamespace(refractive_index=1.0)))
+    rng = np.random.default_rng(3)
+    decisions, turned = [], []
+    for k in range(60):
+        p = rng.normal(size=3); p /= np.linalg.norm(p)
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        leaving = k % 2 == 0
+        if (np.dot(d, p) > 0) != leaving:
+            d = -d
+        ray = c.Ray(position=tuple(p.tolist()), direction=tuple(d.tolist()), wavelength=555.0)
+        where = (ball, inside, outside) if leaving else (ball, outside, inside)
+        surface = material.surface
+        hit = surface.is_reflected(ray, *where)
+        decisions.append(float(hit))
+        turned.append(list((surface.reflect(ray, *where) if hit else surface.transmit(ray, *where)).direction))
+    out["surface_reflected"] = np.array(decisions)
+    out["surface_direction"] = np.array(turned)
+    null = c.Surface(delegate=c.NullSurfaceDelegate())
+    ray = c.Ray(position=(0.0, 0.0, 1.0), direction=(0.0, 0.6, 0.8), wavelength=555.0)
+    out["null"] = np.array([float(null.is_reflected(ray, ball, inside, outside))] + list(null.transmit(ray, ball, inside, outside).direction))
+    return out

@@ -270,3 +270,32 @@ def test_recorder_vocabulary_is_the_references():
         assert str(err.value) == doc["refused"][key], key
     r = R.Recorder("r")
     assert (r.event, r.atol, r.facet) == (doc["defaults"]["event"], doc["defaults"]["atol"], doc["defaults"]["facet"])
+
+
+def test_host_objects_make_the_references_decisions_under_the_same_numpy_seeds():
+    """tests/golden/object_methods.npz: the reference's `Material.penetration_depth / is_absorbed / component`
+    (material/material.py:22-63), its components' `is_radiative / nonradiative_absorb / emit` (component.py:168-196, :236-239,
+    :381-440: HG and cone phase functions, kT / redshift / full re-emission, radiative and non-radiative lifetimes) and its
+    `Surface.is_reflected / reflect / transmit` (surface.py:224-272) on a glass ball, called in a fixed order under numpy
+    seeds.  The product's classes run the same script (tests/scenes.py::object_method_script): same draws in the same order,
+    so the same numbers, bit for bit -- what code that steps rays itself through these objects relies on."""
+    import types
+
+    import pvtrace_amd as P
+    from pvtrace_amd.data import lumogen_f_red_305
+    from tests import scenes
+    from tests.util import load_golden
+
+    g = load_golden("object_methods.npz")
+    c = types.SimpleNamespace(Material=P.Material, Absorber=P.Absorber, Scatterer=P.Scatterer, Reactor=P.Reactor,
+                              Luminophore=P.Luminophore, Surface=P.Surface, NullSurfaceDelegate=P.NullSurfaceDelegate,
+                              Sphere=P.Sphere, Ray=P.Ray, henyey_greenstein=P.henyey_greenstein, cone=P.cone,
+                              lumogen=lumogen_f_red_305)
+    mine = scenes.object_method_script(c)
+    assert set(mine) == set(g.files)
+    for key in g.files:
+        assert mine[key].shape == g[key].shape and np.array_equal(mine[key], g[key]), key
+    # the fixture has teeth: both outcomes of every decision occur
+    assert 0 < g["surface_reflected"].mean() < 1 and 0 < g["dye_radiative"].mean() < 1 and g["host_radiative"].sum() == 0
+    assert len(np.unique(g["component"])) == 4 and np.isinf(g["clear_depth"][0])
+    assert (g["host_ended_duration"] > 0).all() and np.array_equal(g["react_ended_duration"], g["react_ended_duration"])
