@@ -128,6 +128,12 @@ class Geometry(object):
     def _ray_distances(self, o, d):
         raise NotImplementedError
 
+    def is_on_surface(self, point):
+        raise NotImplementedError
+
+    def contains(self, point):
+        raise NotImplementedError
+
     def normal(self, point):
         raise NotImplementedError
 

@@ -60,6 +60,14 @@ def bandgap(x, cutoff, alpha):
     return (1 - np.heaviside(x - cutoff, 0.5)) * alpha
 
 
+def simple_convert_spectum(spec):
+    """(n, 2) spectrum with its x column turned from nanometres into electron-volts or back (E [eV] = hc/q 10^9 / nm is
+    its own inverse); the y column untouched.  (The reference's helper of this -- misspelt -- name, material/utils.py:59-69.)"""
+    out = np.array(spec)
+    out[:, 0] = (6.62607015e-34 * 299792458.0 / 1.60217662e-19 * 1e9) / out[:, 0]
+    return out
+
+
 def thermodynamic_emission(abs_spec, T=300, mu=0.5):
     """Emission line shape in detailed balance with an absorption spectrum (generalised Planck
     law): `abs_spec` is an (n, 2) array of (nm, absorptance); returns (nm, emission) normalised to
@@ -381,7 +389,28 @@ class CoatedSurfaceDelegate(FresnelSurfaceDelegate):
         )
 
 
-class Surface(object):
+class BaseSurface(abc.ABC):
+    """What a material's surface answers (reference material/surface.py:180-203): its delegate, and the three verbs."""
+
+    @property
+    @abc.abstractmethod
+    def delegate(self):
+        """An object that implements `SurfaceDelegate`."""
+
+    @abc.abstractmethod
+    def is_reflected(self, ray, geometry, container, adjacent):
+        """True when the ray is reflected."""
+
+    @abc.abstractmethod
+    def reflect(self, ray, geometry, container, adjacent):
+        """The reflected ray."""
+
+    @abc.abstractmethod
+    def transmit(self, ray, geometry, container, adjacent):
+        """The transmitted ray."""
+
+
+class Surface(BaseSurface):
     def __init__(self, delegate=None):
         super(Surface, self).__init__()
         self._delegate = FresnelSurfaceDelegate() if delegate is None else delegate

@@ -226,6 +226,16 @@ def is_end_ray(event, metadata):
     return False
 
 
+def do_simulation(scene, num_rays, seed):
+    """One worker's share (reference scene/scene.py:20-30): its numpy generator re-seeded, `num_rays` histories returned."""
+    return scene.simulate(num_rays, workers=1, seed=seed)
+
+
+def do_simulation_add_to_queue(scene, num_rays, seed, queue, end_rays):
+    """The same with every event put on `queue` (reference :60-89); returns the pid."""
+    return scene.simulate(num_rays, workers=1, seed=seed, queue=queue, end_rays=end_rays)
+
+
 class Scene(object):
     """A scene graph of nodes rooted at `root`."""
 
@@ -241,6 +251,12 @@ class Scene(object):
         if self.root is None:
             return []
         return [n for n in self.root.levelorder() if isinstance(n.light, Light)]
+
+    def finalise_nodes(self):
+        """The reference refreshes the nodes' bounding boxes here before tracing (scene/scene.py:99-120; its renderer and its
+        Python tracer's culling use them).  Nothing is cached on the nodes here -- the scene is flattened anew whenever it
+        is traced -- so there is nothing to refresh; kept so that code written against the reference runs."""
+        return None
 
     @property
     def component_nodes(self):
