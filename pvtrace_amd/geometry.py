@@ -134,7 +134,7 @@ class Geometry(object):
     def contains(self, point):
         raise NotImplementedError
 
-    def normal(self, point):
+    def normal(self, surface_point):
         raise NotImplementedError
 
     def is_entering(self, surface_point, direction):
@@ -183,7 +183,8 @@ class Box(Geometry):
         inside = np.all(p <= half + EPS_ZERO)
         return bool(inside and np.any(np.abs(p - half) < EPS_ZERO))
 
-    def normal(self, point):
+    def normal(self, surface_point):
+        point = surface_point
         p = np.asarray(point, dtype=np.float64)
         best, out = math.inf, (0.0, 0.0, 0.0)
         for a in range(3):
@@ -223,7 +224,8 @@ class Sphere(Geometry):
         r = math.sqrt(float(np.sum(np.asarray(point, dtype=np.float64) ** 2)))
         return abs(r - self.radius) < EPS_ZERO
 
-    def normal(self, point):
+    def normal(self, surface_point):
+        point = surface_point
         p = np.asarray(point, dtype=np.float64)
         return tuple((p / math.sqrt(float(np.dot(p, p)))).tolist())
 
@@ -273,7 +275,8 @@ class Cylinder(Geometry):
         on_side = abs(r - self.radius) < EPS_ZERO and abs(p[2]) <= half + EPS_ZERO
         return bool(on_cap or on_side)
 
-    def normal(self, point):
+    def normal(self, surface_point):
+        point = surface_point
         p = np.asarray(point, dtype=np.float64)
         half = 0.5 * self.length
         tol = 1e-8 + 1e-5 * abs(half)
@@ -391,11 +394,13 @@ class Mesh(Geometry):
     def is_on_surface(self, point):
         return bool(self._closest_face(point)[0] < EPS_ZERO)
 
-    def normal(self, point):
+    def normal(self, surface_point):
+        point = surface_point
         dist, face = self._closest_face(point)
         if not dist < EPS_ZERO:
             raise GeometryError("Point is not on surface.")
         return tuple(self.face_normals[face].tolist())
 
-    def is_entering(self, point, direction):
+    def is_entering(self, surface_point, direction):
+        point = surface_point
         return bool(np.dot(self.normal(point), np.asarray(direction, dtype=np.float64)) < 0.0)
