@@ -26,6 +26,77 @@ def _unit(v):
     return v / math.sqrt(float(np.dot(v, v)))
 
 
+# ----------------------------------------------------------------------
+# Small vector and tolerance helpers (the names of reference geometry/utils.py:364-440): what hand-written surface
+# delegates are written with -- `flip`, `angle_between` and friends; `EPS_ZERO` is the one tolerance everything shares.
+
+def close_to_zero(value):
+    """Every component within EPS_ZERO of zero (strictly)."""
+    return bool(np.all(np.absolute(value) < EPS_ZERO))
+
+
+def floats_close(a, b):
+    return close_to_zero(a - b)
+
+
+def distance_between(point1, point2):
+    return float(np.linalg.norm(np.subtract(point1, point2)))
+
+
+def points_equal(point1, point2):
+    return close_to_zero(distance_between(point1, point2))
+
+
+def allinrange(x, x_range):
+    """No value of `x` (a number or an array) lies outside the closed interval `x_range`."""
+    values = np.atleast_1d(np.asarray(x))
+    return not bool(np.any((values < x_range[0]) | (values > x_range[1])))
+
+
+def flip(vector):
+    return -np.array(vector)
+
+
+def magnitude(vector):
+    v = np.array(vector)
+    return np.sqrt(np.dot(v, v))
+
+
+def norm(vector):
+    return np.array(vector) / np.linalg.norm(vector)
+
+
+def angle_between(normal, vector):
+    """Angle in radians between two UNIT vectors; exactly 0 and pi for (numerically) parallel and anti-parallel ones."""
+    a, b = np.array(normal), np.array(vector)
+    if np.allclose(a, b):
+        return 0.0
+    if np.allclose(-a, b):
+        return np.pi
+    return np.arccos(np.dot(a, b))
+
+
+def smallest_angle_between(normal, vector):
+    rads = angle_between(normal, vector)
+    return np.arctan2(np.sin(rads), np.cos(rads))
+
+
+def intersection_point_is_ahead(ray_position, ray_direction, intersection_point):
+    """A point ON the ray's line lies ahead of its origin by more than EPS_ZERO."""
+    return bool(np.dot(ray_direction, intersection_point) - np.dot(ray_direction, ray_position) > EPS_ZERO)
+
+
+def ray_z_cylinder(length, radius, ray_origin, ray_direction):
+    """(points, distances) of a ray with a capped cylinder along z, centred on the origin, nearest first -- the return form
+    of the reference's helper of this name (geometry/utils.py:131-362); the crossings are `Cylinder`'s (the kernel's
+    arithmetic, distance > EPS_ZERO), `([], [])` for a miss."""
+    o, d = np.asarray(ray_origin, dtype=np.float64), np.asarray(ray_direction, dtype=np.float64)
+    distances = sorted(Cylinder(length, radius)._ray_distances(o, d))
+    if not distances:
+        return ([], [])
+    return tuple(tuple((o + t * d).tolist()) for t in distances), tuple(float(t) for t in distances)
+
+
 def translation_matrix(vector):
     m = np.identity(4)
     m[:3, 3] = np.asarray(vector, dtype=np.float64)[:3]

@@ -85,3 +85,31 @@ def test_distribution_end_points_and_step_tables():              # tests/test_di
     assert 0.0 <= step.lookup(nmmin) <= step.lookup(nmmin + spacing) and step.lookup(nmmax) == 1.0
     values = step.sample(np.linspace(step.lookup(599 - spacing), step.lookup(600 + spacing), 10000))
     assert len(set(np.asarray(values).tolist())) == 3
+
+
+def test_vector_and_tolerance_helpers_known_answers():           # tests/test_geometry_utils.py:24-62
+    from pvtrace_amd.geometry import (EPS_ZERO, allinrange, angle_between, close_to_zero, distance_between, flip, floats_close,
+                                      intersection_point_is_ahead, magnitude, norm, points_equal, ray_z_cylinder,
+                                      smallest_angle_between)
+
+    zero = 0.0
+    assert close_to_zero(zero) and close_to_zero(zero + 0.9 * EPS_ZERO) and close_to_zero(zero - 0.9 * EPS_ZERO)
+    assert not close_to_zero(zero + EPS_ZERO) and not close_to_zero(zero - EPS_ZERO)
+    a = 0.3711
+    assert not floats_close(a, a + EPS_ZERO) and not floats_close(a, a - EPS_ZERO)
+    assert floats_close(a, a + 0.9 * EPS_ZERO) and floats_close(a, a - 0.9 * EPS_ZERO) and floats_close(a, a)
+    v = (1.0, 1.0, 1.0)
+    assert np.isclose(magnitude(v), np.sqrt(3.0)) and np.allclose(norm(v), np.array(v) / magnitude(v))
+    normal, vector = norm((1.0, 0.0, 0.0)), norm((1.0, 0.0, 0.0))
+    assert angle_between(normal, vector) == 0.0 and angle_between(-normal, vector) == np.pi
+    assert np.isclose(angle_between(norm((1.0, 1.0, 0.0)), norm((1.0, 0.0, 0.0))), np.pi / 4.0)
+    v1, v2 = norm((1.0, 1.0, 0.0)), norm((-1.0, 0.0, 0.0))
+    assert np.dot(v1, v2) < 0.0 and np.isclose(angle_between(v1, v2), np.pi - np.pi / 4.0)
+    assert np.isclose(smallest_angle_between(v1, v2), np.pi - np.pi / 4.0)
+    assert np.array_equal(flip((1.0, -2.0, 0.0)), (-1.0, 2.0, 0.0)) and distance_between((0, 0, 0), (3, 4, 0)) == 5.0
+    assert points_equal((1.0, 2.0, 3.0), (1.0, 2.0, 3.0 + 0.5 * EPS_ZERO)) and not points_equal((1.0, 2.0, 3.0), (1.0, 2.0, 3.1))
+    assert allinrange(np.array([1.0, 2.0]), (1.0, 2.0)) and not allinrange(2.5, (1.0, 2.0)) and allinrange(1.5, (1.0, 2.0))
+    assert intersection_point_is_ahead((0, 0, 0), (0, 0, 1), (0, 0, 2)) and not intersection_point_is_ahead((0, 0, 0), (0, 0, 1), (0, 0, -2))
+    points, distances = ray_z_cylinder(1.0, 1.0, (0.2, 0.2, -1), unit((0, 0, 1.0)))     # :63-101, both caps
+    assert np.allclose(points, ((0.2, 0.2, -0.5), (0.2, 0.2, 0.5))) and np.allclose(distances, (0.5, 1.5))
+    assert ray_z_cylinder(1.0, 1.0, (5.0, 5.0, -1.0), unit((0, 0, 1.0))) == ([], [])
