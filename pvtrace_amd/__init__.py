@@ -19,3 +19,6 @@ from pvtrace_amd import engine
 from pvtrace_amd.device.lsc import LSC
 from pvtrace_amd import spec
 from pvtrace_amd.algorithm import photon_tracer
+from pvtrace_amd import compat as _compat
+
+_compat._register("pvtrace_amd")   # `pvtrace_amd.material.surface`, `pvtrace_amd.geometry.utils` ...: the reference's module paths (compat.py)

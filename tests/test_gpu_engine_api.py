@@ -741,3 +741,47 @@ def test_scene_simulate_keeps_the_references_contract():
     from pvtrace_amd.scene import is_end_ray
     assert 0 < len(kept) <= len(items) and all(is_end_ray(i[3], i[4]) for i in kept)
     assert len(kept) == sum(1 for i in items if is_end_ray(i[3], i[4]))
+
+
+def test_a_script_written_for_the_reference_runs_unchanged_after_compat_install():
+    """After `pvtrace_amd.compat.install()` the package answers to `pvtrace` with the reference's module layout: the body of
+    this script is written in the reference's vocabulary only (its README quick start, examples/hello_box.py and the LSC
+    notebook's calls: `from pvtrace import *`, `scene.simulate`, `photon_tracer.follow`, `LSC(...).simulate / report`,
+    `pvtrace.engine.simulate` with recorders) and runs on the engine, in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+
+    script = r"""
+import pvtrace_amd.compat; pvtrace_amd.compat.install()
+# ---- from here on: a user's script for the reference --------------------------------------------------------
+import functools
+import numpy as np
+from pvtrace import *
+from pvtrace.material.utils import cone
+from pvtrace.engine import simulate, Recorder, Histogram
+
+world = Node(name="world (air)", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+sphere = Node(name="sphere (glass)", geometry=Sphere(radius=1.0, material=Material(refractive_index=1.5)), parent=world)
+sphere.location = (0, 0, 2)
+light = Node(name="Light (555nm)", light=Light(direction=functools.partial(cone, np.pi / 8)), parent=world)
+scene = Scene(world)
+np.random.seed(0)
+results = scene.simulate(40, workers=1)
+assert len(results) == 40 and all(h[-1][1] == Event.EXIT for h in results)
+for ray in scene.emit(10):
+    steps = photon_tracer.follow(scene, ray, maxsteps=10)
+    assert steps[0][1] == Event.GENERATE
+sphere.recorders = [Recorder("entering", event="entering", histograms=[Histogram("angle", 0.0, np.pi / 2, 9)])]
+result = simulate(scene, 200000, seed=1, record_every=0)
+assert 0.4 < result.recorders["entering"].rays / 200000 < 1.0
+
+lsc = LSC((5.0, 5.0, 1.0))
+lsc.add_solar_cell({"left", "right"})
+lsc.simulate(20000)
+summary = lsc.summary()
+assert 0.0 < float(summary["Optical Efficiency"]) < 1.0
+print("ok")
+"""
+    done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert done.returncode == 0 and done.stdout.strip().endswith("ok"), (done.stdout[-500:], done.stderr[-2000:])

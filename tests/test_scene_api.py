@@ -660,3 +660,62 @@ def test_scene_simulate_refuses_a_seed_with_several_workers_and_classifies_end_r
     out_of = {"hit": "slab", "container": "slab", "adjacent": "world"}
     assert is_end_ray(Event.TRANSMIT, into) and is_end_ray(Event.REFLECT, into) and is_end_ray(Event.TRANSMIT, out_of)
     assert not is_end_ray(Event.REFLECT, out_of)   # total internal reflection inside a node: not an end ray
+
+
+def test_the_references_module_paths_import_and_the_package_can_answer_to_its_name():
+    """`pvtrace_amd.compat`: every module path of the reference on the traced path and around it resolves to the module
+    here that holds its names, under `pvtrace_amd.` always and under `pvtrace.` after `compat.install()` -- in a fresh
+    interpreter, so that this process keeps no `pvtrace` of ours."""
+    import subprocess
+    import sys
+
+    from pvtrace_amd.material.surface import FresnelSurfaceDelegate, SurfaceDelegate   # noqa: F401
+    from pvtrace_amd.geometry.utils import angle_between, flip                          # noqa: F401
+    from pvtrace_amd.light.light import Light, rectangular_mask                         # noqa: F401
+    from pvtrace_amd.scene.node import Node as by_path
+    from pvtrace_amd import Node
+    assert by_path is Node
+
+    script = r"""
+import sys
+import pvtrace_amd.compat
+pvtrace_amd.compat.install()
+from pvtrace import *
+from pvtrace.material.utils import cone, isotropic, lambertian, henyey_greenstein
+from pvtrace.material.surface import SurfaceDelegate, FresnelSurfaceDelegate, NullSurfaceDelegate, Surface
+from pvtrace.material.component import Luminophore, Absorber, Scatterer, Reactor
+from pvtrace.material.distribution import Distribution
+from pvtrace.material.material import Material
+from pvtrace.geometry.utils import flip, angle_between, EPS_ZERO, norm
+from pvtrace.geometry.sphere import Sphere
+from pvtrace.geometry.box import Box
+from pvtrace.geometry.cylinder import Cylinder
+from pvtrace.geometry.mesh import Mesh
+from pvtrace.light.light import Light, rectangular_mask, CircularMask
+from pvtrace.light.ray import Ray
+from pvtrace.light.event import Event
+from pvtrace.scene.node import Node
+from pvtrace.scene.scene import Scene
+from pvtrace.algorithm import photon_tracer
+from pvtrace.data import lumogen_f_red_305, fluro_red
+from pvtrace.device.lsc import LSC
+from pvtrace.engine import simulate, simulate_stream, compile_scene, Recorder, Histogram, Heatmap, UnsupportedSceneError, is_available
+from pvtrace.engine.api import EngineResult
+from pvtrace.common.errors import AppError
+import pvtrace
+assert pvtrace is sys.modules["pvtrace_amd"] and pvtrace.engine.compile_scene is compile_scene
+world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+Node(name="ball", parent=world, geometry=Sphere(radius=1.0, material=Material(refractive_index=1.5)))
+Node(name="light", parent=world, light=Light(direction=lambda: cone(0.3)))
+assert compile_scene(Scene(world)).node_names == ["world", "ball"]
+try:
+    from pvtrace.scene.renderer import MeshcatRenderer
+except ImportError:
+    print("ok")
+"""
+    done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert done.returncode == 0 and done.stdout.strip() == "ok", done.stderr[-2000:]
+    # a different package already imported under the name is not shadowed unless asked
+    script = "import types, sys; sys.modules['pvtrace'] = types.ModuleType('pvtrace')\nimport pvtrace_amd.compat as c\ntry:\n    c.install()\nexcept ImportError:\n    c.install(force=True); import pvtrace; print(pvtrace.__name__)"
+    done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert done.returncode == 0 and done.stdout.strip() == "pvtrace_amd", done.stderr[-2000:]
