@@ -396,6 +396,16 @@ class LSC(object):
             total = total + recs[name].histogram(0)[1]
         return edges, total
 
+    def show(self, wireframe=True, baubles=True, bauble_radius=None, world_segment="short", short_length=None,
+             open_browser=False):
+        """The reference opens its meshcat renderer here (device/lsc.py:301-336) and draws the ray paths of the next
+        `simulate` into it.  There is no renderer in this package (the visualiser is outside the traced path): the call is
+        accepted, so that a notebook written for the reference runs on, and says so once."""
+        import warnings
+
+        warnings.warn("pvtrace_amd has no renderer: LSC.show() draws nothing (histories of a few rays: "
+                      "engine.simulate(lsc.scene, n).histories())", stacklevel=2)
+
     def report(self):
         print("\nSimulation Report\n-----------------\n\nSurface Counts:")
         print(self.counts())
