@@ -67,6 +67,21 @@ class AirGapMirror(CoatedSurfaceDelegate):
         return [Coating(normal, reflectivity=1.0, reflection=mode) for normal in FACETS.values()]
 
 
+class Spectrum(np.ndarray):
+    """Wavelengths in nm, one per ray, reconstructed from a histogram: every ray at the centre of its bin.  `edges` (n + 1)
+    and `counts` (n) are the histogram it came from, exact."""
+
+    def __new__(cls, edges, counts):
+        edges, counts = np.asarray(edges, dtype=np.float64), np.asarray(counts)
+        obj = np.repeat(0.5 * (edges[:-1] + edges[1:]), counts.astype(np.int64)).view(cls)
+        obj.edges, obj.counts = edges, counts
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.edges = getattr(obj, "edges", None)
+        self.counts = getattr(obj, "counts", None)
+
+
 class LSC(object):
     """Abstraction of a luminescent solar concentrator (high-level API)."""
 
@@ -320,8 +335,10 @@ class LSC(object):
 
     def spectrum(self, facets=set(), kind="last", source="all", events=None):
         """Wavelength spectrum of the rays the reference's `LSC.spectrum` would select (lsc.py:505-566): same arguments,
-        same validation, same errors -- but on recorder tallies, so the answer is `(bin edges, counts)` (5 nm bins over the
-        LSC's wavelength range), not a per-ray series.
+        same validation, same errors, and like the reference's a sequence of wavelengths with ONE ENTRY PER SELECTED RAY
+        (`len(lsc.spectrum(...))` counts rays, `plt.hist(lsc.spectrum(...), bins=...)` plots them) -- answered from
+        recorder tallies, so a ray's wavelength is known to its 5 nm bin and stands at the bin's centre; the histogram
+        itself is exact and rides along as `.edges` / `.counts` (`Spectrum`).
 
         The reference keeps two rows per photon: its `kind="first"` row (the first event after generation: the photon
         transmitted into, or reflected off, a facet) and its `kind="last"` row (the photon when it was lost, or at its
@@ -394,7 +411,7 @@ class LSC(object):
             if not stands_for <= want_sources:
                 continue
             total = total + recs[name].histogram(0)[1]
-        return edges, total
+        return Spectrum(edges, total)
 
     def show(self, wireframe=True, baubles=True, bauble_radius=None, world_segment="short", short_length=None,
              open_browser=False):
