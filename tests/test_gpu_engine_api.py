@@ -777,6 +777,14 @@ for ray in scene.emit(10):
 sphere.recorders = [Recorder("entering", event="entering", histograms=[Histogram("angle", 0.0, np.pi / 2, 9)])]
 result = simulate(scene, 200000, seed=1, record_every=0)
 assert 0.4 < result.recorders["entering"].rays / 200000 < 1.0
+# (the README's own spelling of the two imports, and its recorder on the world)
+from pvtrace.algorithm import photon_tracer as tracer_again
+import pvtrace.engine as engine
+assert tracer_again is photon_tracer
+world.recorders = [Recorder("escaped", event="exit", histograms=[Histogram("wavelength", 400, 800, 40)])]
+result = engine.simulate(scene, 100000)
+escaped = result.recorders["escaped"]
+assert escaped.rays == 100000 and round(escaped.mean("wavelength"), 1) == 555.0 and result.elapsed > 0
 
 lsc = LSC((5.0, 5.0, 1.0))
 lsc.add_solar_cell({"left", "right"})
