@@ -11,14 +11,15 @@ and the aliases are registered so that both spellings import:
     from pvtrace import *                                                # ... and a script written for the reference runs
     from pvtrace.geometry.utils import flip, angle_between               #     on the engine unchanged
 
-What is not there is not aliased: `pvtrace.scene.renderer` (meshcat), `pvtrace.cli`, `pvtrace.studio` raise ImportError as any
-missing module does."""
+What is not there is not aliased: `pvtrace.scene.renderer` (meshcat), `pvtrace.cli.main` and the rest of the command-line tool
+(`pvtrace.cli.parse.parse`, the scene-spec reader, is), `pvtrace.studio` raise ImportError as any missing module does."""
 import importlib
 import sys
 
 # reference module path (below the package) -> module here (below pvtrace_amd)
 LAYOUT = {
     "algorithm": "algorithm", "algorithm.photon_tracer": "algorithm.photon_tracer",
+    "cli": "spec", "cli.parse": "spec",   # (only the scene-spec parser, `parse(filename) -> Scene`; the command-line tool itself is not here)
     "common": "common", "common.errors": "common",
     "data": "data", "data.lumogen_f_red_305": "data.lumogen_f_red_305", "data.fluro_red": "data.fluro_red",
     "device": "device", "device.lsc": "device.lsc",

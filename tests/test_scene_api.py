@@ -702,12 +702,18 @@ from pvtrace.device.lsc import LSC
 from pvtrace.engine import simulate, simulate_stream, compile_scene, Recorder, Histogram, Heatmap, UnsupportedSceneError, is_available
 from pvtrace.engine.api import EngineResult
 from pvtrace.common.errors import AppError
+from pvtrace.cli.parse import parse
 import pvtrace
 assert pvtrace is sys.modules["pvtrace_amd"] and pvtrace.engine.compile_scene is compile_scene
 world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
 Node(name="ball", parent=world, geometry=Sphere(radius=1.0, material=Material(refractive_index=1.5)))
 Node(name="light", parent=world, light=Light(direction=lambda: cone(0.3)))
 assert compile_scene(Scene(world)).node_names == ["world", "ball"]
+spec = {"version": "1.0", "nodes": {"world": {"sphere": {"radius": 10.0, "material": {"refractive-index": 1.0}}},
+                                    "slab": {"record": True, "box": {"size": [5, 5, 1], "material": {"refractive-index": 1.5}}},
+                                    "laser": {"location": [0, 0, 3], "direction": [0, 0, -1], "light": {"wavelength": 555}}}}
+names = {r.name for n in parse(spec).root.preorder() for r in n.recorders}     # (reference tests/test_engine.py:374-415)
+assert len(names) == 7 and {"slab-top", "slab-lost"} <= names
 try:
     from pvtrace.scene.renderer import MeshcatRenderer
 except ImportError:
