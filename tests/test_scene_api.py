@@ -725,3 +725,13 @@ except ImportError:
     script = "import types, sys; sys.modules['pvtrace'] = types.ModuleType('pvtrace')\nimport pvtrace_amd.compat as c\ntry:\n    c.install()\nexcept ImportError:\n    c.install(force=True); import pvtrace; print(pvtrace.__name__)"
     done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert done.returncode == 0 and done.stdout.strip() == "pvtrace_amd", done.stderr[-2000:]
+
+
+def test_intersection_objects_known_answers():               # reference tests/test_intersection.py:14-23
+    from pvtrace_amd import Node
+    from pvtrace_amd.geometry.intersection import Intersection     # (the reference's module path: pvtrace_amd.compat)
+
+    inter1 = Intersection(coordsys=Node, hit=Node, point=(0.0, 0.0, 0.0), distance=0.0)
+    inter2 = Intersection(coordsys=Node, hit=Node, point=(0.0, 0.0, 0.0), distance=0.0)
+    assert type(inter1) == Intersection and inter1 == inter2
+    assert inter1 != Intersection(coordsys=Node, hit=Node, point=(0.0, 0.0, 1.0), distance=1.0)
