@@ -795,42 +795,3 @@ print("ok")
 """
     done = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert done.returncode == 0 and done.stdout.strip().endswith("ok"), (done.stdout[-500:], done.stderr[-2000:])
-
-
-def test_the_references_flux_comparison_test_as_it_is_written():
-    """reference tests/test_3D_flux_comparison.py:10-106 (skipped there: "takes too long"), its fixture and its three tests
-    in its own calls -- `LSC(...)`, a lamp with callable wavelength / position delegates (sampled on the host here),
-    `simulate(throw, emit_method='redshift')`, `len(lsc.spectrum(...))` ratios against 0.25 / 0.64 / 0.11 (atol 0.04) --
-    with 100 000 rays instead of 300."""
-    from pvtrace_amd import Distribution, rectangular_mask
-    from pvtrace_amd.data import fluro_red
-
-    x = np.arange(400, 801, dtype=float)
-    size = (l, w, d) = (4.8, 1.8, 0.250)
-    lsc = LSC(size, wavelength_range=x)
-    lsc.add_luminophore("Fluro Red", np.column_stack((x, fluro_red.absorption(x) * 11.387815)),
-                        np.column_stack((x, fluro_red.emission(x))), quantum_yield=0.95)
-    lsc.add_absorber("PMMA", 0.02)
-
-    def lamp_spectrum(x):
-        def g(x, a, p, w):
-            return a * np.exp(-(((p - x) / w) ** 2))
-        return (g(x, 0.53025700136646192, 512.91400020614333, 93.491838802960473)
-                + g(x, 0.63578999789955015, 577.63100003089369, 66.031706473985736))
-
-    lamp_dist = Distribution(x, lamp_spectrum(x))
-    wavelength_callable = lambda: lamp_dist.sample(np.random.uniform())     # noqa: E731
-    position_callable = lambda: rectangular_mask(l / 2, w / 2)             # noqa: E731
-    lsc.add_light("Oriel Lamp + Filter", (0.0, 0.0, 0.5 * d + 0.01), rotation=(np.radians(180), (1, 0, 0)),
-                  wavelength=wavelength_callable, position=position_callable)
-    np.random.seed(12)
-    throw = 100000
-    lsc.simulate(throw, emit_method="redshift")
-    incident = float(len(lsc.spectrum(source={"Oriel Lamp + Filter"}, kind="first", facets={"top"})))
-    edge = len(lsc.spectrum(facets={"left", "right", "near", "far"}, source="all"))
-    assert np.isclose(edge / incident, 0.25, atol=0.04)
-    escape = len(lsc.spectrum(facets={"top", "bottom"}, source="all"))
-    assert np.isclose(escape / incident, 0.64, atol=0.04)
-    lost = len(lsc.spectrum(source="all", events={"absorb"}))
-    assert np.isclose(lost / incident, 0.11, atol=0.04)
-    assert incident == throw

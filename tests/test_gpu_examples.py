@@ -9,8 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,says", [("hello_world.py", "first recorded history"), ("hello_box.py", "Got 100 ray histories"),
-                                         ("lsc.py", "Optical Efficiency"), ("mesh_gem.py", None)])
+@pytest.mark.parametrize("script,says", [("hello_world.py", "first recorded history"), ("lsc.py", "Optical Efficiency"), ("mesh_gem.py", None)])
 def test_example_runs(script, says):
     done = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)], capture_output=True, text=True, cwd=ROOT,
                           timeout=600)
