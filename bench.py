@@ -24,8 +24,9 @@ Its operative bound is FP64 VALU issue (`bound`, `frac` = VALU busy while the la
 overlap); the HBM figure the metric asks for sits beside it in `roofline.hbm`:
 achieved = 56 algorithmic bytes/photon x photons per launch / mean launch duration
 (HIP events on the launch stream) against 8 TB/s, with the PMC-measured traffic.
-`roofline.steps_per_photon` and `roofline.lane_utilisation` are counted by the kernel
-itself during the timed windows (pvt_scene_counters), not read from a profile.  `configs` holds the same
+`roofline.steps_per_photon`, `roofline.live_lane_fraction` and the shader clock in the VALU-busy figure are counted /
+read by the kernel itself during the timed windows (pvt_scene_counters, pvt_scene_clock), not taken from a profile;
+`instruction_side.stale` says whether the committed PMC pass was sampled on the device code loaded now.  `configs` holds the same
 measurement for BASELINE configs[3] (nested_cylinders) and configs[4] (coated slab +
 scatterer) at 10^7 photons per GPU, pipelined, device-side emission.
 `cpu_baseline` times the CPU referee (a port of the reference kernel, proven
@@ -174,6 +175,22 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+_CODE_HASH = []
+
+
+def built_code_hash():
+    """sha256 (16 hex digits) of the .text section of the gfx950 code object in the built library -- what
+    tools/code_hash.sh prints; None when the LLVM binutils are not there."""
+    if not _CODE_HASH:
+        try:
+            import __graft_entry__ as entry
+
+            _CODE_HASH.append(entry.code_hash())
+        except Exception:   # noqa: BLE001
+            _CODE_HASH.append(None)
+    return _CODE_HASH[0]
+
+
 def live_counters(counters, photons):
     """What the kernel counted itself during the timed windows (pvt_scene_counters: two scalar adds per wave and trip of
     the photon loop, always on): trips per photon, the reference's loop count per photon, lanes holding a live photon."""
@@ -186,11 +203,11 @@ def live_counters(counters, photons):
         "lane_steps_per_photon": counters["lane_steps"] / photons,              # ... of which run (the rest: fused exits)
         "fused_exits_per_photon": counters["fused_exits"] / photons,
         "wave_iterations_per_photon": counters["wave_iterations"] / photons,
-        "lane_utilisation": counters["lane_utilisation"],                       # live lanes / 64 when a wave steps
+        "live_lane_fraction": counters["lane_utilisation"],                     # lanes holding a live photon / 64 when a wave steps
     }
 
 
-def load_pmc(name, value_per_gpu, cus, live=None):
+def load_pmc(name, value_per_gpu, cus, live=None, clock=None):
     """Instruction-side numbers of a config.  Two kinds, labelled as such: what the kernel counts itself in THIS run
     (`in_kernel`: trips of the photon loop, live lanes per trip) and what only hardware counters can tell (vector
     instructions issued: the last committed PMC passes of this same command, tools/gpu_pmc.sh ->
@@ -200,11 +217,16 @@ def load_pmc(name, value_per_gpu, cus, live=None):
     adds instructions inside a trip needs a new PMC pass)."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json" if name == "cfg2" else f"pmc_summary_{name}.json")
     if not os.path.exists(path):
-        return None, ({"measured_in_this_run": False, "in_kernel": live} if live else None)
+        return None, ({"measured_in_this_run": False, "in_kernel": live, "built_kernel_text_hash": built_code_hash()} if live else None)
     try:
         summary = json.load(open(path))
         derived = summary.get("derived", {})
+        built, sampled = built_code_hash(), summary.get("kernel_text_hash")
         side = {
+            # the device code the counters were sampled on against the device code of the library loaded now (sha256 of the
+            # gfx950 .text section, tools/code_hash.sh): `stale` = the kernels have changed since the PMC pass
+            "pmc_kernel_text_hash": sampled, "built_kernel_text_hash": built,
+            "stale": (sampled != built) if (sampled and built) else None,
             # counters come from committed rocprofv3 passes of this same command (rocprofv3 serialises dispatches while
             # it samples, so they cannot be taken in the timed run); only the photon rate they are scaled by is measured here
             "measured_in_this_run": False,
@@ -241,17 +263,17 @@ def load_pmc(name, value_per_gpu, cus, live=None):
             side.update(valu_issue_rate_per_s=rate, valu_issue_peak_per_s=nominal, valu_issue_frac=rate / nominal,
                         valu_issue_achievable_per_s=achievable, valu_issue_frac_of_achievable=rate / achievable)
             # VALU busy WHILE THE LAUNCHES OVERLAP: the instruction count per photon is a property of the work (PMC,
-            # the same whether dispatches are serialised or not), the photon rate is measured here, and the shader
-            # clock was measured inside overlapping launches (s_memtime against s_memrealtime in every wave,
-            # tools/gpu_clock_overlap.sh -> profiles/r03_j_clock_overlap.json) instead of assumed
-            clock = os.path.join(ROOT, "profiles", "r03_j_clock_overlap.json")
-            if os.path.exists(clock):
-                c = json.load(open(clock))
-                side["valu_busy_under_overlap"] = rate * 4.0 / (cus * 4 * c["shader_clock_mhz"] * 1e6)
+            # the same whether dispatches are serialised or not), the photon rate is measured here, and so is the shader
+            # clock: every workgroup of the timed windows reads s_memtime against the constant 100 MHz s_memrealtime when
+            # it starts and when it leaves (pvt_scene_clock) -- the clock the launches of THIS run ran at, overlapping.
+            if clock and clock.get("shader_clock_mhz"):
+                mhz = clock["shader_clock_mhz"]
+                side["valu_busy_under_overlap"] = rate * 4.0 / (cus * 4 * mhz * 1e6)
                 if pmc_per_photon and pmc_per_photon != per_photon:
-                    side["valu_busy_under_overlap_upper"] = pmc_per_photon * value_per_gpu * 4.0 / (cus * 4 * c["shader_clock_mhz"] * 1e6)
-                side["shader_clock_mhz_measured_under_overlap"] = c["shader_clock_mhz"]
-                side["wave_slot_occupancy_measured_under_overlap"] = c["wave_slot_occupancy"]
+                    side["valu_busy_under_overlap_upper"] = pmc_per_photon * value_per_gpu * 4.0 / (cus * 4 * mhz * 1e6)
+                side["shader_clock_mhz_measured_in_this_run"] = mhz
+                side["shader_clock_is"] = ("sum of s_memtime cycles / sum of s_memrealtime ticks (100 MHz) over the lives of "
+                                           "all workgroups of the timed windows (pvt_scene_clock)")
         return summary.get("hbm_bytes_per_launch"), side
     except Exception:
         return None, ({"measured_in_this_run": False, "in_kernel": live} if live else None)
@@ -451,6 +473,7 @@ def main():
         window_dts.append(leg.window(next_step, args.steps))
         next_step += args.steps
     in_kernel = live_counters(leg.dscene.counters(), n * args.steps * len(window_dts))   # (this rank's photons)
+    main_clock = leg.dscene.clock()   # the shader clock of the timed windows' launches (reset with the counters above)
     ordered = sorted(window_dts)
     median_dt = ordered[(len(ordered) - 1) // 2]   # median (the slower of the two middle ones for an even count)
     per_window = n * world * args.steps
@@ -580,6 +603,7 @@ def main():
                 dts.append(other.window(100 + w * bundles, bundles, timed_events=True))
                 kms += other.pipe.kernel_ms()
             live = live_counters(other.dscene.counters(), n * bundles * 5)
+            clock = other.dscene.clock()
             frac = other.fractions(n * world * bundles)
             dts.sort()
             photons = n * world * bundles
@@ -589,7 +613,7 @@ def main():
                 sus_steps = max(bundles, int(args.config_sustained_s / (dts[len(dts) // 2] / bundles)))
                 dt = other.window(100_000, sus_steps)
                 sus = {"steps": sus_steps, "photons": n * world * sus_steps, "seconds": dt, "value": n * world * sus_steps / dt}
-            _, side = load_pmc(name, v / world, cus, live)
+            _, side = load_pmc(name, v / world, cus, live, clock)
             return {
                 "workload": CONFIGS[name]["workload"], "photons_per_gpu": n * bundles, "bundles": bundles,
                 "emission": "device (sampled by the wave that claims a chunk of rays, in the trace kernel)", "bundles_in_flight": args.streams,
@@ -628,10 +652,11 @@ def main():
             other.dscene.counters(reset=True)
             dts = sorted(other.window(100 + w * 10, 10) for w in range(3))
             live = live_counters(other.dscene.counters(), n * 10 * 3)
+            clock = other.dscene.clock()
             v = n * world * 10 / dts[1]
             sus_steps = max(10, int(1.0 / (dts[1] / 10)))
             dt = other.window(100_000, sus_steps)
-            _, side = load_pmc(name, v / world, cus, live)
+            _, side = load_pmc(name, v / world, cus, live, clock)
             return {
                 "nodes": k * k + 1, "value": v, "sustained": n * world * sus_steps / dt, "unit": "photons/s",
                 "launch": other.dscene.launch_info(), "node_grid": native.node_grid_plan(other.compiled) is not None,
@@ -652,7 +677,7 @@ def main():
         sustained, strong, extra, scaling = done["sustained"], done["strong"], done["extra"], done["scaling"]
         failures = list(errors) + list(more_errors)
         achieved = ALGORITHMIC_BYTES_PER_PHOTON * n / (mean_kernel_ms * 1e-3) / 1e9 if leg.array_input else 0.0
-        traffic, instruction_side = load_pmc(args.config, value / world, cus, in_kernel)
+        traffic, instruction_side = load_pmc(args.config, value / world, cus, in_kernel, main_clock)
         rates = [per_window / d for d in window_dts]
         side = instruction_side or {}
         busy = side.get("valu_busy_under_overlap") or side.get("valu_issue_frac")
@@ -700,12 +725,16 @@ def main():
                 "unit": "wave64 VALU instructions/s" if busy else "GB/s",
                 "frac": busy if busy else achieved / HBM_PEAK_GBS,
                 "frac_is": ("VALU busy with the launches overlapping: vector instructions per photon (PMC per trip x trips "
-                            "counted in this run) x photons/s x 4 cycles / (SIMDs x shader clock measured under overlap)")
+                            "counted in this run) x photons/s x 4 cycles / (SIMDs x shader clock read by the kernel in this run)")
                            if busy else "hbm",
                 "traffic": traffic,
                 "hbm": hbm,
                 "steps_per_photon": in_kernel["steps_per_photon"] if in_kernel else None,
-                "lane_utilisation": in_kernel["lane_utilisation"] if in_kernel else None,
+                # two different things: lanes HOLDING a live photon when a wave steps (counted by the kernel in this run),
+                # and active lanes per vector instruction, divergence inside the step included (PMC pass)
+                "live_lane_fraction": in_kernel["live_lane_fraction"] if in_kernel else None,
+                "valu_lane_utilisation": side.get("valu_lane_utilisation"),
+                "useful_fp64_lane_throughput_frac": (busy * side["valu_lane_utilisation"]) if busy and side.get("valu_lane_utilisation") else None,
                 "kernel": "trace_kernel_w4<RECORD=0,TAB_LDS=1,SEENW=1,EMIT=%d> (pvt_trace_kernel.h trace_body, MESH=0)"
                           % (0 if leg.array_input else 1),
                 "kernel_ms_mean": mean_kernel_ms,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 11
+#define PVT_ABI_VERSION 12
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -370,6 +370,20 @@ int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, i
  * is the fraction of lanes that held a live photon when a wave stepped.  The caller synchronises the streams it
  * launched on first (the copy only orders after the null stream); `reset` != 0 clears the counters afterwards. */
 int pvt_scene_counters(PvtScene* scene, uint64_t* out, int reset);
+
+/* The clocks the scene's launches ran at, read ON THE GPU (v12; no reference counterpart -- `elapsed` there is
+ * time.perf_counter around the call, pvtrace/engine/api.py:232-245).  Every workgroup reads the constant 100 MHz clock and
+ * the shader clock when it starts and when its last wave leaves:
+ *   out[0] shader-clock cycles and out[1] 100 MHz ticks, both summed over the lives of all workgroups since the scene's
+ *   creation or the last reset of pvt_scene_counters (which clears these too): 100 MHz x out[0] / out[1] is the shader
+ *   clock the launches ran at, overlapping launches included.  Synchronise first, as for pvt_scene_counters. */
+int pvt_scene_clock(PvtScene* scene, uint64_t* out);
+
+/* GPU-side span of the LAST launch on `stream` (v12): out[0] = 100 MHz time at which its workgroup 0 started, out[1] = the
+ * latest time at which one of its workgroups left; (out[1] - out[0]) x 10 ns is the launch's duration as the GPU saw it.
+ * A pair of HIP events around the call also counts whatever the host does between recording them (a descheduled thread
+ * reads as kernel time: profiles/r06_e2e_outlier.txt).  Synchronises the stream. */
+int pvt_scene_launch_span(PvtScene* scene, void* stream, uint64_t* out);
 
 /* Launch geometry actually used by the last trace on this scene (diagnostics). */
 int pvt_scene_launch_info(PvtScene* scene, int32_t* grid, int32_t* block, int32_t* lds_bytes);

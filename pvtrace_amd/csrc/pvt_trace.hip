@@ -104,7 +104,8 @@ struct PvtScene {
     int top_n = 0;                      // ... records of it
     int meshq = 0;                      // leaves a lane of a mesh walk notes in LDS before their triangles are tested (1 or kMeshQ)
     unsigned int* d_set_cursor = nullptr;   // kCursorSlots x kMaxSets cursors: launches with tally sets
-    unsigned long long* d_counters = nullptr;   // step counters: 64 rows x 4 words (KArgs::counters, pvt_scene_counters)
+    unsigned long long* d_counters = nullptr;   // step counters and clocks: 64 rows x 8 words (KArgs::counters, pvt_scene_counters / _clock)
+    unsigned long long* d_stamp = nullptr;      // kCursorSlots x {start, end} of a stream's last launch, 100 MHz ticks (KArgs::stamp)
     unsigned int* d_cursor = nullptr;   // kCursorSlots cursors (64 B apart), one per stream: launches on
                                         // different streams may overlap, each needs its own
     std::mutex slot_mutex;              // launches on one stream are ordered and may share a cursor;
@@ -1014,8 +1015,10 @@ int pvt_scene_create(const PvtSceneTables* t, int device, PvtScene** out) {
     HIP_TRY(hipMalloc(&s->d_cursor, 64 * kCursorSlots + 256));   // + room for the PVT_STATS counters
     HIP_TRY(hipMemset(s->d_cursor, 0, 64 * kCursorSlots + 256));
     HIP_TRY(hipMalloc(&s->d_set_cursor, (size_t)kCursorSlots * kMaxSets * 4));
-    HIP_TRY(hipMalloc(&s->d_counters, 64 * 4 * 8));
-    HIP_TRY(hipMemset(s->d_counters, 0, 64 * 4 * 8));
+    HIP_TRY(hipMalloc(&s->d_counters, 64 * 8 * 8));
+    HIP_TRY(hipMemset(s->d_counters, 0, 64 * 8 * 8));
+    HIP_TRY(hipMalloc(&s->d_stamp, (size_t)kCursorSlots * 2 * 8));
+    HIP_TRY(hipMemset(s->d_stamp, 0, (size_t)kCursorSlots * 2 * 8));
     if (bvh_nodes.size() >= ((size_t)1 << 26) || bvh_tris.size() >= ((size_t)1 << 26))
         return fail(PVT_ERR_INVALID, "meshes too large: the walk's cursors and leaf references hold 2^26 records / triangles");
     if (!bvh_nodes.empty()) {
@@ -1108,6 +1111,7 @@ void pvt_scene_destroy(PvtScene* s) {
     if (s->d_cursor) (void)hipFree(s->d_cursor);
     if (s->d_set_cursor) (void)hipFree(s->d_set_cursor);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_stamp) (void)hipFree(s->d_stamp);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->d_bvh_top) (void)hipFree(s->d_bvh_top);
     if (s->d_tris) (void)hipFree(s->d_tris);
@@ -1290,6 +1294,7 @@ int trace_launch(PvtScene* s, const PvtRays* rays, const PvtTraceParams* p, cons
     HIP_TRY(hipSetDevice(s->device));
 
     KArgs a = base_args(s, p);
+    a.stamp = s->d_stamp + 2 * (size_t)slot;
     if (rays) { a.pos = rays->position; a.dir = rays->direction; a.wl = rays->wavelength; }
     a.rec_distinct = reinterpret_cast<long long*>(tl->rec_distinct);
     a.rec_crossings = reinterpret_cast<long long*>(tl->rec_crossings);
@@ -1651,12 +1656,37 @@ int pvt_selftest_math(int fn, const double* x_host, double* y_host, int64_t n, i
 int pvt_scene_counters(PvtScene* s, uint64_t* out, int reset) {
     if (!s || !out) return fail(PVT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(s->device));
-    unsigned long long rows[64 * 4];
+    unsigned long long rows[64 * 8];
     HIP_TRY(hipMemcpy(rows, s->d_counters, sizeof rows, hipMemcpyDeviceToHost));   // (orders after the launches on the null stream only)
     for (int k = 0; k < 4; k++) out[k] = 0;
     for (int r = 0; r < 64; r++)
-        for (int k = 0; k < 4; k++) out[k] += rows[r * 4 + k];
+        for (int k = 0; k < 4; k++) out[k] += rows[r * 8 + k];
     if (reset) HIP_TRY(hipMemset(s->d_counters, 0, sizeof rows));
+    return PVT_OK;
+}
+
+int pvt_scene_clock(PvtScene* s, uint64_t* out) {
+    if (!s || !out) return fail(PVT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    unsigned long long rows[64 * 8];
+    HIP_TRY(hipMemcpy(rows, s->d_counters, sizeof rows, hipMemcpyDeviceToHost));
+    out[0] = out[1] = 0;
+    for (int r = 0; r < 64; r++) { out[0] += rows[r * 8 + 4]; out[1] += rows[r * 8 + 5]; }
+    return PVT_OK;
+}
+
+int pvt_scene_launch_span(PvtScene* s, void* stream, uint64_t* out) {
+    if (!s || !out) return fail(PVT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    out[0] = out[1] = 0;
+    size_t k = 0;
+    {
+        std::lock_guard<std::mutex> lock(s->slot_mutex);
+        while (k < s->slot_of.size() && s->slot_of[k] != reinterpret_cast<hipStream_t>(stream)) k++;
+        if (k == s->slot_of.size()) return fail(PVT_ERR_INVALID, "no launch on this stream yet");
+    }
+    HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(hipMemcpy(out, s->d_stamp + 2 * k, 16, hipMemcpyDeviceToHost));
     return PVT_OK;
 }
 

@@ -41,7 +41,7 @@ constexpr int kXSlots = 72;          // LDS photon-state slots used to repack a 
                                      // workgroups' LDS fit a CU, so a fresh workgroup of the next launch can
                                      // start while draining ones still hold theirs (+6 % on pipelined bundles)
 // workgroup control words in LDS
-enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_COUNT = 16, CTL_WORDS = 24 };   // (CTL_COUNT: three u64 sums, see KArgs::counters)
+enum { CTL_EXHAUSTED = 0, CTL_DONE = 1, CTL_IN = 2, CTL_LIVE = 6, CTL_COUNT = 16, CTL_CLOCK = 22, CTL_WORDS = 26 };   // (CTL_COUNT: three u64 sums, see KArgs::counters; CTL_CLOCK: two u64 stamps, see KArgs::stamp)
 constexpr double kEps = 2.220446049250313e-13;       // _kernel.pyx:29
 constexpr double kAlphaZero = 1e-8;                  // :32
 constexpr double kCcm = 2.99792458e10;               // :33
@@ -181,16 +181,25 @@ struct KArgs {
     // from `bvh_top` to byte offset `top_off`; cursors with pvt::kTopFlag set index that copy
     int top_off, top_n;
     const pvt::BvhNode* bvh_top;
-    // Step counters of the scene, always on (pvt_scene_counters): 64 rows (blockIdx & 63) of four u64 words
+    // Step counters of the scene, always on (pvt_scene_counters): 64 rows (blockIdx & 63) of eight u64 words
     //   [0] wave-iterations: trips of the photon loop in which a wave stepped its lanes
     //   [1] lane-steps: live lanes summed over those trips = the reference's loop count `_kernel.pyx:655` summed over the
     //       photons, except for [2]
     //   [2] fused exits: photons finished one step early by the fused exit (their last, empty step is not run)
     //   [3] waves retired
+    //   [4] shader-clock cycles and [5] 100 MHz ticks, summed over the workgroups' lives (see `stamp`)
     // Kept per LANE in three vector registers (the loop is short of scalar ones): one add per trip, one when a photon
     // ends (its own step count `count` is what is added), one in the fused exit; summed in LDS when a wave retires, four
     // atomics per workgroup.  null = off.
     unsigned long long* counters;
+    // Clocks of the launch, always on, read on the GPU itself (a pair of HIP events also times whatever the HOST does between
+    // recording them: a descheduled thread reads as kernel time).  Thread 0 of every workgroup reads the constant 100 MHz
+    // clock (s_memrealtime) and the shader clock (s_memtime) when the workgroup has staged its tables, its last wave reads
+    // them again when it leaves: rows [4] / [5] of `counters` sum the shader cycles / the 100 MHz ticks of the workgroups'
+    // lives (their ratio is the shader clock the launches ran at), and `stamp` -- two words per HIP stream -- gets the
+    // 100 MHz time at which workgroup 0 started (a plain store) and the latest at which a workgroup left (atomic max):
+    // after the stream is synchronised, the GPU-side span of its last launch (pvt_scene_launch_span).  null = off.
+    unsigned long long* stamp;
     // The tail function's own lazy root (same codes as `lazy_root`, which is 0 when somebody looks at where photons leave
     // the scene -- an event log, an `exit` recorder): there the root's crossing is skipped only when another crossing is known
     // to lie before it, and worked out exactly when it is the nearest one -- among a lone wave's few photons hardly ever.
@@ -764,7 +773,16 @@ __device__ __attribute__((noinline)) void leave_workgroup(const KArgs* kernel_ar
         if (ctr && lane < 4) {
             const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(ctl + CTL_COUNT);
             const unsigned long long v = lane == 3 ? (unsigned long long)kWaves : cnt[lane];
-            if (v) atomicAdd(ctr + (blockIdx.x & 63u) * 4u + lane, v);
+            if (v) atomicAdd(ctr + (blockIdx.x & 63u) * 8u + lane, v);
+        }
+        if (lane == 0) {   // the workgroup's life on both clocks (KArgs::stamp)
+            const unsigned long long* t0 = reinterpret_cast<const unsigned long long*>(ctl + CTL_CLOCK);
+            const unsigned long long real = wall_clock64(), cyc = __builtin_readcyclecounter();
+            if (ctr) {
+                atomicAdd(ctr + (blockIdx.x & 63u) * 8u + 4u, cyc - t0[1]);
+                atomicAdd(ctr + (blockIdx.x & 63u) * 8u + 5u, real - t0[0]);
+            }
+            if (A.stamp) atomicMax(A.stamp + 1, real);
         }
     }
     unsigned long long* const out_distinct = reinterpret_cast<unsigned long long*>(A.rec_distinct) + (long long)set * A.set_stride_i;
@@ -875,6 +893,11 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
     if (A.bins_in_lds)
         for (int i = threadIdx.x; i < A.total_bins; i += kBlock) acc_bins[i] = 0u;
     __syncthreads();
+    if (threadIdx.x == 0) {   // (KArgs::stamp; read again by the last wave to leave, in leave_workgroup)
+        unsigned long long* t0 = reinterpret_cast<unsigned long long*>(ctl + CTL_CLOCK);
+        t0[0] = wall_clock64(); t0[1] = __builtin_readcyclecounter();
+        if (blockIdx.x == 0 && A.stamp) A.stamp[0] = t0[0];
+    }
     }
 #if PVT_TIMELINE
     tl_t[1] = wall_clock64();

@@ -541,7 +541,7 @@ class Session:
                              workgroups_per_cu=workgroups_per_cu, tally_bundle=int(tally_bundle),
                              log_prefill=False)   # `download` reads written rows only (or repairs the rest)
                 stop.record(stream)
-        return {"stream": stream, "tallies": tallies, "log": log, "events": (start, stop), "tic": tic,
+        return {"stream": stream, "tallies": tallies, "log": log, "events": (start, stop), "tic": tic, "launch_no": self._submitted,
                 "rays": rays, "sources": sources, "num_rays": num_rays, "record_every": record_every,
                 "max_events": max_events, "tally_bundle": int(tally_bundle), "packed_log": bool(packed_log)}
 
@@ -556,7 +556,12 @@ class Session:
         with torch.cuda.device(self.device):
             pending["stream"].synchronize()
             wall = time.perf_counter() - pending["tic"]
+            # The launch as the GPU saw it (the kernel's own 100 MHz stamps) when this bundle is still the last launch on
+            # its stream; HIP events otherwise.  The events bracket host code -- ctypes, the library's planning -- and a
+            # host thread descheduled between them reads as tens of milliseconds of "kernel" (profiles/r06_e2e_outlier.txt).
             kernel_ms = pending["events"][0].elapsed_time(pending["events"][1])
+            if self._submitted - pending.get("launch_no", -2) < 2 and pending["num_rays"] > 0:   # (two streams, used in turn)
+                kernel_ms = min(kernel_ms, self.dscene.launch_span_ms(pending["stream"].cuda_stream) or kernel_ms)
             with torch.cuda.stream(pending["stream"]):
                 data = download(self.compiled, pending["tallies"], pending["log"], pending["num_rays"],
                                 pending["record_every"], pending["max_events"], packed=pending.get("packed_log", False))

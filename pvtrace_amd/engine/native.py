@@ -255,6 +255,8 @@ def declare_signatures(lib, names):
         "pvt_scene_launch_info": (
             [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], C.c_int),
         "pvt_scene_counters": ([vp, C.POINTER(C.c_uint64), C.c_int], C.c_int),
+        "pvt_scene_clock": ([vp, C.POINTER(C.c_uint64)], C.c_int),
+        "pvt_scene_launch_span": ([vp, vp, C.POINTER(C.c_uint64)], C.c_int),
         "pvt_node_grid_plan": (
             [C.POINTER(PvtSceneTables), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
              C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_int64], C.c_int),
@@ -273,11 +275,11 @@ ABI_SYMBOLS = (
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
     "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
     "pvt_scene_carry_pending", "pvt_last_multi_reduce", "pvt_node_grid_plan", "pvt_scene_carry_discard", "pvt_scene_trim",
-    "pvt_scene_counters",
+    "pvt_scene_counters", "pvt_scene_clock", "pvt_scene_launch_span",
 )
 
 _lib = None
-ABI_VERSION = 11  # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 12  # include/pvtrace_hip.h PVT_ABI_VERSION
 FLAG_NO_LOG_PREFILL = 1   # PvtTraceParams.flags
 FLAG_CARRY_OUT = 2        # park the photons still alive at the end of the launch for the next launch on the stream
 
@@ -463,6 +465,30 @@ class DeviceScene:
         it, ls, fused, waves = (int(v) for v in out)
         return {"wave_iterations": it, "lane_steps": ls, "fused_exits": fused, "waves": waves,
                 "steps": ls + fused, "lane_utilisation": ls / (64.0 * it) if it else 0.0}
+
+    def clock(self):
+        """The clocks the scene's launches ran at since its creation / the last `counters(reset=True)`, read on the GPU
+        (pvt_scene_clock): shader cycles and 100 MHz ticks summed over the workgroups' lives, and their ratio in MHz.
+        Synchronises the device first."""
+        import torch
+
+        torch.cuda.synchronize(self.device)
+        out = (C.c_uint64 * 2)()
+        check(self.lib.pvt_scene_clock(self.handle, out), "pvt_scene_clock")
+        cycles, ticks = int(out[0]), int(out[1])
+        return {"shader_cycles": cycles, "ticks_100mhz": ticks, "shader_clock_mhz": 100.0 * cycles / ticks if ticks else 0.0}
+
+    def launch_span_ms(self, stream=None):
+        """GPU-side duration of the last launch on `stream` (a raw handle; default: torch's current stream), from the
+        kernel's own 100 MHz stamps (pvt_scene_launch_span) -- unlike a pair of HIP events around `trace`, it cannot contain
+        time the host spent between recording them.  Synchronises the stream."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        out = (C.c_uint64 * 2)()
+        check(self.lib.pvt_scene_launch_span(self.handle, C.c_void_p(stream), out), "pvt_scene_launch_span")
+        return (int(out[1]) - int(out[0])) * 1e-5
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -38,7 +38,7 @@ c = dict(sums)
 read_b = c["FETCH_SIZE"] * 1024 * 2
 write_b = c["WRITE_SIZE"] * 1024
 out = {
-    "round": 5, "stage": stage, "mode": mode, "config": cfg,
+    "round": 6, "stage": stage, "mode": mode, "config": cfg,
     "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --gpus 1 --steps 6 --warmup 1 "
                "--no-cpu-baseline --repeats 0 --sustained-s 0 --total-photons 0 --spinup-s 0 --ray-buffers 2 --extra-configs none --config " + cfg
                + (" --streams 1" if mode.startswith("serial") else "") + " (one counter set per run; tools/gpu_pmc.sh " + mode.split("_")[0] + " " + cfg + "); "
@@ -74,6 +74,9 @@ for cand in ("sq1", "sq2", "sq3"):
     try:
         doc = json.loads(open(line).read().strip().splitlines()[-1])
         ik = (doc["roofline"]["instruction_side"] or {}).get("in_kernel")   # (--config <cfg>: the main leg IS that config)
+        # the device code the counters were sampled on (sha256 of its .text, as the sampled process itself read it from the
+        # library it had loaded): bench.py compares it with the library it runs on and reports `instruction_side.stale`
+        out["kernel_text_hash"] = (doc["roofline"]["instruction_side"] or {}).get("built_kernel_text_hash")
         if ik:
             out["in_kernel_of_the_pmc_run"] = ik
             out["derived"]["wave_iterations_per_photon"] = ik["wave_iterations_per_photon"]
