@@ -541,6 +541,81 @@ def make_lsc_tracer():
     save("lsc_tracer.npz", **out)
 
 
+CFG5_TRACER_RAYS = 20000
+
+
+def make_cfg5_tracer():
+    """SURVEY §8(c)(5) / §8(d) cfg5, as they are written: BASELINE configs[4] traced by the reference's OWN per-ray Python
+    tracer (`algorithm/photon_tracer.py:276-328` `follow`) calling the Coatings notebook's OWN delegate.  The class
+    `PartialTopSurfaceMirror` is read from `examples/006 Coatings.ipynb` where it lies (`json.load`, cell 3) and `exec`'d
+    against the reference's `FresnelSurfaceDelegate` -- nothing of it is stored here; the scene is the notebook's cell 5
+    (world Box 15^3, slab Box (10,10,1) of index 1.5 with that delegate, `Light(position=partial(rectangular_mask, 5, 5))`
+    at (0,0,2) turned by 180 degrees about x) plus the `Scatterer(1.0)` of benchmarks/configs.py:cfg5_coated_slab, built
+    from the reference's Material / Surface / Scatterer / Light.  Module substitutions as in make_lsc_tracer: the
+    reference's scene graph needs anytree and its Box needs trimesh, neither is here and neither is imitated -- the
+    PRODUCT's Node / Scene / Box stand in their place, so the tree traversal and the ray-box arithmetic under the
+    reference's tracer are the product's (each held to the reference's known answers elsewhere: tests/test_golden_units.py,
+    tests/test_intersection.py); the tracer, the delegate, the material, the scatterer and the emission are the reference's.
+    Kept per ray (numbers only): event counts by kind, the last event, and the position the reference's `LSC.simulate`
+    would store as the exit ray.  Rays: the reference's `emit_bundle` under numpy seed 905."""
+    import functools
+    import json
+
+    import pvtrace_amd.geometry as prod_geometry
+    import pvtrace_amd.scene as prod_scene
+
+    ref_module("pvtrace.data.lumogen_f_red_305")
+    for sub in ("scene", "light", "material", "geometry", "algorithm", "common", "device", "engine"):
+        if f"pvtrace.{sub}" not in sys.modules:
+            pkg = types.ModuleType(f"pvtrace.{sub}")
+            pkg.__path__ = [os.path.join(REF, sub)]
+            sys.modules[f"pvtrace.{sub}"] = pkg
+    sys.modules["pvtrace.scene.node"] = prod_scene
+    sys.modules["pvtrace.scene.scene"] = prod_scene
+    sys.modules["pvtrace.geometry.box"] = prod_geometry
+    surface = ref_module("pvtrace.material.surface")
+    material = ref_module("pvtrace.material.material")
+    component = ref_module("pvtrace.material.component")
+    light = ref_module("pvtrace.light.light")
+    emit = ref_module("pvtrace.engine.emit")
+    tracer = ref_module("pvtrace.algorithm.photon_tracer")
+    ray_cls = ref_module("pvtrace.light.ray").Ray
+    event_cls = ref_module("pvtrace.light.event").Event
+
+    notebook = json.load(open(os.path.join(os.path.dirname(REF), "examples", "006 Coatings.ipynb")))
+    cells = ["".join(c["source"]) for c in notebook["cells"] if c["cell_type"] == "code"]
+    (source,) = [c for c in cells if c.lstrip().startswith("class PartialTopSurfaceMirror")]
+    namespace = {"np": np, "FresnelSurfaceDelegate": surface.FresnelSurfaceDelegate}
+    exec(compile(source, "006 Coatings.ipynb cell 3", "exec"), namespace)   # noqa: S102 -- the notebook's class, where it lies
+    mirror_cls = namespace["PartialTopSurfaceMirror"]
+
+    world = prod_scene.Node(name="world (air)", geometry=prod_geometry.Box((15.0, 15.0, 15.0), material=material.Material(refractive_index=1.0)))
+    prod_scene.Node(name="box (glass)", parent=world, geometry=prod_geometry.Box(
+        (10.0, 10.0, 1.0), material=material.Material(refractive_index=1.5, surface=surface.Surface(delegate=mirror_cls()),
+                                                      components=[component.Scatterer(1.0, name="Scatterer")])))
+    lamp = prod_scene.Node(name="Light", parent=world,
+                           light=light.Light(position=functools.partial(light.rectangular_mask, 5, 5), name="Light"))
+    lamp.location = (0, 0, 2)
+    lamp.rotate(np.radians(180), (1, 0, 0))
+    full = prod_scene.Scene(world)
+    view = types.SimpleNamespace(root=full.root, light_nodes=[n for n in full.root.levelorder() if getattr(n, "light", None) is not None])
+    n = CFG5_TRACER_RAYS
+    np.random.seed(905)
+    pos, direc, wl, _ = emit.emit_bundle(view, n)
+    counts = np.zeros((n, 10), dtype=np.uint16)
+    last = np.zeros(n, dtype=np.uint8)
+    where = np.zeros((n, 3))
+    for j in range(n):
+        hist = tracer.follow(full, ray_cls(position=tuple(pos[j]), direction=tuple(direc[j]), wavelength=float(wl[j])))
+        for _, event in hist:
+            counts[j, event.value] += 1
+        last[j] = hist[-1][1].value
+        where[j] = hist[-2][0].position if hist[-1][1] == event_cls.EXIT else hist[-1][0].position
+    print("   cfg5: mean events per ray by kind value:", np.round(counts.mean(axis=0), 4).tolist())
+    save("cfg5_tracer.npz", **{"cfg5/counts": counts, "cfg5/last": last, "cfg5/where": where,
+                               "cfg5/first_positions": pos[:64], "cfg5/first_directions": direc[:64]})
+
+
 def make_object_methods():
     """The per-interaction methods of the reference's host objects -- `Material.penetration_depth / is_absorbed / component`
     (material/material.py:22-63), `Scatterer / Absorber / Luminophore .is_radiative / nonradiative_absorb / emit`
@@ -781,6 +856,7 @@ if __name__ == "__main__":
         make_lsc_delegates()
         make_lsc_scenes()
         make_lsc_tracer()
+        make_cfg5_tracer()
         make_object_methods()
         make_compiled_tables()
         make_engine_result()
@@ -804,6 +880,7 @@ if __name__ == "__main__":
     make_lsc_delegates()
     make_lsc_scenes()
     make_lsc_tracer()
+    make_cfg5_tracer()
     make_object_methods()
     make_compiled_tables()
     make_engine_result()

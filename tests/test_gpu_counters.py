@@ -81,3 +81,69 @@ def test_cfg2_steps_per_photon_is_the_surveys():
         assert c["fused_exits"] > 0.5 * n   # most photons leave the slab for good: their empty last step is not run
     finally:
         dscene.close()
+
+
+def test_clocks_read_on_the_gpu_span_of_a_launch_and_shader_clock():
+    """ABI v12 (pvt_scene_launch_span, pvt_scene_clock): the GPU-side span of a launch agrees with a pair of HIP events
+    recorded right around it on an idle device, and does NOT grow when the host dawdles between recording the first event and
+    launching (the events do: that is how a descheduled host thread once read as a 29.5 ms kernel, profiles/r05_e2e.txt:3,
+    profiles/r06_e2e_outlier.txt); the shader clock read by the workgroups is a plausible MI355X clock."""
+    import time
+
+    import torch
+
+    from benchmarks.configs import cfg2_lsc
+
+    scene = cfg2_lsc()
+    compiled = compile_scene(scene)
+    n = 500_000
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=1)
+    dscene = native.DeviceScene(compiled, device=0)
+    try:
+        rays = tuple(torch.from_numpy(a).to(torch.device("cuda", 0)) for a in (pos, dirs, wl))
+        tallies = dscene.new_tallies()
+        for _ in range(3):   # warm: clocks, code
+            dscene.trace(rays, n, 1, tallies)
+        torch.cuda.synchronize()
+        dscene.counters(reset=True)
+        spans, events = [], []
+        for dawdle in (0.0, 0.0, 0.02):
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            time.sleep(dawdle)   # a host that is held up between the event and the launch
+            dscene.trace(rays, n, 2, tallies)
+            stop.record()
+            torch.cuda.synchronize()
+            spans.append(dscene.launch_span_ms())
+            events.append(start.elapsed_time(stop))
+        assert 0.05 < spans[0] < 5.0 and 0.05 < spans[1] < 5.0
+        assert abs(spans[1] - events[1]) < 0.25 * events[1] + 0.05          # same launch, two clocks
+        assert events[2] > 20.0 and spans[2] < 2.0 * max(spans[:2]) + 0.1   # the host's 20 ms are in the events only
+        clk = dscene.clock()
+        assert clk["ticks_100mhz"] > 0 and 500.0 < clk["shader_clock_mhz"] < 3000.0, clk
+    finally:
+        dscene.close()
+
+
+def test_the_reference_harness_recorder_mode_launch_is_about_a_millisecond():
+    """The reference's own benchmark shape (benchmarks/benchmark_engine.py:97-130 there): 2 000 000 host-emitted rays,
+    tallies for every ray, paths for every 1000th.  VERDICT r5 #9 found one 29.5 ms reading of this launch in a kept
+    profile; 25 repetitions in round 6 read 0.73-0.81 ms per 10^6 (profiles/r06_e2e_outlier.txt).  Guarded here on the
+    GPU's own clock: five launches, every one below 2.5 ms for 2 x 10^6 rays (1.5 ms typical)."""
+    from benchmarks.benchmark_engine import make_lsc_scene
+    from pvtrace_amd import engine
+    from pvtrace_amd.engine import Histogram, Recorder
+
+    scene = make_lsc_scene()
+    slab = [node for node in scene.root.children if node.name == "slab"][0]
+    slab.recorders = [Recorder("top-escape", event="escaping", facet=(0, 0, 1), histograms=[Histogram("wavelength", 400, 900, 100)]),
+                      Recorder("lost", event="lost")]
+    np.random.seed(5)
+    engine.simulate(scene, 1000, seed=0, record_every=1000, emission="host")
+    readings = []
+    for rep in range(5):
+        np.random.seed(100 + rep)
+        result = engine.simulate(scene, 2_000_000, seed=rep, record_every=1000, emission="host")
+        readings.append(result.kernel_ms)
+        assert result.num_recorded == 2000 and result.recorders["top-escape"].rays > 0
+    assert max(readings) < 2.5, readings

@@ -193,6 +193,47 @@ def test_references_tracer_with_its_lsc_delegates_against_the_gpu_engine():
                                facet_classes(last, where, LSC_CASE_SIZES[name]))
 
 
+# -- BASELINE configs[4] under the REFERENCE's tracer and the Coatings notebook's own delegate (tests/golden/cfg5_tracer.npz) ----
+def test_config5_references_tracer_with_the_notebooks_mirror_against_the_coating_tables():
+    """SURVEY §8(c)(5) / §8(d) cfg5.  tests/golden/cfg5_tracer.npz: 20 000 rays traced by the REFERENCE's
+    `photon_tracer.follow` through the Coatings notebook's scene (cell 5) + `Scatterer(1.0)`, its `PartialTopSurfaceMirror`
+    (cell 3, exec'd from the notebook where it lies by tests/golden/make_golden.py:make_cfg5_tracer) called at every hit.
+    The product's cfg5 (benchmarks/configs.py) states the same mirror as a `Coating` with a region, lowered to tables:
+    same per-ray event-count means (Welch, 5 sigma) and the same shares of (last event, exit facet) -- here on the C
+    referee, below on the GPU."""
+    from benchmarks.configs import cfg5_coated_slab
+    from tests.util import load_golden
+
+    g = load_golden("cfg5_tracer.npz")
+    mine, result = referee_counts(cfg5_coated_slab(), 40000, seed=31)
+    assert_means_close(reference_lsc_counts(g, "cfg5"), mine)
+    last, where = data_last_and_where(result.data, 256)
+    assert_fractions_close(facet_classes(g["cfg5/last"], g["cfg5/where"], (10.0, 10.0, 1.0)),
+                           facet_classes(last, where, (10.0, 10.0, 1.0)))
+    # the mirror is where the notebook puts it: a quarter of the lamp's 5 x 5 cm footprint lies on it, and those rays are
+    # turned back outside the glass without another event (GENERATE, REFLECT, EXIT) -- in the reference's run and in ours
+    ref_counts = g["cfg5/counts"].astype(int)
+    ref_bounced = (ref_counts.sum(axis=1) == 3) & (ref_counts[:, Event.REFLECT.value] == 1) & (g["cfg5/where"][:, 0] > 0) & (g["cfg5/where"][:, 1] > 0)
+    assert abs(ref_bounced.mean() - 0.25) < 5 * math.sqrt(0.25 * 0.75 / len(ref_counts))
+    my_bounced = (mine.sum(axis=1) == 3) & (mine[:, KINDS.index(Event.REFLECT)] == 1) & (where[:, 0] > 0) & (where[:, 1] > 0)
+    assert abs(my_bounced.mean() - 0.25) < 5 * math.sqrt(0.25 * 0.75 / len(mine))
+
+
+@pytest.mark.gpu
+def test_config5_references_tracer_with_the_notebooks_mirror_against_the_gpu_engine():
+    from benchmarks.configs import cfg5_coated_slab
+    from pvtrace_amd import engine
+    from tests.util import load_golden
+
+    g = load_golden("cfg5_tracer.npz")
+    result = engine.simulate(cfg5_coated_slab(), 100000, seed=33, max_events=256)
+    assert (result.data["counts"] >= 255).sum() == 0
+    assert_means_close(reference_lsc_counts(g, "cfg5"), table_counts(result.data, 256))
+    last, where = data_last_and_where(result.data, 256)
+    assert_fractions_close(facet_classes(g["cfg5/last"], g["cfg5/where"], (10.0, 10.0, 1.0)),
+                           facet_classes(last, where, (10.0, 10.0, 1.0)))
+
+
 @pytest.mark.gpu
 def test_python_tracer_against_the_gpu_engine():
     from pvtrace_amd import engine
