@@ -352,3 +352,69 @@ def test_py_tracer_reproduces_the_references_python_tracer_history_by_history():
         at += n
     assert at == len(g["kind"])
     assert {Event.REFLECT, Event.TRANSMIT, Event.ABSORB, Event.EMIT, Event.SCATTER, Event.NONRADIATIVE, Event.EXIT} <= seen
+
+
+# -- the PRODUCT's per-ray path on the scene objects (pvtrace_amd/algorithm/photon_tracer.py, backend="host") ----------------
+def test_config1_hello_world_through_the_products_own_per_ray_path_without_a_gpu():
+    """BASELINE configs[0] as it is written: hello_world, 1 000 rays, the package's Python-level per-ray path, no GPU.
+    `photon_tracer.follow` steps the ray through the scene objects (their per-interaction methods, numpy's generator) when
+    no GPU is visible; `backend="host"` asks for that path outright, so the test means the same on the GPU box.  SURVEY §8(d):
+    per-ray event means GENERATE 1, TRANSMIT ~1.91, REFLECT ~0.087, EXIT 1; and Welch 5 sigma against the C referee."""
+    from pvtrace_amd import photon_tracer
+
+    scene = scenes.hello_world()
+    np.random.seed(1)
+    table = np.zeros((1000, len(KINDS)))
+    for j, ray in enumerate(scene.emit(1000)):
+        history = photon_tracer.follow(scene, ray, backend="host")
+        assert history[0][1] == Event.GENERATE and history[-1][1] == Event.EXIT
+        assert np.isclose(np.linalg.norm(history[-1][0].position), 10.0)
+        for _, event in history:
+            table[j, KINDS.index(event)] += 1
+    mean = dict(zip(KINDS, table.mean(axis=0)))
+    assert mean[Event.GENERATE] == 1.0 and mean[Event.EXIT] == 1.0 and mean[Event.KILL] == 0.0
+    assert mean[Event.TRANSMIT] == pytest.approx(1.91, abs=0.03)
+    assert mean[Event.REFLECT] == pytest.approx(0.087, abs=0.03)
+    ref, _ = referee_counts(scenes.hello_world(), 20000, seed=7, max_events=64)
+    assert_means_close(table, ref)
+
+
+def test_products_per_ray_path_reproduces_the_references_python_tracer_history_by_history():
+    """The same 300 reference histories as above (tests/golden/py_tracer.npz), asked of the PRODUCT's host path: it calls
+    the host classes' per-interaction methods, which keep the reference's draw order, so equal numpy seeds must give equal
+    histories -- every event, position, direction and wavelength."""
+    from pvtrace_amd import photon_tracer
+    from pvtrace_amd.light import Ray
+    from tests.util import load_golden
+
+    g = load_golden("py_tracer.npz")
+    dirs, wls, seeds = scenes.py_tracer_pin_rays()
+    scene = scenes.py_tracer_pin_scene()
+    at = 0
+    for d, w, sd, n in zip(dirs, wls, seeds, g["counts"]):
+        np.random.seed(int(sd))
+        hist = photon_tracer.follow(scene, Ray(position=(0.0, 0.0, 0.0), direction=tuple(d), wavelength=float(w)), backend="host")
+        assert len(hist) == n, (sd, len(hist), n)
+        for k, (ray, event) in enumerate(hist):
+            assert event.value == g["kind"][at + k], (sd, k)
+            assert np.allclose(ray.position, g["position"][at + k], rtol=0, atol=1e-9), (sd, k)
+            assert np.allclose(ray.direction, g["direction"][at + k], rtol=0, atol=1e-9), (sd, k)
+            assert abs(ray.wavelength - g["wavelength"][at + k]) < 1e-9, (sd, k)
+        at += n
+    assert at == len(g["kind"])
+
+
+def test_products_per_ray_path_honours_maxsteps_and_maxpathlength():
+    """reference photon_tracer.py:162-172: KILL at the start of the first step entered beyond either limit."""
+    from pvtrace_amd import photon_tracer
+
+    scene = scenes.trapped_light()
+    np.random.seed(3)
+    ray = next(iter(scene.emit(1)))
+    capped = photon_tracer.follow(scene, ray, maxsteps=5, backend="host")
+    assert capped[-1][1] == Event.KILL and len(capped) <= 2 * 5 + 2
+    np.random.seed(3)
+    short = photon_tracer.follow(scene, ray, maxpathlength=0.5, backend="host")
+    assert short[-1][1] == Event.KILL and short[-1][0].travelled > 0.5
+    with pytest.raises(ValueError):
+        photon_tracer.follow(scene, ray, backend="cpu")
