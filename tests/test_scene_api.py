@@ -633,6 +633,10 @@ def test_photon_tracer_entry_points_shape_a_history_like_the_references(monkeypa
                 (ray(4.0), Event.TRANSMIT, {"hit": "slab", "container": "slab", "adjacent": "world"}),
                 (ray(9.0), Event.EXIT, {"hit": "world", "container": "world", "adjacent": None})]
     monkeypatch.setattr(photon_tracer, "_history", lambda *a, **k: list(injected))
+    import functools
+
+    for name in ("step_forward", "follow"):   # (the engine's form of the entry points: its history is what is injected)
+        monkeypatch.setattr(photon_tracer, name, functools.partial(getattr(photon_tracer, name), backend="gpu"))
     steps = list(photon_tracer.step_forward(None, ray(0.0)))
     assert steps[0] == (ray(0.0), Event.GENERATE, None) and [e for _, e, _ in steps] == [e for _, e, _ in injected]
     assert photon_tracer.follow(None, ray(0.0)) == [(r, e) for r, e, _ in injected]
