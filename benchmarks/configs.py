@@ -106,6 +106,17 @@ def tiles_lsc(k, recorders="centre"):
     return Scene(world)
 
 
+def hello_world():
+    """BASELINE configs[0] and the scene of the reference's one published engine figure (README.md:163-170,
+    examples/hello_world.py:8-32): a glass ball of radius 1 at (0, 0, 2) in a 10 cm air sphere, pi/8 cone from the origin
+    at 555 nm; no recorders -- the README's call keeps every event of every ray instead."""
+    world = Node(name="world", geometry=Sphere(radius=10.0, material=Material(refractive_index=1.0)))
+    ball = Node(name="ball-lens", parent=world, geometry=Sphere(radius=1.0, material=Material(refractive_index=1.5)))
+    ball.location = (0, 0, 2)
+    Node(name="green-laser", parent=world, light=Light(direction=functools.partial(cone, np.pi / 8), name="green-laser"))
+    return Scene(world)
+
+
 def mesh_ball(subdivisions):
     """The reference's hello_world (examples/hello_world.py:8-32: a glass ball of radius 1 at (0, 0, 2) in a 10 cm air
     sphere, pi/8 cone from the origin) with the ball as a TRIANGLE MESH -- an icosphere of 20 * 4^subdivisions faces --

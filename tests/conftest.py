@@ -10,6 +10,47 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    if os.path.exists("/dev/kfd") and "not gpu" not in (config.getoption("-m", default="") or ""):
+        prefetch_torch_libraries()
+
+
+def prefetch_torch_libraries(threads=8):
+    """A fresh GPU box pages its image in on demand, and the first `import torch` of a session walks ~6 GB of shared
+    libraries through 4 KB page faults: 61 s on one box of round 6, 1 299 s on another (`gpurun_out/r06_pytest_gpu_a.log`:
+    one test "took" 1 299 of the suite's 1 488 s -- its `import torch`), 650 s of round 5's 865.  Sequential reads pull the
+    same bytes at the store's streaming rate: a few daemon threads read torch/lib/*.so (largest first) into the page cache
+    while the first tests -- which go through the C ABI and do not need torch -- already run.  Nothing is imported here."""
+    import importlib.util
+    import threading
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    lib = os.path.join(os.path.dirname(spec.origin), "lib")
+    try:
+        files = sorted((os.path.join(lib, f) for f in os.listdir(lib) if ".so" in f), key=os.path.getsize, reverse=True)
+    except OSError:
+        return
+    todo, lock = list(files), threading.Lock()
+
+    def reader():
+        while True:
+            with lock:
+                if not todo:
+                    return
+                path = todo.pop(0)
+            try:
+                with open(path, "rb", buffering=0) as fp:
+                    while fp.read(8 << 20):
+                        pass
+            except OSError:
+                pass
+
+    for _ in range(threads):
+        threading.Thread(target=reader, daemon=True).start()
 
 
 @pytest.fixture(scope="session")

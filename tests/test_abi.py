@@ -109,8 +109,9 @@ def test_shard_ranges_of_the_library_match_the_python_sharder(built):
     from pvtrace_amd.engine import native as N
     from pvtrace_amd.engine.distributed import shard_range
 
-    for n in (0, 1, 63, 1000, 1_000_003, 2 ** 31 - 1):
-        for shards in (1, 2, 3, 8):
+    # (10^8 over 2 / 4 / 8 shards with record_every 0 / 1000 / 7: BASELINE configs[2], the job no 8-GPU node has run yet)
+    for n in (0, 1, 63, 1000, 1_000_003, 100_000_000, 2 ** 31 - 1):
+        for shards in (1, 2, 3, 4, 8):
             for align in (0, 1, 7, 1000):
                 spans = [N.shard_range(n, g, shards, align) for g in range(shards)]
                 assert spans == [shard_range(n, g, shards, align) for g in range(shards)]
