@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PVT_ABI_VERSION 12
+#define PVT_ABI_VERSION 13
 
 /* limits (reference _kernel.pyx:65-68) */
 #define PVT_MAX_NODES 128
@@ -323,6 +323,12 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
                      const PvtRays* rays, const PvtTraceParams* params,
                      const PvtTallies* tallies, const PvtEventLog* log, int device,
                      double* kernel_ms);
+
+/* (The rays are uploaded in chunks and a chunk is traced while the next one crosses PCIe; results do not depend on the
+ * split.  The device block that held the rays and tallies -- up to 1 GiB, one per device -- is kept for the next
+ * host-buffer call on that device; pvt_release_cached_memory() frees what is kept.  The reference's trace_bundle keeps
+ * nothing between calls either way: _kernel.pyx:1035-1066 allocates per call.) */
+void pvt_release_cached_memory(void);
 
 /* In-process multi-GPU form of pvt_trace_bundle: the bundle is split over
  * `devices[0 .. n_devices)` by contiguous index range — shard g traces the global indices

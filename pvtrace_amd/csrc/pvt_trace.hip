@@ -41,6 +41,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <chrono>
 #include <dlfcn.h>
 #include <string>
 #include <thread>
@@ -1869,6 +1870,113 @@ int rccl_reduce_to_first(const std::vector<int>& devs, const std::vector<void*> 
     return 0;
 }
 
+constexpr size_t kChunkRays = 524288;   // rays per upload chunk of a host-buffer bundle (28 MB: ~0.5 ms of PCIe; a chunk costs ~70 us of host time)
+
+// PVT_HOST_PHASES=1 (developer switch): where the milliseconds of a host-buffer call go, on stderr
+struct PhaseClock {
+    bool on = getenv("PVT_HOST_PHASES") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    std::string line;
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof buf, " %s %.3f", what, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    void report(size_t n, size_t chunks) const {
+        if (on) fprintf(stderr, "[pvt host phases] n %zu chunks %zu ms:%s\n", n, chunks, line.c_str());
+    }
+};
+
+// The device block of a host-buffer call (rays + tallies) is kept for the next call on the device: freeing 56 MB and
+// allocating them again is a quarter of a millisecond per call, an eighth of a 10^6-photon pvt_trace_bundle
+// (profiles/r06_host_bundle.txt).  ONE block per device, at most kArenaKeep bytes, handed to one call at a time (a call
+// that finds it taken, or too small, allocates its own); pvt_release_cached_memory() frees what is kept.
+constexpr size_t kArenaKeep = (size_t)1 << 30;
+struct ArenaCache {
+    struct Kept { int device; void* ptr; size_t bytes; };
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static std::vector<Kept>& kept() { static std::vector<Kept> k; return k; }
+    static void* take(int device, size_t bytes, size_t* got) {
+        std::lock_guard<std::mutex> lock(mutex());
+        auto& k = kept();
+        for (size_t i = 0; i < k.size(); i++)
+            if (k[i].device == device && k[i].bytes >= bytes) {
+                void* p = k[i].ptr;
+                *got = k[i].bytes;
+                k.erase(k.begin() + (long)i);
+                return p;
+            }
+        return nullptr;
+    }
+    // -> the block the caller must free itself (the one handed in, or the smaller one it displaced), or null
+    static void* give(int device, void* ptr, size_t bytes) {
+        if (bytes > kArenaKeep || getenv("PVT_NO_HOST_CACHE")) return ptr;
+        std::lock_guard<std::mutex> lock(mutex());
+        auto& k = kept();
+        for (size_t i = 0; i < k.size(); i++)
+            if (k[i].device == device) {
+                if (k[i].bytes >= bytes) return ptr;
+                void* old = k[i].ptr;
+                k[i] = Kept{device, ptr, bytes};
+                return old;
+            }
+        k.push_back(Kept{device, ptr, bytes});
+        return nullptr;
+    }
+    static void release_all() {
+        std::vector<Kept> mine;
+        {
+            std::lock_guard<std::mutex> lock(mutex());
+            mine.swap(kept());
+        }
+        for (auto& b : mine) { (void)hipSetDevice(b.device); (void)hipFree(b.ptr); }
+    }
+};
+
+// The streams and events of one host-buffer call, taken from a per-device pool (creating and destroying four streams
+// per call costs more than tracing a small bundle) and handed back by the destructor.
+struct StreamSet {
+    hipStream_t copy = nullptr, trace[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, arrived = nullptr;
+    int n_trace = 0, device = -1;
+    struct Pooled { int device; hipStream_t copy, trace[3]; hipEvent_t ev0, ev1, arrived; };
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static std::vector<Pooled>& pool() { static std::vector<Pooled> p; return p; }
+
+    hipError_t open(int dev, int want_trace) {
+        device = dev;
+        n_trace = want_trace;
+        {
+            std::lock_guard<std::mutex> lock(mutex());
+            auto& p = pool();
+            for (size_t k = 0; k < p.size(); k++)
+                if (p[k].device == dev) {
+                    copy = p[k].copy; ev0 = p[k].ev0; ev1 = p[k].ev1; arrived = p[k].arrived;
+                    for (int q = 0; q < 3; q++) trace[q] = p[k].trace[q];
+                    p.erase(p.begin() + (long)k);
+                    return hipSuccess;
+                }
+        }
+        hipError_t e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+        for (int q = 0; q < 3 && e == hipSuccess; q++) e = hipStreamCreateWithFlags(&trace[q], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&ev0);
+        if (e == hipSuccess) e = hipEventCreate(&ev1);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&arrived, hipEventDisableTiming);
+        return e;
+    }
+    ~StreamSet() {
+        if (!copy || !trace[0] || !trace[1] || !trace[2] || !ev0 || !ev1 || !arrived) return;   // (a failed open: leaked, once)
+        // nothing of this call may still be running on streams the next call will be handed
+        (void)hipStreamSynchronize(copy);
+        for (int q = 0; q < 3; q++) (void)hipStreamSynchronize(trace[q]);
+        std::lock_guard<std::mutex> lock(mutex());
+        pool().push_back(Pooled{device, copy, {trace[0], trace[1], trace[2]}, ev0, ev1, arrived});
+    }
+};
+
 // One host-buffer bundle on one device, in phases (pvt_trace_bundle runs them back to back; pvt_trace_bundle_multi
 // runs one per device and can sum the tallies on the devices in between): upload + trace, fetch the tallies, fetch
 // the event log.
@@ -1884,11 +1992,21 @@ struct HostBundle {
     int* counts = nullptr;
     size_t nrec = 0;
     double ms = 0.0;
+    PhaseClock clock;
+    size_t n_chunks = 1;
+    char* arena = nullptr;              // tallies | rays | counts of the log, one block (ArenaCache)
+    size_t arena_bytes = 0, tally_bytes = 0;
+    int arena_device = -1;
 
     ~HostBundle() {
         if (scene) (void)hipSetDevice(scene->device);
         for (void* b : bufs) (void)hipFree(b);
+        if (arena)
+            if (void* mine = ArenaCache::give(arena_device, arena, arena_bytes)) (void)hipFree(mine);
+        clock.mark("free");
         if (scene) pvt_scene_destroy(scene);
+        clock.mark("scene-destroy");
+        clock.report((size_t)params.n_rays, n_chunks);
     }
     hipError_t dalloc(size_t bytes, void** out) {
         hipError_t e = hipMalloc(out, bytes ? bytes : 8);
@@ -1901,7 +2019,15 @@ struct HostBundle {
         return hipMemcpy2D(dst, pitch_elems * 8, src, pitch_elems * 8, width_elems * 8, n_sets, kind);
     }
 
-    // scene + rays + tallies (seeded with `seed`, or zero) on `device`, trace enqueued and finished
+    // scene + rays + tallies (seeded with `seed`, or zero) on `device`, trace enqueued and finished.
+    //
+    // The rays cross PCIe in CHUNKS and a chunk is traced while the next one is still on its way: the copies go down
+    // one stream, each chunk's launch waits for its own copy and runs on one of three trace streams used in turn (the
+    // drain tail of one launch -- a few long histories -- is covered by the bulk of the next), ray i keeps the
+    // stream seed + ray_offset + i whatever chunk carries it, every launch adds into the same tallies with atomics and
+    // writes the event-log rows of its own rays (inner chunk boundaries are multiples of record_every).  One upload
+    // followed by one launch left the GPU idle for the whole upload: 56 MB at the link's ~50 GB/s is 1.1 ms, the trace
+    // of those 10^6 photons 0.65 ms (profiles/r06_host_io.txt).
     int trace(const PvtSceneTables* tb, const PvtEmitterTables* emitter, const PvtRays* rays, const PvtTraceParams* pp,
               const PvtTallies* seed, bool want_log, int device) {
         tables = tb;
@@ -1913,66 +2039,145 @@ struct HostBundle {
             rc = pvt_scene_set_emitter(scene, emitter);
             if (rc != PVT_OK) return rc;
         }
+        clock.mark("scene");
         const size_t n = (size_t)p->n_rays;
         nR = (size_t)tables->n_recorders; nB = (size_t)tables->total_bins;
         R = nR > 0 ? nR : 1; B = nB > 0 ? nB : 1;
-        PvtRays drays{};
-        if (rays) {
-            void *dp, *dd, *dw;
-            HIP_TRY(dalloc(n * 24, &dp)); HIP_TRY(dalloc(n * 24, &dd)); HIP_TRY(dalloc(n * 8, &dw));
-            HIP_TRY(hipMemcpy(dp, rays->position, n * 24, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(dd, rays->direction, n * 24, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(dw, rays->wavelength, n * 8, hipMemcpyHostToDevice));
-            drays = PvtRays{(const double*)dp, (const double*)dd, (const double*)dw};
-        }
         // tally sets (PvtTraceParams.tally_bundle): the device copies keep the caller's strides, slices move as
         // 2-D copies (one row per set)
         n_sets = p->tally_bundle > 0 ? (size_t)((p->n_rays + p->tally_bundle - 1) / p->tally_bundle) : 1;
         si = n_sets > 1 ? (size_t)p->tally_stride_i64 : 0; sd = n_sets > 1 ? (size_t)p->tally_stride_f64 : 0;
         if (n_sets > 1 && (si < R || si < B || sd < R * 8)) return fail(PVT_ERR_INVALID, "tally strides smaller than a set");
+        if (p->record_every > 0 && !want_log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
+        // ONE allocation for the rays, the tallies and the counts of the log (allocating and freeing device memory is a
+        // large part of a small call); the event records, which can be gigabytes, have their own
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t bytes_i[3] = {((n_sets - 1) * si + R) * 8, ((n_sets - 1) * si + R) * 8, ((n_sets - 1) * si + B) * 8};
-        for (int k = 0; k < 3; k++) { HIP_TRY(dalloc(bytes_i[k], &t_i[k])); HIP_TRY(hipMemset(t_i[k], 0, bytes_i[k])); }
-        HIP_TRY(dalloc(((n_sets - 1) * sd + R * 8) * 8, &t_d));
-        HIP_TRY(hipMemset(t_d, 0, ((n_sets - 1) * sd + R * 8) * 8));
-        if (seed) {   // the trace ADDS into the caller's tallies: seed the device copies with them
+        const size_t bytes_d = ((n_sets - 1) * sd + R * 8) * 8;
+        nrec = p->record_every > 0 ? (size_t)((p->n_rays + p->record_every - 1) / p->record_every) : 0;
+        tally_bytes = up(bytes_i[0]) + up(bytes_i[1]) + up(bytes_i[2]) + up(bytes_d);
+        const size_t ray_bytes = rays ? up(n * 24) * 2 + up(n * 8) : 0;
+        const size_t need = tally_bytes + ray_bytes + up(nrec * 4);
+        arena_device = device;
+        arena = (char*)ArenaCache::take(device, need, &arena_bytes);
+        if (!arena) {
+            HIP_TRY(hipMalloc((void**)&arena, need));
+            arena_bytes = need;
+        }
+        char* at = arena;
+        for (int k = 0; k < 3; k++) { t_i[k] = at; at += up(bytes_i[k]); }
+        t_d = at; at += up(bytes_d);
+        char *dp = nullptr, *dd = nullptr, *dw = nullptr;
+        if (rays) { dp = at; at += up(n * 24); dd = at; at += up(n * 24); dw = at; at += up(n * 8); }
+        if (nrec) {
+            counts = (int*)at; at += up(nrec * 4);
+            void* b1;
+            HIP_TRY(dalloc(nrec * (size_t)p->max_events * kRecWords * 8, &b1));
+            rows = (unsigned long long*)b1;
+        }
+        clock.mark("alloc");
+        // The trace ADDS into the caller's tallies: the device copies start from them.  A caller who hands in zeros (the
+        // reference's trace_bundle always starts from zero, _kernel.pyx:1035-1047) costs a fill on the first trace stream,
+        // no transfer; the other trace streams wait for that fill.
+        bool seeded = false;
+        if (seed) {
+            auto any = [&](const void* base, size_t stride_elems, size_t width_elems) {
+                for (size_t j = 0; j < n_sets && !seeded; j++) {
+                    const unsigned long long* w = (const unsigned long long*)base + j * stride_elems;
+                    for (size_t q = 0; q < width_elems; q++)
+                        if (w[q]) { seeded = true; break; }
+                }
+            };
+            any(seed->rec_distinct, si, nR); any(seed->rec_crossings, si, nR);
+            any(seed->rec_sums, sd, nR * 8); any(seed->rec_bins, si, nB);
+        }
+        if (seeded) {
+            HIP_TRY(hipMemset(arena, 0, tally_bytes));
             HIP_TRY(move(t_i[0], seed->rec_distinct, si, nR, hipMemcpyHostToDevice));
             HIP_TRY(move(t_i[1], seed->rec_crossings, si, nR, hipMemcpyHostToDevice));
             HIP_TRY(move(t_d, seed->rec_sums, sd, nR * 8, hipMemcpyHostToDevice));
             HIP_TRY(move(t_i[2], seed->rec_bins, si, nB, hipMemcpyHostToDevice));
+            HIP_TRY(hipDeviceSynchronize());   // (these ran on the null stream; the streams below do not wait for it)
         }
         PvtTallies dt{(int64_t*)t_i[0], (int64_t*)t_i[1], (double*)t_d, (int64_t*)t_i[2]};
-        PvtEventRecords rec{};
-        if (p->record_every > 0) {
-            if (!want_log) return fail(PVT_ERR_INVALID, "record_every > 0 needs an event log");
-            nrec = (size_t)((p->n_rays + p->record_every - 1) / p->record_every);
-            void *b0, *b1;
-            HIP_TRY(dalloc(nrec * 4, &b0));
-            HIP_TRY(dalloc(nrec * (size_t)p->max_events * kRecWords * 8, &b1));
-            counts = (int*)b0; rows = (unsigned long long*)b1;
-            rec = PvtEventRecords{counts, reinterpret_cast<uint64_t*>(rows)};
+
+        // chunks: about kChunkRays rays each, inner boundaries on multiples of record_every; a launch with tally sets
+        // indexes its sets from its first ray and is not split
+        size_t chunk = n;
+        if (rays && n_sets == 1 && n >= kChunkRays + kChunkRays / 2) {
+            chunk = kChunkRays;
+            if (const char* env = getenv("PVT_HOST_CHUNK_RAYS")) chunk = (size_t)atoll(env) > 0 ? (size_t)atoll(env) : n;   // (tests: force many / one)
+            if (p->record_every > 1) chunk = (chunk + (size_t)p->record_every - 1) / (size_t)p->record_every * (size_t)p->record_every;
+            if (chunk > n) chunk = n;
+        } else if (rays && n_sets == 1 && getenv("PVT_HOST_CHUNK_RAYS") && (size_t)atoll(getenv("PVT_HOST_CHUNK_RAYS")) > 0 && n > 0) {
+            chunk = (size_t)atoll(getenv("PVT_HOST_CHUNK_RAYS"));
+            if (p->record_every > 1) chunk = (chunk + (size_t)p->record_every - 1) / (size_t)p->record_every * (size_t)p->record_every;
+            if (chunk > n) chunk = n;
         }
-        hipEvent_t ev0, ev1;
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
-        HIP_TRY(hipEventRecord(ev0, nullptr));
-        rc = pvt_trace_device_records(scene, rays ? &drays : nullptr, p, &dt, p->record_every > 0 ? &rec : nullptr, nullptr);
-        if (rc != PVT_OK) return rc;
-        HIP_TRY(hipEventRecord(ev1, nullptr));
-        HIP_TRY(hipDeviceSynchronize());
+        n_chunks = n ? (n + chunk - 1) / chunk : 1;
+        StreamSet ss;
+        HIP_TRY(ss.open(device, n_chunks > 1 ? 3 : 1));
+        if (!seeded) {
+            HIP_TRY(hipMemsetAsync(arena, 0, tally_bytes, ss.trace[0]));
+            HIP_TRY(hipEventRecord(ss.arrived, ss.trace[0]));
+            for (int k = 1; k < ss.n_trace; k++) HIP_TRY(hipStreamWaitEvent(ss.trace[k], ss.arrived, 0));
+        }
+        clock.mark("tallies");
+        HIP_TRY(hipEventRecord(ss.ev0, ss.trace[0]));
+        for (size_t k = 0; k < n_chunks && n > 0; k++) {   // (an empty bundle launches nothing)
+            const size_t lo = k * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            hipStream_t st = ss.trace[k % ss.n_trace];
+            PvtRays drays{};
+            if (rays) {
+                HIP_TRY(hipMemcpyAsync(dp + lo * 24, rays->position + lo * 3, (hi - lo) * 24, hipMemcpyHostToDevice, ss.copy));
+                HIP_TRY(hipMemcpyAsync(dd + lo * 24, rays->direction + lo * 3, (hi - lo) * 24, hipMemcpyHostToDevice, ss.copy));
+                HIP_TRY(hipMemcpyAsync(dw + lo * 8, rays->wavelength + lo, (hi - lo) * 8, hipMemcpyHostToDevice, ss.copy));
+                HIP_TRY(hipEventRecord(ss.arrived, ss.copy));
+                HIP_TRY(hipStreamWaitEvent(st, ss.arrived, 0));
+                drays = PvtRays{(const double*)(dp + lo * 24), (const double*)(dd + lo * 24), (const double*)(dw + lo * 8)};
+            }
+            PvtTraceParams pk = params;
+            pk.n_rays = (int64_t)(hi - lo);
+            pk.ray_offset = params.ray_offset + (uint64_t)lo;
+            PvtEventRecords rec{};
+            if (nrec) {
+                const size_t j0 = lo / (size_t)p->record_every;   // (lo is a multiple of record_every)
+                rec = PvtEventRecords{counts + j0, reinterpret_cast<uint64_t*>(rows + j0 * (size_t)p->max_events * kRecWords)};
+            }
+            rc = pvt_trace_device_records(scene, rays ? &drays : nullptr, &pk, &dt, nrec ? &rec : nullptr, st);
+            if (rc != PVT_OK) return rc;
+        }
+        clock.mark("enqueue");
+        for (int k = 1; k < ss.n_trace; k++) {   // the last event waits for every trace stream
+            HIP_TRY(hipEventRecord(ss.arrived, ss.trace[k]));
+            HIP_TRY(hipStreamWaitEvent(ss.trace[0], ss.arrived, 0));
+        }
+        HIP_TRY(hipEventRecord(ss.ev1, ss.trace[0]));
+        HIP_TRY(hipEventSynchronize(ss.ev1));
         float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, ev0, ev1));
-        ms = t;
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
+        HIP_TRY(hipEventElapsedTime(&t, ss.ev0, ss.ev1));
+        ms = t;   // (several chunks: from the start of the upload to the end of the last launch)
+        clock.mark("wait");
         return PVT_OK;
     }
 
     int fetch_tallies(const PvtTallies* out) {
         HIP_TRY(hipSetDevice(scene->device));
+        if (n_sets == 1) {   // the four arrays lie side by side in the block: one transfer, four host copies
+            std::vector<char> host(tally_bytes);
+            HIP_TRY(hipMemcpy(host.data(), arena, tally_bytes, hipMemcpyDeviceToHost));
+            std::memcpy(out->rec_distinct, host.data() + ((char*)t_i[0] - arena), nR * 8);
+            std::memcpy(out->rec_crossings, host.data() + ((char*)t_i[1] - arena), nR * 8);
+            std::memcpy(out->rec_sums, host.data() + ((char*)t_d - arena), nR * 8 * 8);
+            std::memcpy(out->rec_bins, host.data() + ((char*)t_i[2] - arena), nB * 8);
+            clock.mark("fetch-tallies");
+            return PVT_OK;
+        }
         HIP_TRY(move(out->rec_distinct, t_i[0], si, nR, hipMemcpyDeviceToHost));
         HIP_TRY(move(out->rec_crossings, t_i[1], si, nR, hipMemcpyDeviceToHost));
         HIP_TRY(move(out->rec_sums, t_d, sd, nR * 8, hipMemcpyDeviceToHost));
         HIP_TRY(move(out->rec_bins, t_i[2], si, nB, hipMemcpyDeviceToHost));
+        clock.mark("fetch-tallies");
         return PVT_OK;
     }
 
@@ -2045,6 +2250,8 @@ int pvt_trace_bundle(const PvtSceneTables* tables, const PvtEmitterTables* emitt
     if (rc != PVT_OK) return rc;
     return hb.fetch_log(log);
 }
+
+void pvt_release_cached_memory(void) { ArenaCache::release_all(); }
 
 int pvt_shard_range(int64_t n_rays, int shard, int n_shards, int64_t align, int64_t* start, int64_t* stop) {
     if (n_rays < 0 || n_shards <= 0 || shard < 0 || shard >= n_shards || !start || !stop)

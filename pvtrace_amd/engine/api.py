@@ -281,6 +281,28 @@ def _default_device():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+_PINNED_FROM = 1 << 20   # bytes: smaller results take the plain pageable road
+
+
+def to_host(tensor):
+    """A device tensor -> a host numpy array.  Results of a megabyte and more land in PINNED host memory from torch's
+    caching host allocator: a fresh pageable array is committed page by page while the copy runs (5-8 GB/s measured on
+    the GPU box for 56-512 MB, `profiles/r06_host_io.txt`) whereas a pinned block moves at the link's rate (50 GB/s)
+    and, once the result that owns it has been dropped, is handed out again by the allocator without being faulted in
+    a second time.  The array keeps its block alive (numpy `base`); nothing here is shared between results."""
+    nbytes = tensor.numel() * tensor.element_size()
+    if nbytes < _PINNED_FROM or os.environ.get("PVT_NO_PINNED_RESULTS"):
+        return tensor.cpu().numpy()
+    import torch
+
+    try:
+        host = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+    except RuntimeError:   # (no page-locked memory to be had: the pageable road still works)
+        return tensor.cpu().numpy()
+    host.copy_(tensor)
+    return host.numpy()
+
+
 def download(compiled, tallies, log, n_rays, record_every, max_events, packed=False):
     """Device buffers -> the reference's `data` dict (host numpy).  `packed`: keep only the written
     rows of the event log (plus `row_start`, see `EngineResult.packed`) instead of rebuilding the
@@ -288,7 +310,7 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
     nrec = int(compiled.rec_node.shape[0])
     n_recorded = native.num_recorded(n_rays, record_every)
     rows = n_recorded * max_events
-    data = {"counts": (log["counts"][:n_recorded].cpu().numpy() if log is not None
+    data = {"counts": (to_host(log["counts"][:n_recorded]) if log is not None
                        else np.zeros(0, dtype=np.int32))}
     if "_ints" in tallies:   # DeviceScene.new_tallies(): distinct | crossings | bins share one buffer
         ints = tallies["_ints"].cpu().numpy()
@@ -338,12 +360,12 @@ def download(compiled, tallies, log, n_rays, record_every, max_events, packed=Fa
         columns = {"kind": i32[:, 5].to(torch.uint8), "hit": i32[:, 0], "container": i32[:, 1], "adjacent": i32[:, 2],
                    "component": i32[:, 3], "source": i32[:, 4], "position": f64[:, 3:6], "direction": f64[:, 6:9],
                    "normal": f64[:, 9:12], "wavelength": f64[:, 12], "travelled": f64[:, 13], "duration": f64[:, 14]}
-        written = {name: col.contiguous().cpu().numpy() for name, col in columns.items()}
+        written = {name: to_host(col.contiguous()) for name, col in columns.items()}
         del picked, i32, f64, columns
     if packed:
         data.update(written)
         return data
-    index_host = index.cpu().numpy()
+    index_host = to_host(index)
 
     def dense(name, dtype, width):
         def build():
@@ -417,12 +439,15 @@ def _release_scene(key, dscene):
 
 
 def release_resident_scenes():
-    """Free every scene kept on a GPU for reuse (also run at interpreter exit)."""
+    """Free every scene kept on a GPU for reuse, and the device block the host-buffer entry keeps between calls
+    (also run at interpreter exit)."""
     with _RESIDENT_LOCK:
         held = [d for _, d in _RESIDENT]
         del _RESIDENT[:]
     for d in held:
         d.close()
+    if native._lib is not None:
+        native._lib.pvt_release_cached_memory()
 
 
 __import__("atexit").register(release_resident_scenes)

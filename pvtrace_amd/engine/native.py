@@ -246,6 +246,7 @@ def declare_signatures(lib, names):
             [C.POINTER(PvtSceneTables), C.POINTER(PvtEmitterTables), C.POINTER(PvtRays),
              C.POINTER(PvtTraceParams), C.POINTER(PvtTallies), C.POINTER(PvtEventLog), C.POINTER(C.c_int),
              C.c_int, C.POINTER(C.c_double)], C.c_int),
+        "pvt_release_cached_memory": ([], None),
         "pvt_shard_range": ([C.c_int64, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
         "pvt_emit_device": ([vp, C.POINTER(PvtTraceParams), vp, vp, vp, vp], C.c_int),
         "pvt_selftest_math": ([C.c_int, vp, vp, C.c_int64, C.c_int], C.c_int),
@@ -275,11 +276,11 @@ ABI_SYMBOLS = (
     "pvt_emit_device", "pvt_selftest_math", "pvt_scene_launch_info", "pvt_mesh_bvh_check",
     "pvt_trace_bundle_multi", "pvt_shard_range", "pvt_trace_device_records", "pvt_unpack_records_device",
     "pvt_scene_carry_pending", "pvt_last_multi_reduce", "pvt_node_grid_plan", "pvt_scene_carry_discard", "pvt_scene_trim",
-    "pvt_scene_counters", "pvt_scene_clock", "pvt_scene_launch_span",
+    "pvt_scene_counters", "pvt_scene_clock", "pvt_scene_launch_span", "pvt_release_cached_memory",
 )
 
 _lib = None
-ABI_VERSION = 12  # include/pvtrace_hip.h PVT_ABI_VERSION
+ABI_VERSION = 13  # include/pvtrace_hip.h PVT_ABI_VERSION
 FLAG_NO_LOG_PREFILL = 1   # PvtTraceParams.flags
 FLAG_CARRY_OUT = 2        # park the photons still alive at the end of the launch for the next launch on the stream
 

@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol(built):
     lib = native.load_library()
     for name in names:
         assert hasattr(lib, name), name
-    assert lib.pvt_abi_version() == 12 == native.ABI_VERSION
+    assert lib.pvt_abi_version() == 13 == native.ABI_VERSION
     # the embedded device code object really targets gfx950
     blob = open(native.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
