@@ -287,6 +287,9 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
+    # (ranks started by somebody else's launcher -- the driver's torch.distributed.run line -- get the same setting
+    # spawn_ranks gives its own: dmabuf IPC, without which RCCL cannot share device memory across processes here)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
     import torch
@@ -746,6 +749,7 @@ def main():
         return out
 
     printed = threading.Lock()
+    line_is_out = threading.Event()   # set once the line has been written (whoever wrote it)
 
     def report(more_errors=()):
         """Rank 0's ONE line, from whatever has been measured when it is called: at the end of the run, or -- from the
@@ -844,6 +848,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and leg.array_input:   # the CPU referee is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(leg.compiled, *leg.host_rays)
         print(json.dumps(out), flush=True)
+        line_is_out.set()
 
 
     def watch_for_a_lost_rank():
@@ -863,6 +868,9 @@ def main():
                 got = os.read(r_fd, 1)
                 if got and got[0] == signal.SIGTERM:
                     report(["the launcher ended this rank (SIGTERM): another rank was lost during a leg after the timed region"])
+                    # (the main thread may be in the middle of writing the line itself -- it reads the PMC summaries and hashes
+                    # the library's code first, a few hundred milliseconds: leaving now would take the line with it)
+                    line_is_out.wait(20.0)
                     os._exit(1)
 
         threading.Thread(target=waiter, daemon=True).start()
