@@ -448,6 +448,14 @@ def release_resident_scenes():
         d.close()
     if native._lib is not None:
         native._lib.pvt_release_cached_memory()
+    # the pinned blocks dropped results gave back to torch's host allocator (`to_host`); blocks of results still alive stay
+    torch = __import__("sys").modules.get("torch")
+    empty = getattr(getattr(torch, "_C", None), "_host_emptyCache", None) if torch is not None else None
+    if empty is not None:
+        try:
+            empty()
+        except Exception:   # noqa: BLE001 -- a private entry of torch: its absence or refusal is not this call's failure
+            pass
 
 
 __import__("atexit").register(release_resident_scenes)

@@ -448,9 +448,22 @@ class Surface(BaseSurface):
 # ----------------------------------------------------------------------
 # Volume components (reference material/component.py:33-440)
 
-class Component(object):
+def _spectrum(value, x, hist, what):
+    """A constant, an (n, 2) table or a list of callables sampled on `x` -> `Distribution` (the three spellings the
+    reference's components accept for a coefficient or an emission spectrum, component.py:64-90, :327-350)."""
+    if isinstance(value, np.ndarray):
+        return Distribution(x=value[:, 0], y=value[:, 1], hist=hist)
+    if isinstance(value, (list, tuple)):
+        if x is None:
+            raise ValueError(f"{what} given as callables needs `x`, the wavelengths to sample them on.")
+        return Distribution.from_functions(x, value, hist=hist)
+    if isinstance(value, float):
+        return Distribution(x=None, y=value, hist=hist)
+    raise ValueError(f"{what}: expected a number, an (n, 2) array or a list of callables, got {type(value).__name__}.")
+
+
+class Component:
     def __init__(self, name="Component"):
-        super(Component, self).__init__()
         self.name = name
 
     def is_radiative(self, ray):
@@ -463,49 +476,22 @@ class Component(object):
 class Scatterer(Component):
     """Scattering centre with attenuation coefficient (cm^-1), constant or spectral."""
 
-    def __init__(
-        self,
-        coefficient,
-        x=None,
-        quantum_yield=1.0,
-        tau_rad=None,
-        tau_nr=None,
-        phase_function=None,
-        hist=False,
-        name="Scatterer",
-    ):
-        super(Scatterer, self).__init__(name=name)
+    def __init__(self, coefficient, x=None, quantum_yield=1.0, tau_rad=None, tau_nr=None, phase_function=None,
+                 hist=False, name="Scatterer"):
+        super().__init__(name=name)
         if coefficient is None:
-            raise ValueError("Coefficient must be specified.")
+            raise ValueError("A component needs an attenuation coefficient.")
         if isinstance(coefficient, (int, np.integer, np.floating)) and not isinstance(coefficient, bool):
             coefficient = float(coefficient)
         self._coefficient = coefficient
-        if isinstance(coefficient, float):
-            self._abs_dist = Distribution(x=None, y=coefficient, hist=hist)
-        elif isinstance(coefficient, np.ndarray):
-            self._abs_dist = Distribution(
-                x=coefficient[:, 0], y=coefficient[:, 1], hist=hist
-            )
-        elif isinstance(coefficient, (list, tuple)):
-            if x is None:
-                raise ValueError("Requires `x`.")
-            self._abs_dist = Distribution.from_functions(x, coefficient, hist=hist)
-        else:
-            raise ValueError("coefficient must be a float, an (n, 2) array or callables.")
-
-        qy = float("nan")
-        if tau_rad is not None and tau_nr is not None:
-            qy = tau_nr / (tau_nr + tau_rad)
-        elif quantum_yield is not None:
-            qy = quantum_yield
+        self._abs_dist = _spectrum(coefficient, x, hist, "coefficient")
+        # two lifetimes fix the yield; otherwise it is given (reference component.py:92-104)
+        both = tau_rad is not None and tau_nr is not None
+        qy = tau_nr / (tau_nr + tau_rad) if both else (float("nan") if quantum_yield is None else quantum_yield)
         if not np.isfinite(qy):
-            raise ValueError(
-                "Specify either `quantum yield` or both `tau_rad` and `tau_nr`"
-            )
-        self.quantum_yield = qy
-        self.tau_rad = tau_rad
-        self.tau_nr = tau_nr
-        self.phase_function = isotropic if phase_function is None else phase_function
+            raise ValueError("Give `quantum_yield`, or both `tau_rad` and `tau_nr`.")
+        self.quantum_yield, self.tau_rad, self.tau_nr = qy, tau_rad, tau_nr
+        self.phase_function = phase_function or isotropic
 
     def coefficient(self, wavelength):
         return self._abs_dist(wavelength)
@@ -529,16 +515,7 @@ class Absorber(Scatterer):
     """Non-radiative absorber (quantum yield 0)."""
 
     def __init__(self, coefficient, x=None, tau_nr=None, name="Absorber", hist=False):
-        super(Absorber, self).__init__(
-            coefficient,
-            x=x,
-            quantum_yield=0.0,
-            tau_nr=tau_nr,
-            tau_rad=0.0,
-            phase_function=None,
-            hist=hist,
-            name=name,
-        )
+        super().__init__(coefficient, x=x, quantum_yield=0.0, tau_rad=0.0, tau_nr=tau_nr, hist=hist, name=name)
 
     def is_radiative(self, ray):
         return False   # (and no draw, as in the reference, component.py:236-239)
@@ -548,47 +525,22 @@ class Reactor(Absorber):
     """Absorber whose absorptions are tallied as photochemical reactions."""
 
     def __init__(self, coefficient, x=None, name="Reactor", hist=False):
-        super(Reactor, self).__init__(coefficient, x=x, hist=hist, name=name)
+        super().__init__(coefficient, x=x, hist=hist, name=name)
 
 
 class Luminophore(Scatterer):
     """Absorbs and re-emits with a new wavelength drawn from `emission`."""
 
-    def __init__(
-        self,
-        coefficient,
-        emission=None,
-        x=None,
-        hist=False,
-        quantum_yield=1.0,
-        tau_rad=None,
-        tau_nr=None,
-        phase_function=None,
-        name="Luminophore",
-    ):
-        super(Luminophore, self).__init__(
-            coefficient,
-            x=x,
-            quantum_yield=quantum_yield,
-            tau_rad=tau_rad,
-            tau_nr=tau_nr,
-            phase_function=phase_function,
-            hist=hist,
-            name=name,
-        )
+    def __init__(self, coefficient, emission=None, x=None, hist=False, quantum_yield=1.0, tau_rad=None, tau_nr=None,
+                 phase_function=None, name="Luminophore"):
+        super().__init__(coefficient, x=x, quantum_yield=quantum_yield, tau_rad=tau_rad, tau_nr=tau_nr,
+                         phase_function=phase_function, hist=hist, name=name)
         self._emission = emission
-        if emission is None:
-            self._ems_dist = Distribution.from_functions(
-                x, [lambda v: gaussian(v, 1.0, 600.0, 40.0)], hist=hist
-            )
-        elif isinstance(emission, np.ndarray):
-            self._ems_dist = Distribution(x=emission[:, 0], y=emission[:, 1], hist=hist)
-        elif isinstance(emission, (tuple, list)):
-            if x is None:
-                raise ValueError("Requires `x`.")
-            self._ems_dist = Distribution.from_functions(x, emission, hist=hist)
-        else:
-            raise ValueError("Luminophore `emission` arg has wrong type.")
+        if emission is None:   # the reference's default line: a Gaussian at 600 nm, 40 nm wide (component.py:330-335)
+            emission = [lambda v: gaussian(v, 1.0, 600.0, 40.0)]
+        elif isinstance(emission, float):
+            raise ValueError("emission: expected an (n, 2) array or a list of callables.")
+        self._ems_dist = _spectrum(emission, x, hist, "emission")
 
     def emit(self, ray, method="kT", T=300.0, **kwargs):
         """Re-emitted (reference component.py:381-440; draws in its order: phase function, wavelength, delay): a new
