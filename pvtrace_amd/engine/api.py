@@ -281,7 +281,8 @@ def _default_device():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
-_PINNED_FROM = 1 << 20   # bytes: smaller results take the plain pageable road
+_PINNED_FROM = 1 << 20   # bytes: smaller results take the plain pageable road,
+_PINNED_UP_TO = 1 << 30  # and so do arrays beyond a gigabyte each (page-locking that much of the host is not this call's to decide)
 
 
 def to_host(tensor):
@@ -291,7 +292,7 @@ def to_host(tensor):
     and, once the result that owns it has been dropped, is handed out again by the allocator without being faulted in
     a second time.  The array keeps its block alive (numpy `base`); nothing here is shared between results."""
     nbytes = tensor.numel() * tensor.element_size()
-    if nbytes < _PINNED_FROM or os.environ.get("PVT_NO_PINNED_RESULTS"):
+    if nbytes < _PINNED_FROM or nbytes > _PINNED_UP_TO or os.environ.get("PVT_NO_PINNED_RESULTS"):
         return tensor.cpu().numpy()
     import torch
 
