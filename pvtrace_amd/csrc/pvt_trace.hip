@@ -2104,15 +2104,17 @@ struct HostBundle {
         // chunks: about kChunkRays rays each, inner boundaries on multiples of record_every; a launch with tally sets
         // indexes its sets from its first ray and is not split
         size_t chunk = n;
-        if (rays && n_sets == 1 && n >= kChunkRays + kChunkRays / 2) {
-            chunk = kChunkRays;
-            if (const char* env = getenv("PVT_HOST_CHUNK_RAYS")) chunk = (size_t)atoll(env) > 0 ? (size_t)atoll(env) : n;   // (tests: force many / one)
-            if (p->record_every > 1) chunk = (chunk + (size_t)p->record_every - 1) / (size_t)p->record_every * (size_t)p->record_every;
-            if (chunk > n) chunk = n;
-        } else if (rays && n_sets == 1 && getenv("PVT_HOST_CHUNK_RAYS") && (size_t)atoll(getenv("PVT_HOST_CHUNK_RAYS")) > 0 && n > 0) {
-            chunk = (size_t)atoll(getenv("PVT_HOST_CHUNK_RAYS"));
-            if (p->record_every > 1) chunk = (chunk + (size_t)p->record_every - 1) / (size_t)p->record_every * (size_t)p->record_every;
-            if (chunk > n) chunk = n;
+        if (rays && n_sets == 1 && n > 0) {
+            size_t want = n >= kChunkRays + kChunkRays / 2 ? kChunkRays : n;
+            if (const char* env = getenv("PVT_HOST_CHUNK_RAYS")) {   // (tests: 0 = one upload and one launch, k = chunks of k rays)
+                const long long k = atoll(env);
+                want = k > 0 ? (size_t)k : n;
+            }
+            if (p->record_every > 1) {   // inner boundaries on multiples of record_every: a chunk's recorded rays are whole rows of the log
+                const size_t re = (size_t)p->record_every;
+                want = (want + re - 1) / re * re;
+            }
+            chunk = want < n ? want : n;
         }
         n_chunks = n ? (n + chunk - 1) / chunk : 1;
         StreamSet ss;
