@@ -50,3 +50,26 @@ def test_default_chunking_of_a_large_bundle_matches_the_unsplit_call(monkeypatch
     whole = _kernel.trace_bundle(compiled, pos, dirs, wl, 5, 1000, 2, 0, 1, 0)
     _same(split, whole, "default chunks")
     assert split["rec_distinct"].sum() > n // 2 and timing["kernel_ms"] > 0
+
+
+def test_the_kept_device_block_can_be_released_and_is_not_needed(monkeypatch):
+    """The host-buffer entry keeps the device block of a call for the next one (ABI v13); `pvt_release_cached_memory`
+    frees it, PVT_NO_HOST_CACHE never keeps it: the same numbers every way, a smaller bundle after a larger one included
+    (the kept block is larger than it needs: stale rays beyond its own must never be read)."""
+    from pvtrace_amd.engine import native
+
+    lib = native.load_library()
+    scene = scenes.ALL_SCENES["lsc_equivalent"]()
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, 30_000, seed=2)
+    big = _kernel.trace_bundle(compiled, pos, dirs, wl, 3, 1000, 16, 0, 1, 5)
+    small = _kernel.trace_bundle(compiled, pos[:7001], dirs[:7001], wl[:7001], 3, 1000, 16, 0, 1, 5)   # in the block `big` left
+    lib.pvt_release_cached_memory()
+    lib.pvt_release_cached_memory()                                                                   # (nothing kept: a no-op)
+    small_again = _kernel.trace_bundle(compiled, pos[:7001], dirs[:7001], wl[:7001], 3, 1000, 16, 0, 1, 5)
+    monkeypatch.setenv("PVT_NO_HOST_CACHE", "1")
+    big_again = _kernel.trace_bundle(compiled, pos, dirs, wl, 3, 1000, 16, 0, 1, 5)
+    _same(small_again, small, "after release")
+    _same(big_again, big, "without the cache")
+    cpu = O.trace_bundle(compiled, pos[:7001], dirs[:7001], wl[:7001], 3, 1000, 16, 0, 4, 5, math_mode=O.MATH_PORTABLE)
+    _same(small, cpu, "small bundle in a larger kept block")
