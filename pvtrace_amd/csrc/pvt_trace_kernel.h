@@ -732,13 +732,6 @@ struct Seen {
 #ifndef PVT_TAIL_LAZY
 #define PVT_TAIL_LAZY 1   // (0: a developer build whose tail function intersects the root wherever the kernels' loop does)
 #endif
-#ifndef PVT_TAIL_SPREAD_MIN_NODES
-#define PVT_TAIL_SPREAD_MIN_NODES 3   // (scenes of two nodes -- a body in its lazy root -- have one intersection per step: nothing to put side by side)
-#endif
-#ifndef PVT_TAIL_SPREAD
-#define PVT_TAIL_SPREAD 0   // (1: a developer build whose tail function tests a photon's nodes side by side, one lane each -- built, bit-identical,
-                            // measured and NOT faster: profiles/r06_coop_tail.txt)
-#endif
 #ifndef PVT_TAIL_ALPHA
 #define PVT_TAIL_ALPHA 1   // (0: a developer build whose tail function looks the absorption coefficients up in every step)
 #endif
@@ -1491,99 +1484,6 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
         int hit = -1, container = -1, adjacent = -1;
         double t0 = 0.0;
         bool pend = false;   // reaches the exit / absorption / surface decision
-        // ---- (tail function) a photon's nodes tested SIDE BY SIDE, one lane each ---------------------------------------
-        // A wave that finishes a workgroup's last photons has a handful of live lanes and sixty idle ones, and what it waits for
-        // is its own chain of dependent instructions: the node loop below costs it one intersection after the other (scene
-        // of k nodes: k transforms, k quadratics with their square roots and divisions), the lanes' results needed only at
-        // the end.  With live x k <= 64 the photon of rank r (among the live lanes) lends its ray to lanes r k ... r k + k - 1,
-        // lane r k + j intersects node j of the loop's order with it -- the same operations on the same operands, per-lane
-        // records from the tables -- and leaves its crossings in LDS in the order it found them; the photon's own lane then
-        // folds them node by node, crossing by crossing, exactly as the loop would have met them (the lazy root's bound
-        // included: its lane also works out the exact crossings, which the fold takes when the bound cannot decide).  Same
-        // bits, one intersection's latency instead of k.  The exchange goes through the workgroup's photon-exchange buffer,
-        // which the tail function owns (words 256 ... 639; the absorption-coefficient cache above uses 0 ... 255).
-        // MEASURED (round 6, profiles/r06_coop_tail.txt; 194 parity tests and 400 fuzz scenes identical either way): the
-        // three LDS round trips of the exchange cost a lone wave ~0.45 us per step, an analytic shape's intersection only
-        // ~0.2 us -- cfg4's lone 10^7 launch 5.57-5.60 ms without, 5.86-5.91 ms with; the slab's lone step 2.39-2.49 us
-        // without, 2.82 with (from two nodes on).  The step's time is not in its node tests.  OFF in the tree (PVT_TAIL_SPREAD).
-        constexpr bool kSpread = TAIL && PVT_TAIL_SPREAD && !GRID && !MESH;
-        bool sp_on = false;      // wave-uniform
-        int sp_base = 0;         // (owner) its first worker lane
-        unsigned long long* const sp_lds = xbuf + 256;   // [10][64]: ray in (6 rows), then crossings out (4 rows t, 1 row count, 1 row bound)
-        if constexpr (kSpread) {
-            const unsigned long long lm = __ballot(alive);
-            const int nlive = __popcll(lm);
-            sp_on = k_nodes >= PVT_TAIL_SPREAD_MIN_NODES && nlive > 0 && nlive * k_nodes <= 64;
-            if (sp_on) {
-                const int lz = (PVT_TAIL_LAZY && (uf(UF_TAIL_LAZY1) || uf(UF_TAIL_LAZY2))) ? (uf(UF_TAIL_LAZY1) ? 1 : 2)
-                                                                                             : (RECORD ? 0 : (uf(UF_LAZY1) ? 1 : (uf(UF_LAZY2) ? 2 : 0)));
-                sp_base = (int)rank_in(lm) * k_nodes;
-                // the rays out: every live lane its own column
-                sp_lds[0 * 64 + lane] = pvt_d2u(pos.x); sp_lds[1 * 64 + lane] = pvt_d2u(pos.y); sp_lds[2 * 64 + lane] = pvt_d2u(pos.z);
-                sp_lds[3 * 64 + lane] = pvt_d2u(dir.x); sp_lds[4 * 64 + lane] = pvt_d2u(dir.y); sp_lds[5 * 64 + lane] = pvt_d2u(dir.z);
-                // which photon, which node
-                const int r = (int)(((float)lane + 0.5f) * (1.0f / (float)k_nodes));   // lane / k (exact: the fraction is >= 0.5 / k off an integer)
-                const int j = lane - r * k_nodes;
-                int src = 0;
-                {
-                    unsigned long long m = lm;
-                    for (int q = 0; m != 0ull; q++) {   // the r-th live lane (a handful of scalar trips)
-                        const int b = __builtin_ctzll(m);
-                        m &= m - 1ull;
-                        src = (q == r) ? b : src;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const bool work = r < nlive;
-                double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, bound = 0.0;
-                int nl = 0;
-                if (work) {
-                    const V3 wp{pvt_u2d(sp_lds[0 * 64 + src]), pvt_u2d(sp_lds[1 * 64 + src]), pvt_u2d(sp_lds[2 * 64 + src])};
-                    const V3 wd{pvt_u2d(sp_lds[3 * 64 + src]), pvt_u2d(sp_lds[4 * 64 + src]), pvt_u2d(sp_lds[5 * 64 + src])};
-                    const int node = !lz ? j : (j == k_nodes - 1 ? k_root : (j < k_root ? j : j + 1));
-                    const int hn = node * ND;
-                    const double tx = T.dv(hn + ND_T), ty = T.dv(hn + ND_T + 1), tz = T.dv(hn + ND_T + 2);
-                    const double g0 = T.dv(hn + ND_PARAMS), g1 = T.dv(hn + ND_PARAMS + 1), g2 = T.dv(hn + ND_PARAMS + 2);
-                    const unsigned long long hb = pvt_d2u(T.dv(hn + ND_BITS));
-                    const int gt = (int)(((unsigned int)hb >> 8) & 0xffu);
-                    V3 o, dl;
-                    if ((hb & 1ull) != 0) {
-                        o.x = wp.x + tx; o.y = wp.y + ty; o.z = wp.z + tz;
-                        dl = wd;
-                    } else {
-                        const int rm = L.rot_d + (int)(unsigned int)(hb >> 32) * RT + RT_W2L;
-                        o.x = T.dv(rm + 0) * wp.x + T.dv(rm + 1) * wp.y + T.dv(rm + 2) * wp.z + tx;
-                        o.y = T.dv(rm + 3) * wp.x + T.dv(rm + 4) * wp.y + T.dv(rm + 5) * wp.z + ty;
-                        o.z = T.dv(rm + 6) * wp.x + T.dv(rm + 7) * wp.y + T.dv(rm + 8) * wp.z + tz;
-                        dl.x = T.dv(rm + 0) * wd.x + T.dv(rm + 1) * wd.y + T.dv(rm + 2) * wd.z;
-                        dl.y = T.dv(rm + 3) * wd.x + T.dv(rm + 4) * wd.y + T.dv(rm + 5) * wd.z;
-                        dl.z = T.dv(rm + 6) * wd.x + T.dv(rm + 7) * wd.y + T.dv(rm + 8) * wd.z;
-                    }
-                    if (lz && node == k_root) {   // (the loop's bound, below: same expressions)
-                        if (lz == 1) bound = __builtin_fmin(__builtin_fmin(0.5 * g0 - pvt_fabs(o.x), 0.5 * g1 - pvt_fabs(o.y)), 0.5 * g2 - pvt_fabs(o.z));
-                        else bound = (g0 * g0 - dot3(o, o)) * A.lazy_k;
-                    }
-                    double il0 = 0.0, il1 = 0.0, il2 = 0.0;
-                    if (gt == PVT_GEOM_BOX) { il0 = rcp_normal(dl.x); il1 = rcp_normal(dl.y); il2 = rcp_normal(dl.z); }
-                    auto note = [&](double t) __attribute__((always_inline)) {
-                        const int have = nl;
-                        c0 = have == 0 ? t : c0; c1 = have == 1 ? t : c1; c2 = have == 2 ? t : c2; c3 = have == 3 ? t : c3;
-                        nl = have + 1;
-                    };
-                    shape_hits(gt, g0, g1, g2, o, dl, il0, il1, il2, note);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();   // (every worker has read its ray: the columns are reused for the answers)
-                sp_lds[0 * 64 + lane] = pvt_d2u(c0); sp_lds[1 * 64 + lane] = pvt_d2u(c1);
-                sp_lds[2 * 64 + lane] = pvt_d2u(c2); sp_lds[3 * 64 + lane] = pvt_d2u(c3);
-                sp_lds[4 * 64 + lane] = (unsigned long long)(unsigned int)nl; sp_lds[5 * 64 + lane] = pvt_d2u(bound);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
         if (alive) {
             count += 1;
             bool budget_kill = false;
@@ -1814,50 +1714,7 @@ __device__ __forceinline__ void trace_body(const KArgs& A, int tail_total = 0, u
                     }
                 }
                 // (grid scenes have visited every node they need by now)
-                bool sp_done = false;   // wave-uniform
-                if constexpr (kSpread) {
-                    if (sp_on) {   // the crossings the node lanes left, folded in the loop's order (see above)
-                        sp_done = true;
-                        for (int j = 0; j < k_nodes; j++) {
-                            const int node = !lazy_root ? j : (j == k_nodes - 1 ? k_root : (j < k_root ? j : j + 1));
-                            const int at = sp_base + j;
-                            const double q0 = pvt_u2d(sp_lds[0 * 64 + at]), q1 = pvt_u2d(sp_lds[1 * 64 + at]);
-                            const double q2 = pvt_u2d(sp_lds[2 * 64 + at]), q3 = pvt_u2d(sp_lds[3 * 64 + at]);
-                            const int found = (int)(unsigned int)sp_lds[4 * 64 + at];
-                            int nl = 0;
-                            double tfirst = 0.0;
-                            bool root_known = false;
-                            if (lazy_root && node == k_root) {
-                                const double bound = pvt_u2d(sp_lds[5 * 64 + at]);
-                                const bool undecided = !(bound > 0.0) || (nhits > 0 && !(t1 < bound)) || (nhits >= 2 && !(t2 < bound)) ||
-                                                       (cnode >= 0 && !(cbest < bound)) || (lazy_exact && nhits == 0);
-                                if (!undecided) {
-                                    if (nhits == 0) { t1 = bound; n1 = node; }
-                                    else if (nhits == 1) { t2 = INFINITY; n2 = node; }
-                                    nhits += 1;
-                                    if (cnode < 0) cnode = node;
-                                    root_known = true;
-                                }
-                            }
-                            auto fold = [&](double t) __attribute__((always_inline)) {
-                                if (nl == 0) tfirst = t;
-                                nl += 1;
-                                if (nhits == 0) { t1 = t; n1 = node; }
-                                else if (t < t1) { t2 = t1; n2 = n1; t1 = t; n1 = node; }
-                                else if (n2 < 0 || t < t2) { t2 = t; n2 = node; }
-                                nhits += 1;
-                            };
-                            if (!root_known) {
-                                if (found > 0) fold(q0);
-                                if (found > 1) fold(q1);
-                                if (found > 2) fold(q2);
-                                if (found > 3) fold(q3);
-                            }
-                            if (nl == 1 && !root_known && tfirst < cbest) { cbest = tfirst; cnode = node; }
-                        }
-                    }
-                }
-                for (int k = 0; k < ((GRID || sp_done) ? 0 : k_nodes); k++) {
+                for (int k = 0; k < (GRID ? 0 : k_nodes); k++) {
                     const int node = !lazy_root ? k : (k == k_nodes - 1 ? k_root : (k < k_root ? k : k + 1));
                     // An unrotated node (identity rotation, bit for bit -- the usual case) only translates:
                     // 1*x + 0*y + 0*z + t equals x + t up to the sign of a zero, which no comparison,

@@ -3,6 +3,7 @@
 # the same tree built without it (build/dev/spread0.so: -DPVT_TAIL_SPREAD=0) and with it from two nodes on
 # (build/dev/spread2.so: -DPVT_TAIL_SPREAD_MIN_NODES=2), same box: parity first, then the lone wave's step, lone cfg4
 # launches (the 1000-step photon), lone cfg2 launches, and the bench's stream.
+# (The variant is kept as profiles/r06_coop_tail.patch, not in the tree: apply it first, then build spread0 / spread2 with tools/dev_build_full.sh.)
 # usage: tools/gpu_spread_ab.sh [fuzz-count]
 mkdir -p gpurun_out
 {
