@@ -73,3 +73,17 @@ def test_the_kept_device_block_can_be_released_and_is_not_needed(monkeypatch):
     _same(big_again, big, "without the cache")
     cpu = O.trace_bundle(compiled, pos[:7001], dirs[:7001], wl[:7001], 3, 1000, 16, 0, 4, 5, math_mode=O.MATH_PORTABLE)
     _same(small, cpu, "small bundle in a larger kept block")
+
+
+def test_chunks_inside_the_shards_of_a_device_list(monkeypatch):
+    """`pvt_trace_bundle_multi` gives every entry of the device list a shard, and every shard uploads in chunks of its own:
+    shard edges and chunk edges on multiples of record_every, every ray still on the stream seed + global index."""
+    n, seed, every, max_events = 20_011, 41, 7, 12
+    scene = scenes.ALL_SCENES["nested_cylinders"]()
+    compiled = compile_scene(scene)
+    pos, dirs, wl, _ = emit_bundle(scene, n, seed=6)
+    cpu = O.trace_bundle(compiled, pos, dirs, wl, seed, 1000, max_events, 0, 4, every, math_mode=O.MATH_PORTABLE)
+    monkeypatch.setenv("PVT_HOST_CHUNK_RAYS", "1500")
+    for devices in ([0, 0], [0, 0, 0]):
+        got = _kernel.trace_bundle(compiled, pos, dirs, wl, seed, 1000, max_events, 0, 1, every, devices=devices)
+        _same(got, cpu, f"devices {devices}, chunks of 1500")
